@@ -1,0 +1,366 @@
+// gsr_math.h -- per-Gaussian and per-(pixel,Gaussian) arithmetic of the splat rasteriser.
+//
+// Pure scalar float32 functions, usable from HIP kernels (hipcc) and from a host C++ test harness
+// (g++; tests/host_math) so that the exact source the kernels run is checked against the oracle on
+// CPU before any GPU time is spent.  No reference code: formulas follow SURVEY.md section 8(a)
+// (rows a4, a6, a8, a9) and the in-tree Python twins cited there
+// (utils/sh_utils.py:57-112, utils/general_utils.py:78-110, utils/graphics_utils.py:38-71).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GSR_HD __host__ __device__ __forceinline__
+#else
+#define GSR_HD inline
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GSR_EXP(x) __expf(x)
+#else
+#define GSR_EXP(x) expf(x)
+#endif
+
+namespace gsr {
+
+constexpr int TILE = 16;            // 16x16-pixel tiles
+constexpr int NUM_OBJ = 16;         // object-feature channels (scene/gaussian_model.py:52)
+constexpr float NEAR_Z = 0.2f;      // view-space near cull
+constexpr float FOV_CLAMP = 1.3f;   // t.x/t.z clamp, in units of tanfov
+constexpr float DILATE = 0.3f;      // px^2 added to the 2D covariance diagonal
+constexpr float ALPHA_CAP = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_STOP = 1e-4f;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+
+// Per-view constants, filled on the device from the settings' device tensors.
+struct View {
+  float V[16];    // viewmatrix, row-major as given: p_view = [p,1] * V (row-vector convention)
+  float PV[16];   // full projection, same convention
+  float cam[3];
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  int W, H, gridx, gridy, sh_degree;
+};
+
+GSR_HD void make_view(View& v, const float* vm, const float* pm, const float* campos, int H, int W, float tanfovx,
+                      float tanfovy, float scale_modifier, int sh_degree) {
+  for (int i = 0; i < 16; ++i) { v.V[i] = vm[i]; v.PV[i] = pm[i]; }
+  v.cam[0] = campos[0]; v.cam[1] = campos[1]; v.cam[2] = campos[2];
+  v.tanfovx = tanfovx; v.tanfovy = tanfovy;
+  v.focal_x = (float)W / (2.0f * tanfovx);
+  v.focal_y = (float)H / (2.0f * tanfovy);
+  v.scale_modifier = scale_modifier;
+  v.W = W; v.H = H; v.gridx = (W + TILE - 1) / TILE; v.gridy = (H + TILE - 1) / TILE;
+  v.sh_degree = sh_degree;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3D covariance from scale + quaternion (q = (r,x,y,z) used as given), packed xx,xy,xz,yy,yz,zz
+// ---------------------------------------------------------------------------------------------
+GSR_HD void quat_to_R(const float q[4], float R[9]) {
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z);       R[2] = 2.f * (x * z + r * y);
+  R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+  R[6] = 2.f * (x * z - r * y);       R[7] = 2.f * (y * z + r * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+GSR_HD void cov3d_from_scale_rot(const float s_in[3], float mod, const float q[4], float c6[6]) {
+  float R[9];
+  quat_to_R(q, R);
+  const float s0 = mod * s_in[0], s1 = mod * s_in[1], s2 = mod * s_in[2];
+  // L = R * diag(s);  Sigma = L L^T
+  const float L00 = R[0] * s0, L01 = R[1] * s1, L02 = R[2] * s2;
+  const float L10 = R[3] * s0, L11 = R[4] * s1, L12 = R[5] * s2;
+  const float L20 = R[6] * s0, L21 = R[7] * s1, L22 = R[8] * s2;
+  c6[0] = L00 * L00 + L01 * L01 + L02 * L02;
+  c6[1] = L00 * L10 + L01 * L11 + L02 * L12;
+  c6[2] = L00 * L20 + L01 * L21 + L02 * L22;
+  c6[3] = L10 * L10 + L11 * L11 + L12 * L12;
+  c6[4] = L10 * L20 + L11 * L21 + L12 * L22;
+  c6[5] = L20 * L20 + L21 * L21 + L22 * L22;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of one Gaussian on screen (K1 steps 1-8, 10)
+// ---------------------------------------------------------------------------------------------
+struct Splat {
+  float px, py;      // pixel-space centre
+  float depth;       // view-space z
+  float A, B, C;     // conic = inverse of the dilated 2D covariance
+  int radius;        // 0 => culled
+  int rminx, rminy, rmaxx, rmaxy;   // tile rect [min,max)
+};
+
+GSR_HD int trunc_clamp(float v, int hi) {
+  // (int) truncation toward zero, then clamp to [0,hi]; NaN/inf safe
+  if (!(v > 0.f)) return 0;
+  if (v >= (float)hi) return hi;
+  return (int)v;
+}
+
+// M = J * Wr (2x3): the affine map from world-space covariance to screen space.
+// Also returns the clamped view-space point and whether each axis was clamped.
+struct ProjLin {
+  float M[6];
+  float tx, ty, tz;
+  bool clx, cly;
+};
+
+GSR_HD void proj_linear(const View& v, const float t[3], ProjLin& o) {
+  const float limx = FOV_CLAMP * v.tanfovx, limy = FOV_CLAMP * v.tanfovy;
+  const float tz = t[2];
+  const float txtz = t[0] / tz, tytz = t[1] / tz;
+  o.clx = (txtz < -limx) || (txtz > limx);
+  o.cly = (tytz < -limy) || (tytz > limy);
+  o.tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+  o.ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+  o.tz = tz;
+  const float J00 = v.focal_x / tz, J02 = -(v.focal_x * o.tx) / (tz * tz);
+  const float J11 = v.focal_y / tz, J12 = -(v.focal_y * o.ty) / (tz * tz);
+  // Wr[j][i] = V[i*4+j] (column-vector view rotation); M[a][i] = sum_j J[a][j] Wr[j][i]
+  for (int i = 0; i < 3; ++i) {
+    o.M[i] = J00 * v.V[i * 4 + 0] + J02 * v.V[i * 4 + 2];
+    o.M[3 + i] = J11 * v.V[i * 4 + 1] + J12 * v.V[i * 4 + 2];
+  }
+}
+
+GSR_HD void cov2d_from_M(const float M[6], const float c6[6], float& a, float& b, float& c) {
+  // u = Sigma * M0^T, w = Sigma * M1^T
+  const float u0 = c6[0] * M[0] + c6[1] * M[1] + c6[2] * M[2];
+  const float u1 = c6[1] * M[0] + c6[3] * M[1] + c6[4] * M[2];
+  const float u2 = c6[2] * M[0] + c6[4] * M[1] + c6[5] * M[2];
+  const float w0 = c6[0] * M[3] + c6[1] * M[4] + c6[2] * M[5];
+  const float w1 = c6[1] * M[3] + c6[3] * M[4] + c6[4] * M[5];
+  const float w2 = c6[2] * M[3] + c6[4] * M[4] + c6[5] * M[5];
+  a = M[0] * u0 + M[1] * u1 + M[2] * u2 + DILATE;
+  b = M[3] * u0 + M[4] * u1 + M[5] * u2;
+  c = M[3] * w0 + M[4] * w1 + M[5] * w2 + DILATE;
+}
+
+GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Splat& s) {
+  s.radius = 0;
+  float t[3];
+  for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+  if (!(t[2] > NEAR_Z)) return false;
+  float h[4];
+  for (int j = 0; j < 4; ++j) h[j] = p[0] * v.PV[j] + p[1] * v.PV[4 + j] + p[2] * v.PV[8 + j] + v.PV[12 + j];
+  const float w = 1.0f / (h[3] + 1e-7f);
+  const float ndcx = h[0] * w, ndcy = h[1] * w;
+  ProjLin pl;
+  proj_linear(v, t, pl);
+  float a, b, c;
+  cov2d_from_M(pl.M, c6, a, b, c);
+  const float det = a * c - b * b;
+  if (det == 0.0f) return false;
+  const float dinv = 1.0f / det;
+  s.A = c * dinv; s.B = -b * dinv; s.C = a * dinv;
+  const float mid = 0.5f * (a + c);
+  const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+  const int radius = (int)ceilf(3.0f * sqrtf(lam));
+  s.px = ((ndcx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
+  s.py = ((ndcy + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+  const float rf = (float)radius;
+  s.rminx = trunc_clamp((s.px - rf) / (float)TILE, v.gridx);
+  s.rminy = trunc_clamp((s.py - rf) / (float)TILE, v.gridy);
+  s.rmaxx = trunc_clamp((s.px + rf + (float)(TILE - 1)) / (float)TILE, v.gridx);
+  s.rmaxy = trunc_clamp((s.py + rf + (float)(TILE - 1)) / (float)TILE, v.gridy);
+  if ((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy) <= 0) return false;
+  s.depth = t[2];
+  s.radius = radius;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SH -> RGB (K1 step 9) and its backward
+// ---------------------------------------------------------------------------------------------
+GSR_HD int sh_count(int deg) { return (deg + 1) * (deg + 1); }
+
+GSR_HD void sh_basis(int deg, float x, float y, float z, float b[16]) {
+  b[0] = SH_C0;
+  if (deg > 0) {
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+      b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+      if (deg > 2) {
+        b[9] = SH_C3_0 * y * (3.f * xx - yy);
+        b[10] = SH_C3_1 * xy * z;
+        b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+        b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+        b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+        b[14] = SH_C3_5 * z * (xx - yy);
+        b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+      }
+    }
+  }
+}
+
+// d(basis_k)/d(x,y,z) for unit-direction components
+GSR_HD void sh_basis_grad(int deg, float x, float y, float z, float gx[16], float gy[16], float gz[16]) {
+  for (int k = 0; k < 16; ++k) { gx[k] = 0.f; gy[k] = 0.f; gz[k] = 0.f; }
+  if (deg > 0) {
+    gy[1] = -SH_C1; gz[2] = SH_C1; gx[3] = -SH_C1;
+    if (deg > 1) {
+      gx[4] = SH_C2_0 * y; gy[4] = SH_C2_0 * x;
+      gy[5] = SH_C2_1 * z; gz[5] = SH_C2_1 * y;
+      gx[6] = -2.f * SH_C2_2 * x; gy[6] = -2.f * SH_C2_2 * y; gz[6] = 4.f * SH_C2_2 * z;
+      gx[7] = SH_C2_3 * z; gz[7] = SH_C2_3 * x;
+      gx[8] = 2.f * SH_C2_4 * x; gy[8] = -2.f * SH_C2_4 * y;
+      if (deg > 2) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        gx[9] = 6.f * SH_C3_0 * xy;            gy[9] = SH_C3_0 * (3.f * xx - 3.f * yy);
+        gx[10] = SH_C3_1 * yz;                 gy[10] = SH_C3_1 * xz;                      gz[10] = SH_C3_1 * xy;
+        gx[11] = -2.f * SH_C3_2 * xy;          gy[11] = SH_C3_2 * (4.f * zz - xx - 3.f * yy); gz[11] = 8.f * SH_C3_2 * yz;
+        gx[12] = -6.f * SH_C3_3 * xz;          gy[12] = -6.f * SH_C3_3 * yz;               gz[12] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+        gx[13] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); gy[13] = -2.f * SH_C3_4 * xy;       gz[13] = 8.f * SH_C3_4 * xz;
+        gx[14] = 2.f * SH_C3_5 * xz;           gy[14] = -2.f * SH_C3_5 * yz;               gz[14] = SH_C3_5 * (xx - yy);
+        gx[15] = SH_C3_6 * (3.f * xx - 3.f * yy); gy[15] = -6.f * SH_C3_6 * xy;
+      }
+    }
+  }
+}
+
+// sh: this Gaussian's coefficients, [K][3] (coefficient-major, then channel).  Returns clamp bits.
+GSR_HD uint32_t sh_to_rgb(int deg, const float* sh, const float p[3], const float cam[3], float rgb[3]) {
+  float dx = p[0] - cam[0], dy = p[1] - cam[1], dz = p[2] - cam[2];
+  const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= inv; dy *= inv; dz *= inv;
+  float b[16];
+  sh_basis(deg, dx, dy, dz, b);
+  const int n = sh_count(deg);
+  float r = 0.f, g = 0.f, bl = 0.f;
+  for (int k = 0; k < n; ++k) { r += b[k] * sh[3 * k]; g += b[k] * sh[3 * k + 1]; bl += b[k] * sh[3 * k + 2]; }
+  r += 0.5f; g += 0.5f; bl += 0.5f;
+  uint32_t cl = (r < 0.f ? 1u : 0u) | (g < 0.f ? 2u : 0u) | (bl < 0.f ? 4u : 0u);
+  rgb[0] = fmaxf(r, 0.f); rgb[1] = fmaxf(g, 0.f); rgb[2] = fmaxf(bl, 0.f);
+  return cl;
+}
+
+// dL/drgb (already zeroed where clamped) -> dL/dsh [K][3] (written for k < n, zero for the rest up to Kstore)
+// and the view-direction path's contribution to dL/dmean (added into dp).
+GSR_HD void sh_to_rgb_bwd(int deg, int Kstore, const float* sh, const float p[3], const float cam[3],
+                          const float drgb[3], float* dsh, float dp[3]) {
+  const float vx = p[0] - cam[0], vy = p[1] - cam[1], vz = p[2] - cam[2];
+  const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+  const float x = vx * inv, y = vy * inv, z = vz * inv;
+  float b[16], gx[16], gy[16], gz[16];
+  sh_basis(deg, x, y, z, b);
+  sh_basis_grad(deg, x, y, z, gx, gy, gz);
+  const int n = sh_count(deg);
+  float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+  for (int k = 0; k < n; ++k) {
+    dsh[3 * k] = b[k] * drgb[0]; dsh[3 * k + 1] = b[k] * drgb[1]; dsh[3 * k + 2] = b[k] * drgb[2];
+    const float s = sh[3 * k] * drgb[0] + sh[3 * k + 1] * drgb[1] + sh[3 * k + 2] * drgb[2];
+    ddx += gx[k] * s; ddy += gy[k] * s; ddz += gz[k] * s;
+  }
+  for (int k = n; k < Kstore; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+  // d = v/|v| :  dL/dv = (dL/dd - d (d . dL/dd)) / |v|
+  const float dot = x * ddx + y * ddy + z * ddz;
+  dp[0] += (ddx - x * dot) * inv;
+  dp[1] += (ddy - y * dot) * inv;
+  dp[2] += (ddz - z * dot) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the per-Gaussian geometry (K8 + K9)
+// ---------------------------------------------------------------------------------------------
+// Inputs: true partials dL/dA, dL/dB, dL/dC of the conic (B counted once), dL/d(ndc.xy) (= the
+// extension's dL_dmean2D), and the forward inputs.  Outputs: dL/dmean (added into dp), dL/dcov3D
+// packed (dc6), to be pushed further to scale/rotation by cov3d_bwd when those were the inputs.
+GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6], float dA, float dB, float dC,
+                              float dndcx, float dndcy, float dp[3], float dc6[6]) {
+  float t[3];
+  for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+  ProjLin pl;
+  proj_linear(v, t, pl);
+  float a, b, c;
+  cov2d_from_M(pl.M, c6, a, b, c);
+  const float det = a * c - b * b;
+  const float d2 = 1.0f / (det * det);   // det >= DILATE^2 - rounding > 0 for a PSD covariance
+  // conic = (c, -b, a)/det
+  const float da = (-c * c * dA + b * c * dB - b * b * dC) * d2;
+  const float db = (2.f * b * c * dA - (det + 2.f * b * b) * dB + 2.f * a * b * dC) * d2;
+  const float dc = (-b * b * dA + a * b * dB - a * a * dC) * d2;
+  // D = [[da, db/2],[db/2, dc]];  dL/dSigma3 = M^T D M (symmetric 3x3)
+  const float hb = 0.5f * db;
+  const float* M = pl.M;
+  float DM[6];   // D*M (2x3)
+  for (int i = 0; i < 3; ++i) { DM[i] = da * M[i] + hb * M[3 + i]; DM[3 + i] = hb * M[i] + dc * M[3 + i]; }
+  float Gs[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Gs[i * 3 + j] = M[i] * DM[j] + M[3 + i] * DM[3 + j];
+  dc6[0] = Gs[0]; dc6[1] = 2.f * Gs[1]; dc6[2] = 2.f * Gs[2]; dc6[3] = Gs[4]; dc6[4] = 2.f * Gs[5]; dc6[5] = Gs[8];
+  // dL/dM = 2 D M Sigma3  (2x3)
+  float dM[6];
+  {
+    const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+    for (int r = 0; r < 2; ++r)
+      for (int j = 0; j < 3; ++j)
+        dM[r * 3 + j] = 2.f * (DM[r * 3 + 0] * S[0 * 3 + j] + DM[r * 3 + 1] * S[1 * 3 + j] + DM[r * 3 + 2] * S[2 * 3 + j]);
+  }
+  // M[a][i] = sum_j J[a][j] Wr[j][i], Wr[j][i] = V[i*4+j]  =>  dL/dJ[a][j] = sum_i dM[a][i] V[i*4+j]
+  const float dJ00 = dM[0] * v.V[0] + dM[1] * v.V[4] + dM[2] * v.V[8];
+  const float dJ02 = dM[0] * v.V[2] + dM[1] * v.V[6] + dM[2] * v.V[10];
+  const float dJ11 = dM[3] * v.V[1] + dM[4] * v.V[5] + dM[5] * v.V[9];
+  const float dJ12 = dM[3] * v.V[2] + dM[4] * v.V[6] + dM[5] * v.V[10];
+  const float tz = pl.tz, itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+  // clamped axes: t.x (t.y) is treated as a constant
+  const float dtx = pl.clx ? 0.f : -v.focal_x * itz2 * dJ02;
+  const float dty = pl.cly ? 0.f : -v.focal_y * itz2 * dJ12;
+  const float dtz = -v.focal_x * itz2 * dJ00 - v.focal_y * itz2 * dJ11 + 2.f * v.focal_x * pl.tx * itz3 * dJ02 +
+                    2.f * v.focal_y * pl.ty * itz3 * dJ12;
+  // t_j = sum_i p_i V[i*4+j] + V[12+j]
+  for (int i = 0; i < 3; ++i) dp[i] += v.V[i * 4 + 0] * dtx + v.V[i * 4 + 1] * dty + v.V[i * 4 + 2] * dtz;
+  // screen position: ndc = hom.xy / (hom.w + 1e-7)
+  float h[4];
+  for (int j = 0; j < 4; ++j) h[j] = p[0] * v.PV[j] + p[1] * v.PV[4 + j] + p[2] * v.PV[8 + j] + v.PV[12 + j];
+  const float w = 1.0f / (h[3] + 1e-7f);
+  const float dh0 = dndcx * w, dh1 = dndcy * w;
+  const float dh3 = -(dndcx * h[0] + dndcy * h[1]) * w * w;
+  for (int i = 0; i < 3; ++i) dp[i] += v.PV[i * 4 + 0] * dh0 + v.PV[i * 4 + 1] * dh1 + v.PV[i * 4 + 3] * dh3;
+}
+
+// dL/dcov3D packed -> dL/dscale (3), dL/dq (4, w.r.t. the quaternion as given)
+GSR_HD void cov3d_bwd(const float s_in[3], float mod, const float q[4], const float dc6[6], float ds[3], float dq[4]) {
+  float R[9];
+  quat_to_R(q, R);
+  const float s[3] = {mod * s_in[0], mod * s_in[1], mod * s_in[2]};
+  // symmetric dL/dSigma as a full matrix (off-diagonals halved back)
+  const float G[9] = {dc6[0], 0.5f * dc6[1], 0.5f * dc6[2], 0.5f * dc6[1], dc6[3], 0.5f * dc6[4],
+                      0.5f * dc6[2], 0.5f * dc6[4], dc6[5]};
+  // L = R diag(s); dL/dL = 2 G L
+  float dL[9];
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k)
+      dL[i * 3 + k] = 2.f * (G[i * 3 + 0] * R[0 * 3 + k] + G[i * 3 + 1] * R[1 * 3 + k] + G[i * 3 + 2] * R[2 * 3 + k]) * s[k];
+  float dR[9];
+  for (int k = 0; k < 3; ++k) {
+    ds[k] = (dL[0 * 3 + k] * R[0 * 3 + k] + dL[1 * 3 + k] * R[1 * 3 + k] + dL[2 * 3 + k] * R[2 * 3 + k]) * mod;
+    for (int i = 0; i < 3; ++i) dR[i * 3 + k] = dL[i * 3 + k] * s[k];
+  }
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+  dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+  dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+  dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-(pixel, Gaussian) blend weight (K6 inner step).  Returns false when the entry is skipped.
+// ---------------------------------------------------------------------------------------------
+GSR_HD bool splat_alpha(float dx, float dy, float A, float B, float C, float o, float& alpha, float& G) {
+  const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
+  if (power > 0.0f) return false;
+  G = GSR_EXP(power);
+  alpha = fminf(ALPHA_CAP, o * G);
+  return alpha >= ALPHA_MIN;
+}
+
+}  // namespace gsr

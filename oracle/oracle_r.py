@@ -1,0 +1,415 @@
+"""oracle-R: CPU restatement of the differentiable 3D-Gaussian-splat rasteriser.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product
+path: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it, and only as the checker / the reported CPU
+baseline.  The product (``diff_gaussian_rasterization`` -> ``libgsraster.so``)
+never falls back to this code.
+
+PARITY STATUS: **parity unpinned** for the rasteriser arithmetic itself.  The
+reference imports the third-party CUDA extension ``diff_gaussian_rasterization``
+(Gaussian-Grouping variant; ``gaussian_renderer/__init__.py:14``) whose source
+is not vendored under /root/reference and for which no commit is pinned, and the
+reference holds no tests / golden vectors for this path.
+What IS pinned (tests/golden, made by tests/golden/make_golden.py from the
+reference's importable Python twins): the SH basis (``utils/sh_utils.py:57-112``
++ the ``+0.5 / clamp_min`` of ``gaussian_renderer/__init__.py:74-78``), the
+camera matrices (``utils/graphics_utils.py:38-71``, ``scene/cameras.py:54-57``),
+the 3D covariance construction (``utils/general_utils.py:78-110``,
+``scene/gaussian_model.py:25-29``) and the PGD step functions
+(``attack.py:25-173``).  The remainder follows the published 3DGS algorithm
+(Kerbl et al. 2023) with the constants listed in SURVEY.md section 8(a):
+0.2 near cull, 1.3*tanfov clamp, +0.3 px^2 dilation, ceil(3*sqrt(lambda)) radius
+with max(0.1, .), 16x16 tiles, alpha cap 0.99, alpha floor 1/255, T stop 1e-4,
++1e-7 w-guard, pixel centre ((ndc+1)*S-1)/2.
+
+Gradients come from autograd over this restatement, with two deliberate
+straight-through constructions so that they equal what the reference
+extension's hand-written backward produces rather than the "true" derivative:
+  * ``alpha = min(0.99, o*G)``: the backward treats the cap as transparent
+    (dalpha/dG = o even when capped);
+  * the 1.3*tanfov clamp of t.x/t.z: when clamped, t.x is treated as a constant
+    (zero gradient to t.x, and no t.z dependence through the clamp).
+Everything else is the exact derivative.
+
+Works in float32 or float64 (``dtype=``); float64 is the parity reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple, Optional
+
+import torch
+
+TILE = 16
+NUM_OBJECTS = 16  # scene/gaussian_model.py:52
+
+# utils/sh_utils.py:26-54 (values; deg <= 3 is what the rasteriser supports)
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
+         -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
+         0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+         -0.5900435899266435)
+
+
+class Settings(NamedTuple):
+    """Same 12 fields, same order, as the call site gaussian_renderer/__init__.py:36-49."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+# --------------------------------------------------------------------------
+# per-Gaussian stages
+# --------------------------------------------------------------------------
+
+def sh_basis(deg: int, d: torch.Tensor) -> torch.Tensor:
+    """Real SH basis values [P,(deg+1)^2] for unit directions d [P,3].
+
+    Sign/ordering convention of utils/sh_utils.py:72-101 (deg<=3)."""
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    cols = [torch.full_like(x, SH_C0)]
+    if deg > 0:
+        cols += [-SH_C1 * y, SH_C1 * z, -SH_C1 * x]
+    if deg > 1:
+        xx, yy, zz = x * x, y * y, z * z
+        xy, yz, xz = x * y, y * z, x * z
+        cols += [SH_C2[0] * xy, SH_C2[1] * yz, SH_C2[2] * (2.0 * zz - xx - yy),
+                 SH_C2[3] * xz, SH_C2[4] * (xx - yy)]
+    if deg > 2:
+        cols += [SH_C3[0] * y * (3.0 * xx - yy), SH_C3[1] * xy * z,
+                 SH_C3[2] * y * (4.0 * zz - xx - yy),
+                 SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy),
+                 SH_C3[4] * x * (4.0 * zz - xx - yy), SH_C3[5] * z * (xx - yy),
+                 SH_C3[6] * x * (xx - 3.0 * yy)]
+    return torch.stack(cols, dim=1)
+
+
+def sh_to_rgb(deg: int, sh: torch.Tensor, means3D: torch.Tensor, campos: torch.Tensor):
+    """sh [P,K,3] (coefficient-major, then channel: scene/gaussian_model.py:113-116)
+    -> (rgb [P,3] after +0.5 and clamp at 0, clamped flags [P,3])."""
+    d = means3D - campos[None, :]
+    d = d / d.norm(dim=1, keepdim=True)
+    B = sh_basis(deg, d)                                   # [P,k]
+    k = B.shape[1]
+    raw = (B[:, :, None] * sh[:, :k, :]).sum(dim=1) + 0.5  # gaussian_renderer/__init__.py:78
+    clamped = raw < 0
+    return torch.clamp_min(raw, 0.0), clamped
+
+
+def quat_to_rot(q: torch.Tensor) -> torch.Tensor:
+    """utils/general_utils.py:85-98 but WITHOUT the re-normalisation: the rasteriser
+    consumes the quaternion as given (get_rotation normalised it upstream,
+    scene/gaussian_model.py:39,102-103)."""
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.view(-1, 3, 3)
+
+
+def cov3d_from_scale_rot(scales, rotations, mod: float) -> torch.Tensor:
+    """L = R diag(mod*s); Sigma = L L^T (utils/general_utils.py:101-110,
+    scene/gaussian_model.py:25-29) -> full [P,3,3]."""
+    R = quat_to_rot(rotations)
+    L = R * (mod * scales)[:, None, :]
+    return L @ L.transpose(1, 2)
+
+
+def cov3d_pack(S: torch.Tensor) -> torch.Tensor:
+    """strip_lowerdiag order (utils/general_utils.py:64-73): xx,xy,xz,yy,yz,zz."""
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1)
+
+
+def cov3d_unpack(c6: torch.Tensor) -> torch.Tensor:
+    return torch.stack([c6[:, 0], c6[:, 1], c6[:, 2],
+                        c6[:, 1], c6[:, 3], c6[:, 4],
+                        c6[:, 2], c6[:, 4], c6[:, 5]], dim=1).view(-1, 3, 3)
+
+
+class Geom(NamedTuple):
+    valid: torch.Tensor      # [P] bool   radius > 0 after all culls
+    radii: torch.Tensor      # [P] int32
+    xy: torch.Tensor         # [P,2]      pixel-space centre
+    depth: torch.Tensor      # [P]        view-space z
+    conic: torch.Tensor      # [P,3]      (A,B,C) of the inverse dilated 2D covariance
+    rect_min: torch.Tensor   # [P,2] int  tile rect [min,max)
+    rect_max: torch.Tensor   # [P,2] int
+    fragile: torch.Tensor    # [P] bool   an integer decision sits within rounding of its edge
+
+
+def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
+    """K1 of SURVEY.md section 8(a) row a4, steps (1)-(8) and (10)."""
+    dt = means3D.dtype
+    H, W = int(st.image_height), int(st.image_width)
+    V = st.viewmatrix.to(dt)
+    PV = st.projmatrix.to(dt)
+    P = means3D.shape[0]
+    ones = torch.ones(P, 1, dtype=dt)
+    ph = torch.cat([means3D, ones], dim=1)
+    p_view = ph @ V                                        # row-vector convention (scene/cameras.py:54)
+    p_hom = ph @ PV
+    w = 1.0 / (p_hom[:, 3] + 1e-7)
+    ndc = p_hom[:, :3] * w[:, None]
+    if means2D is not None:                                # receives dL/d(ndc.xy) like the extension's dL_dmean2D
+        ndc = torch.cat([ndc[:, :2] + means2D[:, :2], ndc[:, 2:]], dim=1)
+    tz = p_view[:, 2]
+    in_front = tz > 0.2
+
+    if cov3D_precomp is not None:
+        S3 = cov3d_unpack(cov3D_precomp)
+    else:
+        S3 = cov3d_from_scale_rot(scales, rotations, float(st.scale_modifier))
+
+    fx = W / (2.0 * st.tanfovx)
+    fy = H / (2.0 * st.tanfovy)
+    limx = 1.3 * st.tanfovx
+    limy = 1.3 * st.tanfovy
+    tz_safe = torch.where(in_front, tz, torch.ones_like(tz))
+    txtz = p_view[:, 0] / tz_safe
+    tytz = p_view[:, 1] / tz_safe
+    # straight-through-as-constant when clamped (see module docstring)
+    tx = torch.where((txtz < -limx) | (txtz > limx), (txtz.clamp(-limx, limx) * tz_safe).detach(), p_view[:, 0])
+    ty = torch.where((tytz < -limy) | (tytz > limy), (tytz.clamp(-limy, limy) * tz_safe).detach(), p_view[:, 1])
+    zero = torch.zeros_like(tz)
+    J = torch.stack([fx / tz_safe, zero, -(fx * tx) / (tz_safe * tz_safe),
+                     zero, fy / tz_safe, -(fy * ty) / (tz_safe * tz_safe)], dim=1).view(-1, 2, 3)
+    Wr = V[:3, :3].t()                                     # column-vector view rotation
+    M = J @ Wr[None]                                       # [P,2,3]
+    cov2 = M @ S3 @ M.transpose(1, 2)                      # [P,2,2]
+    a = cov2[:, 0, 0] + 0.3
+    b = cov2[:, 0, 1]
+    c = cov2[:, 1, 1] + 0.3
+    det = a * c - b * b
+    det_ok = det != 0
+    det_safe = torch.where(det_ok, det, torch.ones_like(det))
+    conic = torch.stack([c / det_safe, -b / det_safe, a / det_safe], dim=1)
+    mid = 0.5 * (a + c)
+    disc = torch.clamp_min(mid * mid - det, 0.1)
+    lam = mid + torch.sqrt(disc)
+    rr = 3.0 * torch.sqrt(lam.detach())
+    radius = torch.ceil(rr)
+    px = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5
+    py = ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    xy = torch.stack([px, py], dim=1)
+
+    gx = (W + TILE - 1) // TILE
+    gy = (H + TILE - 1) // TILE
+    pxd, pyd = px.detach(), py.detach()
+
+    def _trunc_clamp(v, hi):
+        v = torch.nan_to_num(v, nan=0.0, posinf=1e9, neginf=-1e9)
+        return torch.clamp(torch.trunc(v).to(torch.int64), 0, hi)
+    rminx = _trunc_clamp((pxd - radius) / TILE, gx)
+    rminy = _trunc_clamp((pyd - radius) / TILE, gy)
+    rmaxx = _trunc_clamp((pxd + radius + (TILE - 1)) / TILE, gx)
+    rmaxy = _trunc_clamp((pyd + radius + (TILE - 1)) / TILE, gy)
+    area = (rmaxx - rminx) * (rmaxy - rminy)
+    valid = in_front & det_ok & (area > 0)
+    radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
+
+    # fragile integer decisions (used by tests to excuse +-1 radius / rect flips in float32)
+    def _near_int(v, tol):
+        return (v - torch.round(v)).abs() < tol
+    tol = 2e-4 if dt == torch.float32 else 1e-9
+    fragile = _near_int(rr, tol * rr.clamp_min(1.0))
+    for q in ((pxd - radius) / TILE, (pyd - radius) / TILE,
+              (pxd + radius + (TILE - 1)) / TILE, (pyd + radius + (TILE - 1)) / TILE):
+        fragile = fragile | _near_int(q, tol * q.abs().clamp_min(1.0))
+    fragile = fragile | ((tz - 0.2).abs() < tol)
+
+    return Geom(valid, radii, xy, tz, conic,
+                torch.stack([rminx, rminy], dim=1), torch.stack([rmaxx, rmaxy], dim=1), fragile)
+
+
+# --------------------------------------------------------------------------
+# binning (K2-K5) and compositing (K6)
+# --------------------------------------------------------------------------
+
+def build_tile_lists(g: Geom, H: int, W: int):
+    """(tile id, Gaussian id) pairs sorted by (tile, depth) with ties in Gaussian-index
+    order, i.e. a stable sort of row-major-emitted pairs on key (tile<<32 | depth bits).
+    Returns (sorted gaussian ids [N], ranges [T,2])."""
+    gx = (W + TILE - 1) // TILE
+    gy = (H + TILE - 1) // TILE
+    T = gx * gy
+    ids = torch.nonzero(g.valid).flatten()
+    if ids.numel() == 0:
+        return torch.zeros(0, dtype=torch.int64), torch.zeros(T, 2, dtype=torch.int64)
+    depth = g.depth.detach()[ids].to(torch.float32)        # the key holds float32 depth bits
+    order = torch.argsort(depth, stable=True)
+    ids = ids[order]
+    rmin, rmax = g.rect_min[ids], g.rect_max[ids]
+    wx = rmax[:, 0] - rmin[:, 0]
+    cnt = wx * (rmax[:, 1] - rmin[:, 1])
+    owner = torch.repeat_interleave(torch.arange(ids.numel()), cnt)
+    start = torch.cumsum(cnt, 0) - cnt
+    local = torch.arange(int(cnt.sum())) - start[owner]
+    ty = rmin[owner, 1] + local // wx[owner]
+    tx = rmin[owner, 0] + local % wx[owner]
+    tile = ty * gx + tx
+    o2 = torch.argsort(tile, stable=True)                  # stable => depth order kept inside each tile
+    tile_s = tile[o2]
+    gid_s = ids[owner[o2]]
+    counts = torch.bincount(tile_s, minlength=T)
+    ends = torch.cumsum(counts, 0)
+    ranges = torch.stack([ends - counts, ends], dim=1)
+    return gid_s, ranges
+
+
+class RenderOut(NamedTuple):
+    color: torch.Tensor        # [3,H,W]
+    radii: torch.Tensor        # [P] int32
+    objects: torch.Tensor      # [16,H,W]
+    final_T: torch.Tensor      # [H,W]
+    n_contrib: torch.Tensor    # [H,W] int   (1-based position of the last contributor in the tile list)
+    fragile_px: torch.Tensor   # [H,W] bool  a threshold test sat within rounding of its edge
+    num_rendered: int
+    fragile_gauss: torch.Tensor
+
+
+def rasterize(means3D, means2D, opacities, st: Settings, shs=None, sh_objs=None, colors_precomp=None,
+              scales=None, rotations=None, cov3D_precomp=None, dtype=torch.float64,
+              frag_tol: Optional[float] = None) -> RenderOut:
+    """Full forward (differentiable).  Argument names follow the rasteriser call site
+    gaussian_renderer/__init__.py:86-95."""
+    if (shs is None) == (colors_precomp is None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+    def cv(t):
+        return None if t is None else t.to(dtype)
+    means3D, means2D, opacities = cv(means3D), cv(means2D), cv(opacities)
+    shs, sh_objs, colors_precomp = cv(shs), cv(sh_objs), cv(colors_precomp)
+    scales, rotations, cov3D_precomp = cv(scales), cv(rotations), cv(cov3D_precomp)
+
+    H, W = int(st.image_height), int(st.image_width)
+    P = means3D.shape[0]
+    bg = st.bg.to(dtype).flatten()[:3]                     # bg may hold 4 elements (attack.py:396)
+    g = preprocess(means3D, scales, rotations, cov3D_precomp, st, means2D)
+    if shs is not None:
+        rgb, _ = sh_to_rgb(int(st.sh_degree), shs, means3D, st.campos.to(dtype).flatten()[:3])
+    else:
+        rgb = colors_precomp
+    opac = opacities.view(P)
+    objs = sh_objs.reshape(P, NUM_OBJECTS) if sh_objs is not None else None
+
+    gid, ranges = build_tile_lists(g, H, W)
+    gx = (W + TILE - 1) // TILE
+    gy = (H + TILE - 1) // TILE
+    # relative half-width of the "a float32 implementation may legitimately flip this test" band
+    tol = frag_tol if frag_tol is not None else 1e-4
+
+    color_rows, obj_rows, T_rows, n_rows, f_rows = [], [], [], [], []
+    yy, xx = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
+    for ty in range(gy):
+        c_t, o_t, T_t, n_t, f_t = [], [], [], [], []
+        for tx in range(gx):
+            s, e = int(ranges[ty * gx + tx, 0]), int(ranges[ty * gx + tx, 1])
+            ids = gid[s:e]
+            L = ids.numel()
+            pxs = (tx * TILE + xx).reshape(-1, 1).to(dtype)       # [256,1]
+            pys = (ty * TILE + yy).reshape(-1, 1).to(dtype)
+            if L == 0:
+                c_t.append(bg[:, None].expand(3, TILE * TILE).reshape(3, TILE, TILE))
+                o_t.append(torch.zeros(NUM_OBJECTS, TILE, TILE, dtype=dtype))
+                T_t.append(torch.ones(TILE, TILE, dtype=dtype))
+                n_t.append(torch.zeros(TILE, TILE, dtype=torch.int64))
+                f_t.append(torch.zeros(TILE, TILE, dtype=torch.bool))
+                continue
+            dx = g.xy[ids, 0][None, :] - pxs                       # [256,L]
+            dy = g.xy[ids, 1][None, :] - pys
+            A, B, C = g.conic[ids, 0][None], g.conic[ids, 1][None], g.conic[ids, 2][None]
+            power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
+            Gv = torch.exp(torch.clamp_max(power, 0.0))
+            a_raw = opac[ids][None, :] * Gv
+            alpha = a_raw - torch.relu(a_raw - 0.99).detach()      # min(0.99, .) with transparent backward
+            valid = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)
+            a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+            one_m = 1.0 - a_eff
+            T_incl = torch.cumprod(one_m, dim=1)
+            T_excl = torch.cat([torch.ones(TILE * TILE, 1, dtype=dtype), T_incl[:, :-1]], dim=1)
+            stop = valid & (T_incl.detach() < 1e-4)
+            alive = torch.cumsum(stop.to(torch.int64), dim=1) == 0  # entries strictly before the stopping one
+            wgt = torch.where(alive & valid, a_eff * T_excl, torch.zeros_like(a_eff))   # [256,L]
+            col = wgt @ rgb[ids]                                    # [256,3]
+            # final T = T before the stopping entry, or the full product
+            contrib = alive & valid
+            T_alive = torch.where(alive, one_m, torch.ones_like(one_m))
+            T_fin = torch.prod(T_alive, dim=1)
+            pos = torch.arange(1, L + 1)[None, :].expand_as(contrib)
+            n_c = torch.where(contrib, pos, torch.zeros_like(pos)).max(dim=1).values
+            col = col + T_fin[:, None] * bg[None, :]
+            if objs is not None:
+                ob = wgt @ objs[ids]
+            else:
+                ob = torch.zeros(TILE * TILE, NUM_OBJECTS, dtype=dtype)
+            with torch.no_grad():
+                reach = alive | stop                               # entries the loop actually evaluated
+                fr = (reach & (power <= 0) & ((alpha * 255.0 - 1.0).abs() < tol)).any(dim=1)   # alpha ~ 1/255
+                fr |= (reach & valid & ((T_incl * 1e4 - 1.0).abs() < 10 * tol)).any(dim=1)      # T' ~ 1e-4
+                fr |= (reach & (power.abs() < 1e-6) & ((dx != 0) | (dy != 0))).any(dim=1)       # power ~ 0
+                fr |= g.fragile[ids].any()
+            c_t.append(col.t().reshape(3, TILE, TILE))
+            o_t.append(ob.t().reshape(NUM_OBJECTS, TILE, TILE))
+            T_t.append(T_fin.reshape(TILE, TILE))
+            n_t.append(n_c.reshape(TILE, TILE))
+            f_t.append(fr.reshape(TILE, TILE))
+        color_rows.append(torch.cat(c_t, dim=2))
+        obj_rows.append(torch.cat(o_t, dim=2))
+        T_rows.append(torch.cat(T_t, dim=1))
+        n_rows.append(torch.cat(n_t, dim=1))
+        f_rows.append(torch.cat(f_t, dim=1))
+    color = torch.cat(color_rows, dim=1)[:, :H, :W]
+    objects = torch.cat(obj_rows, dim=1)[:, :H, :W]
+    final_T = torch.cat(T_rows, dim=0)[:H, :W]
+    n_contrib = torch.cat(n_rows, dim=0)[:H, :W]
+    fragile_px = torch.cat(f_rows, dim=0)[:H, :W]
+    return RenderOut(color, g.radii, objects, final_T, n_contrib, fragile_px, int(gid.numel()), g.fragile)
+
+
+def mark_visible(means3D, st: Settings) -> torch.Tensor:
+    """K10: frustum test only (view-space z > 0.2)."""
+    dt = means3D.dtype
+    ph = torch.cat([means3D, torch.ones(means3D.shape[0], 1, dtype=dt)], dim=1)
+    return (ph @ st.viewmatrix.to(dt))[:, 2] > 0.2
+
+
+# --------------------------------------------------------------------------
+# convenience: forward + backward for a fixed dL/dC (what tests and bench use)
+# --------------------------------------------------------------------------
+
+def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, dtype=torch.float64):
+    """inputs: dict of float tensors (means3D, shs, opacities, scales, rotations[, sh_objs, ...]).
+    Returns (RenderOut, grads dict incl. 'means2D')."""
+    leaf = {}
+    for k, v in inputs.items():
+        leaf[k] = None if v is None else v.detach().to(dtype).clone().requires_grad_(True)
+    P = leaf["means3D"].shape[0]
+    m2d = torch.zeros(P, 3, dtype=dtype, requires_grad=True)
+    out = rasterize(leaf["means3D"], m2d, leaf["opacities"], st, shs=leaf.get("shs"),
+                    sh_objs=leaf.get("sh_objs"), colors_precomp=leaf.get("colors_precomp"),
+                    scales=leaf.get("scales"), rotations=leaf.get("rotations"),
+                    cov3D_precomp=leaf.get("cov3D_precomp"), dtype=dtype)
+    loss = (out.color * grad_color.to(dtype)).sum()
+    if grad_objects is not None:
+        loss = loss + (out.objects * grad_objects.to(dtype)).sum()
+    loss.backward()
+    grads = {k: (v.grad if v is not None and v.grad is not None else
+                 (torch.zeros_like(v) if v is not None else None)) for k, v in leaf.items()}
+    grads["means2D"] = m2d.grad if m2d.grad is not None else torch.zeros_like(m2d)
+    return out, grads

@@ -1,0 +1,165 @@
+"""Generate tests/golden/ref_twins.npz from the reference's importable Python twins.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is captured (data only -- inputs and the reference's outputs):
+  * utils/sh_utils.py: eval_sh for deg 0..3, RGB2SH, SH2RGB  (+ the "+0.5, clamp_min 0" of
+    gaussian_renderer/__init__.py:78)
+  * utils/graphics_utils.py: getWorld2View2, getProjectionMatrix; full_proj / camera centre formed as
+    scene/cameras.py:54-57 does, on CPU tensors
+  * utils/general_utils.py: inverse_sigmoid
+  * scene/gaussian_model.py: the activation getters (:97-124) of a CPU GaussianModel
+  * attack.py:25-173: the ten PGD step functions applied to a small fake model with .grad set
+
+Third-party modules the reference imports but this image lacks (hydra, omegaconf, plyfile,
+simple_knn, diff_gaussian_rasterization, detectors.factory's dependencies) are replaced by empty
+stand-in modules *for the import only*; none of their functionality is used by the captured functions.
+Functions that hard-code device="cuda" (utils/general_utils.py:64-110) cannot run here and are
+followed by reading only.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_twins.npz")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def main():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    # import-only stand-ins
+    _stub("hydra", main=lambda **kw: (lambda f: f))
+    _stub("omegaconf", DictConfig=dict, OmegaConf=object)
+    _stub("plyfile", PlyData=object, PlyElement=object)
+    _stub("simple_knn")
+    _stub("simple_knn._C", distCUDA2=None)
+    _stub("diff_gaussian_rasterization", GaussianRasterizationSettings=object, GaussianRasterizer=object)
+    _stub("detectors")
+    _stub("detectors.factory", load_detector=None)
+
+    from utils.sh_utils import eval_sh, RGB2SH, SH2RGB
+    from utils.graphics_utils import getWorld2View2, getProjectionMatrix
+    from utils.general_utils import inverse_sigmoid
+    from scene.gaussian_model import GaussianModel
+    import attack
+
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+
+    # ---- SH ------------------------------------------------------------
+    n = 64
+    sh = torch.randn(n, 3, 16, generator=g)                       # [..., C, (deg+1)^2] as eval_sh wants
+    dirs = torch.randn(n, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    out["sh_coeffs"] = sh.numpy()
+    out["sh_dirs"] = dirs.numpy()
+    for deg in range(4):
+        res = eval_sh(deg, sh, dirs)
+        out[f"sh_eval_deg{deg}"] = res.numpy()
+        out[f"sh_color_deg{deg}"] = torch.clamp_min(res + 0.5, 0.0).numpy()
+    rgb = torch.rand(16, 3, generator=g)
+    out["rgb_in"] = rgb.numpy()
+    out["rgb2sh"] = RGB2SH(rgb).numpy()
+    out["sh2rgb"] = SH2RGB(rgb).numpy()
+
+    # ---- cameras ---------------------------------------------------------
+    Rs, Ts, trs, scs, fovs, w2v, proj, full, cpos = [], [], [], [], [], [], [], [], []
+    for i in range(4):
+        A = torch.randn(3, 3, generator=g).double().numpy()
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        T = torch.randn(3, generator=g).double().numpy() * 2.0
+        trans = np.array([0.0, 0.0, 0.0]) if i < 2 else torch.randn(3, generator=g).double().numpy()
+        scale = 1.0 if i < 3 else 1.7
+        fovx, fovy = 0.6 + 0.2 * i, 0.5 + 0.15 * i
+        V = torch.tensor(getWorld2View2(Q, T, trans, scale)).transpose(0, 1)           # scene/cameras.py:54
+        Pm = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy).transpose(0, 1)   # :55
+        F = (V.unsqueeze(0).bmm(Pm.unsqueeze(0))).squeeze(0)                          # :56
+        C = V.inverse()[3, :3]                                                       # :57
+        Rs.append(Q); Ts.append(T); trs.append(trans); scs.append(scale); fovs.append([fovx, fovy])
+        w2v.append(V.numpy()); proj.append(Pm.numpy()); full.append(F.numpy()); cpos.append(C.numpy())
+    out.update(cam_R=np.stack(Rs), cam_T=np.stack(Ts), cam_trans=np.stack(trs), cam_scale=np.array(scs),
+               cam_fov=np.array(fovs), cam_world_view=np.stack(w2v), cam_proj=np.stack(proj),
+               cam_full=np.stack(full), cam_center=np.stack(cpos))
+
+    # ---- misc ------------------------------------------------------------
+    x = torch.rand(32, generator=g) * 0.98 + 0.01
+    out["isig_in"] = x.numpy()
+    out["isig_out"] = inverse_sigmoid(x).numpy()
+
+    # ---- GaussianModel getters -------------------------------------------
+    P = 40
+    gm = GaussianModel(3)
+    gm._xyz = torch.randn(P, 3, generator=g)
+    gm._features_dc = torch.randn(P, 1, 3, generator=g)
+    gm._features_rest = torch.randn(P, 15, 3, generator=g)
+    gm._scaling = torch.randn(P, 3, generator=g)
+    gm._rotation = torch.randn(P, 4, generator=g)
+    gm._opacity = torch.randn(P, 1, generator=g)
+    gm._objects_dc = torch.randn(P, 1, 16, generator=g)
+    for nme in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_objects_dc"):
+        out["gm" + nme] = getattr(gm, nme).numpy()
+    out["gm_get_scaling"] = gm.get_scaling.numpy()
+    out["gm_get_rotation"] = gm.get_rotation.numpy()
+    out["gm_get_opacity"] = gm.get_opacity.numpy()
+    out["gm_get_features"] = gm.get_features.numpy()
+    out["gm_get_objects"] = gm.get_objects.numpy()
+    out["gm_get_xyz"] = gm.get_xyz.numpy()
+
+    # ---- PGD step functions (attack.py:25-173) ----------------------------
+    class Fake:
+        pass
+
+    def fresh():
+        f = Fake()
+        gg = torch.Generator().manual_seed(77)
+        for nme, shp in (("_xyz", (P, 3)), ("_rotation", (P, 4)), ("_opacity", (P, 1)), ("_scaling", (P, 3)),
+                         ("_features_rest", (P, 15, 3)), ("_features_dc", (P, 1, 3))):
+            t = torch.randn(*shp, generator=gg)
+            t.grad = torch.randn(*shp, generator=gg) * 3.0
+            setattr(f, nme, t)
+        f._opacity.grad.zero_()            # exercises the "norm == 0 -> zero step" branch of the L2 variants
+        return f
+
+    base = fresh()
+    orig = {n: (getattr(base, n) + 0.3 * torch.randn(getattr(base, n).shape, generator=g)) for n in
+            ("_xyz", "_rotation", "_opacity", "_scaling", "_features_rest", "_features_dc")}
+    for n in orig:
+        out["pgd_in" + n] = getattr(base, n).numpy()
+        out["pgd_grad" + n] = getattr(base, n).grad.numpy()
+        out["pgd_orig" + n] = orig[n].numpy()
+    alpha, eps = 0.5, 0.8
+    out["pgd_alpha_eps"] = np.array([alpha, eps])
+    single = {"position": "_xyz", "rotation": "_rotation", "opacity": "_opacity", "scaling": "_scaling"}
+    for norm in ("linf", "l2"):
+        for what, attr in single.items():
+            f = fresh()
+            getattr(attack, f"gaussian_{what}_{norm}_attack")(f, alpha, eps, orig[attr].clone())
+            out[f"pgd_{what}_{norm}"] = getattr(f, attr).numpy()
+        f = fresh()
+        getattr(attack, f"gaussian_color_{norm}_attack")(f, alpha, eps, orig["_features_rest"].clone(),
+                                                        orig["_features_dc"].clone())
+        out[f"pgd_color_{norm}_rest"] = f._features_rest.numpy()
+        out[f"pgd_color_{norm}_dc"] = f._features_dc.numpy()
+
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, "with", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+// TEST HARNESS ONLY (built by tests with g++): runs the per-Gaussian arithmetic of csrc/gsr_math.h on the
+// host so that the exact source the HIP kernels compile is checked against oracle/oracle_r.py without a GPU.
+// Not part of the product: nothing in the package loads this library.
+#include "gsr_math.h"
+
+using namespace gsr;
+
+extern "C" {
+
+// geom out [P,12]: px,py,depth,A,B,C,radius,rminx,rminy,rmaxx,rmaxy,clampbits ; rgb out [P,3]
+void hm_preprocess(int P, int K, int H, int W, float tanfovx, float tanfovy, float mod, int deg, const float* vm,
+                   const float* pm, const float* campos, const float* means, const float* scales, const float* rots,
+                   const float* cov3d_precomp, const float* sh, float* geom, float* rgb) {
+  View v;
+  make_view(v, vm, pm, campos, H, W, tanfovx, tanfovy, mod, deg);
+  for (int g = 0; g < P; ++g) {
+    float c6[6];
+    if (cov3d_precomp) for (int i = 0; i < 6; ++i) c6[i] = cov3d_precomp[6 * g + i];
+    else cov3d_from_scale_rot(scales + 3 * g, mod, rots + 4 * g, c6);
+    Splat s;
+    bool ok = project_splat(v, means + 3 * g, c6, s);
+    float* o = geom + 12 * g;
+    for (int i = 0; i < 12; ++i) o[i] = 0.f;
+    rgb[3 * g] = rgb[3 * g + 1] = rgb[3 * g + 2] = 0.f;
+    if (!ok) continue;
+    uint32_t cl = sh_to_rgb(deg, sh + (size_t)g * K * 3, means + 3 * g, v.cam, rgb + 3 * g);
+    o[0] = s.px; o[1] = s.py; o[2] = s.depth; o[3] = s.A; o[4] = s.B; o[5] = s.C; o[6] = (float)s.radius;
+    o[7] = (float)s.rminx; o[8] = (float)s.rminy; o[9] = (float)s.rmaxx; o[10] = (float)s.rmaxy; o[11] = (float)cl;
+  }
+}
+
+// upstream [P,8]: dA,dB,dC (true partials),dndcx,dndcy,drgb[3]; valid[P]; clamp bits [P]
+void hm_preprocess_bwd(int P, int K, int H, int W, float tanfovx, float tanfovy, float mod, int deg, const float* vm,
+                       const float* pm, const float* campos, const float* means, const float* scales,
+                       const float* rots, const float* cov3d_precomp, const float* sh, const float* upstream,
+                       const int* valid, const int* clampbits, float* dmeans, float* dscales, float* drots,
+                       float* dcov3d, float* dsh) {
+  View v;
+  make_view(v, vm, pm, campos, H, W, tanfovx, tanfovy, mod, deg);
+  for (int g = 0; g < P; ++g) {
+    float dp[3] = {0, 0, 0};
+    float* dshg = dsh + (size_t)g * K * 3;
+    if (!valid[g]) {
+      for (int i = 0; i < 3; ++i) dmeans[3 * g + i] = 0.f;
+      if (dscales) { for (int i = 0; i < 3; ++i) dscales[3 * g + i] = 0.f; for (int i = 0; i < 4; ++i) drots[4 * g + i] = 0.f; }
+      if (dcov3d) for (int i = 0; i < 6; ++i) dcov3d[6 * g + i] = 0.f;
+      for (int i = 0; i < K * 3; ++i) dshg[i] = 0.f;
+      continue;
+    }
+    const float* u = upstream + 8 * g;
+    float c6[6];
+    if (cov3d_precomp) for (int i = 0; i < 6; ++i) c6[i] = cov3d_precomp[6 * g + i];
+    else cov3d_from_scale_rot(scales + 3 * g, mod, rots + 4 * g, c6);
+    float drgb[3] = {u[5], u[6], u[7]};
+    for (int c = 0; c < 3; ++c) if (clampbits[g] & (1 << c)) drgb[c] = 0.f;
+    sh_to_rgb_bwd(deg, K, sh + (size_t)g * K * 3, means + 3 * g, v.cam, drgb, dshg, dp);
+    float dc6[6];
+    project_splat_bwd(v, means + 3 * g, c6, u[0], u[1], u[2], u[3], u[4], dp, dc6);
+    if (dcov3d) for (int i = 0; i < 6; ++i) dcov3d[6 * g + i] = dc6[i];
+    if (dscales) cov3d_bwd(scales + 3 * g, mod, rots + 4 * g, dc6, dscales + 3 * g, drots + 4 * g);
+    for (int i = 0; i < 3; ++i) dmeans[3 * g + i] = dp[i];
+  }
+}
+
+}  // extern "C"
