@@ -1,0 +1,561 @@
+// gsr_api.hip -- C ABI of libgsraster.so (include/gsraster.h): context, workspace pool, stage launches.
+//
+// Host side of the boundary that replaces the reference's third-party `diff_gaussian_rasterization._C`
+// (imported at reference gaussian_renderer/__init__.py:14).  No torch linkage: raw device pointers in,
+// kernels enqueued on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/gsraster.h"
+#include "gsr_kernels.hip.h"
+#include "gsr_sort.hip.h"
+
+using namespace gsr;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(stage, expr)                                                                          \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess) return set_err(GSR_ERR_DEVICE, "%s: %s (%s)", stage, hipGetErrorString(_e), #expr); \
+  } while (0)
+
+#define LAUNCH_CHECK(stage)                                                                       \
+  do {                                                                                            \
+    hipError_t _e = hipGetLastError();                                                            \
+    if (_e != hipSuccess) return set_err(GSR_ERR_DEVICE, "%s: launch failed: %s", stage, hipGetErrorString(_e)); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// workspace pool: grow-only caching of hipMalloc blocks per device; reuse is stream-ordered
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Block {
+  void* p;
+  size_t bytes;
+  hipStream_t stream;   // stream of the last user
+  bool used;
+};
+
+struct Pool {
+  std::mutex mu;
+  std::vector<Block> blocks;
+  size_t total = 0;
+};
+
+constexpr int MAX_DEV = 32;
+Pool g_pool[MAX_DEV];
+
+int cur_dev() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  return std::min(std::max(d, 0), MAX_DEV - 1);
+}
+
+void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
+  bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
+  Pool& pl = g_pool[dev];
+  std::lock_guard<std::mutex> lk(pl.mu);
+  int best = -1;
+  for (size_t i = 0; i < pl.blocks.size(); ++i) {
+    const Block& b = pl.blocks[i];
+    if (!b.used && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + (1u << 20) &&
+        (best < 0 || b.bytes < pl.blocks[best].bytes))
+      best = (int)i;
+  }
+  if (best >= 0) {
+    Block& b = pl.blocks[best];
+    if (b.stream != st) (void)hipStreamSynchronize(b.stream);   // cross-stream reuse: wait for the old user
+    b.used = true;
+    b.stream = st;
+    return b.p;
+  }
+  void* p = nullptr;
+  // leave head-room so that a slowly growing pair count re-uses the block instead of reallocating
+  const size_t want = bytes + bytes / 8;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  pl.blocks.push_back(Block{p, want, st, true});
+  pl.total += want;
+  return p;
+}
+
+void pool_free(int dev, void* p) {
+  if (!p) return;
+  Pool& pl = g_pool[dev];
+  std::lock_guard<std::mutex> lk(pl.mu);
+  for (Block& b : pl.blocks)
+    if (b.p == p) { b.used = false; return; }
+}
+
+// a slab = one pool block carved into 256-byte aligned pieces
+struct Slab {
+  char* base = nullptr;
+  size_t cap = 0, cur = 0;
+  template <typename T>
+  T* take(size_t n) {
+    cur = (cur + 255) & ~size_t(255);
+    T* r = reinterpret_cast<T*>(base + cur);
+    cur += n * sizeof(T);
+    return r;
+  }
+};
+
+struct SlabPlan {
+  size_t bytes = 0;
+  template <typename T>
+  void add(size_t n) { bytes = ((bytes + 255) & ~size_t(255)) + n * sizeof(T); }
+};
+
+// pinned host word for the one D2H read per forward
+uint32_t* g_pinned[MAX_DEV] = {nullptr};
+std::mutex g_pinned_mu;
+
+uint32_t* pinned_word(int dev) {
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  if (!g_pinned[dev]) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+    g_pinned[dev] = static_cast<uint32_t*>(p);
+  }
+  return g_pinned[dev];
+}
+
+// ---- per-stage profiling ----------------------------------------------------------------------
+struct ProfSpan { int stage; hipEvent_t a, b; };
+thread_local bool t_prof = false;
+thread_local std::vector<ProfSpan> t_spans;
+thread_local std::vector<hipEvent_t> t_free_events;
+thread_local float t_ms[GSR_STAGE_COUNT] = {0};
+thread_local int64_t t_calls[GSR_STAGE_COUNT] = {0};
+
+hipEvent_t get_event() {
+  if (!t_free_events.empty()) { hipEvent_t e = t_free_events.back(); t_free_events.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct StageTimer {
+  int stage; hipStream_t st; hipEvent_t a{}, b{}; bool on;
+  StageTimer(int s, hipStream_t stream) : stage(s), st(stream), on(t_prof) {
+    if (on) { a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
+  }
+  ~StageTimer() {
+    if (on) { (void)hipEventRecord(b, st); t_spans.push_back(ProfSpan{stage, a, b}); }
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct GsrCtx {
+  int dev = 0;
+  GsrSettings st{};
+  int P = 0, K = 0;
+  int gridx = 0, gridy = 0, ntiles = 0;
+  uint32_t N = 0;
+  // inputs (owned by the caller)
+  const float *means3D = nullptr, *shs = nullptr, *sh_objs = nullptr, *colors = nullptr, *opac = nullptr,
+              *scales = nullptr, *rots = nullptr, *cov3d = nullptr;
+  // kept workspace
+  void* keep_blk = nullptr;
+  void* rank_blk = nullptr;
+  size_t keep_bytes = 0;
+  float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;
+  uint32_t *order = nullptr, *off = nullptr, *pair_rank = nullptr;
+  uint2* ranges = nullptr;
+  float* final_T = nullptr;
+  uint32_t* n_contrib = nullptr;
+};
+
+static ViewArgs view_args(const GsrSettings& s) {
+  ViewArgs va;
+  va.vm = s.viewmatrix; va.pm = s.projmatrix; va.cam = s.campos;
+  va.H = s.image_height; va.W = s.image_width;
+  va.tanfovx = s.tanfovx; va.tanfovy = s.tanfovy; va.mod = s.scale_modifier; va.deg = s.sh_degree;
+  return va;
+}
+
+static int ceil_log2(uint32_t v) {
+  int b = 0;
+  while ((1u << b) < v) ++b;
+  return b;
+}
+
+extern "C" {
+
+const char* gsr_last_error(void) { return g_err; }
+
+void gsr_ctx_free(GsrCtx* c) {
+  if (!c) return;
+  pool_free(c->dev, c->keep_blk);
+  pool_free(c->dev, c->rank_blk);
+  delete c;
+}
+
+int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
+                const float* sh_objs, const float* colors_precomp, const float* opacities, const float* scales,
+                const float* rotations, const float* cov3D_precomp, float* out_color, float* out_objects,
+                int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream) {
+  if (ctx_out) *ctx_out = nullptr;
+  if (!s || !out_color || !radii || !means3D || !opacities)
+    return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / means3D / opacities / out_color / radii");
+  if ((shs == nullptr) == (colors_precomp == nullptr))
+    return set_err(GSR_ERR_INVALID, "gsr_forward: provide exactly one of shs / colors_precomp");
+  const bool has_sr = scales != nullptr && rotations != nullptr;
+  if (((scales != nullptr) != (rotations != nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
+    return set_err(GSR_ERR_INVALID, "gsr_forward: provide exactly one of (scales, rotations) / cov3D_precomp");
+  if (P < 0 || s->image_height <= 0 || s->image_width <= 0)
+    return set_err(GSR_ERR_INVALID, "gsr_forward: bad sizes P=%d H=%d W=%d", P, s->image_height, s->image_width);
+  if (shs && (s->sh_degree < 0 || s->sh_degree > 3 || K < (s->sh_degree + 1) * (s->sh_degree + 1)))
+    return set_err(GSR_ERR_INVALID, "gsr_forward: sh_degree %d needs K >= %d, got K=%d (degree must be 0..3)",
+                   s->sh_degree, (s->sh_degree + 1) * (s->sh_degree + 1), K);
+  if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
+    return set_err(GSR_ERR_INVALID, "gsr_forward: settings tensors (bg, viewmatrix, projmatrix, campos) must be device pointers");
+  if (out_objects == nullptr && sh_objs != nullptr) sh_objs = nullptr;   // objects not wanted
+
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  const int H = s->image_height, W = s->image_width;
+  const int gridx = (W + TILE - 1) / TILE, gridy = (H + TILE - 1) / TILE;
+  const int ntiles = gridx * gridy;
+  if (gridx > 4095 || gridy > 4095) return set_err(GSR_ERR_INVALID, "gsr_forward: image larger than 65520 px per side");
+  const size_t HW = (size_t)H * W;
+
+  GsrCtx* c = new (std::nothrow) GsrCtx();
+  if (!c) return set_err(GSR_ERR_NOMEM, "gsr_forward: host allocation failed");
+  c->dev = dev; c->st = *s; c->P = P; c->K = K; c->gridx = gridx; c->gridy = gridy; c->ntiles = ntiles;
+  c->means3D = means3D; c->shs = shs; c->sh_objs = sh_objs; c->colors = colors_precomp; c->opac = opacities;
+  c->scales = scales; c->rots = rotations; c->cov3d = cov3D_precomp;
+
+  const size_t Pp = (size_t)std::max(P, 1);
+  // ---- kept slab ---------------------------------------------------------------------------
+  SlabPlan kp;
+  kp.add<float4>(Pp); kp.add<float4>(Pp); kp.add<float4>(Pp);   // R0..R2
+  kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1);                // order, off
+  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW);
+  c->keep_bytes = kp.bytes + 256;
+  c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
+  // ---- scratch slab (released at the end of forward) ----------------------------------------
+  const uint32_t tblP = radix_table_words((uint32_t)Pp);
+  SlabPlan sp;
+  sp.add<float4>(Pp); sp.add<float4>(Pp); sp.add<float4>(Pp);   // G0..G2
+  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey a/b, order b
+  sp.add<uint32_t>(tblP); sp.add<uint32_t>(tblP / SCAN_CHUNK + 2);
+  sp.add<uint32_t>(Pp / SCAN_CHUNK + 2);
+  void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
+  if (!c->keep_blk || !scratch_blk) {
+    pool_free(dev, scratch_blk);
+    gsr_ctx_free(c);
+    return set_err(GSR_ERR_NOMEM, "gsr_forward: workspace allocation failed (P=%d, %dx%d)", P, W, H);
+  }
+  Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
+  c->R0 = ks.take<float4>(Pp); c->R1 = ks.take<float4>(Pp); c->R2 = ks.take<float4>(Pp);
+  c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1);
+  c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
+  Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
+  float4* G0 = ss.take<float4>(Pp); float4* G1 = ss.take<float4>(Pp); float4* G2 = ss.take<float4>(Pp);
+  uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
+  uint32_t* table = ss.take<uint32_t>(tblP); uint32_t* tsums = ss.take<uint32_t>(tblP / SCAN_CHUNK + 2);
+  uint32_t* psums = ss.take<uint32_t>(Pp / SCAN_CHUNK + 2);
+
+  void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
+  auto fail = [&](int code) {
+    pool_free(dev, scratch_blk);
+    for (void* b : pairs_blk) if (b && b != c->rank_blk) pool_free(dev, b);
+    gsr_ctx_free(c);
+    return code;
+  };
+#define F_TRY(stage, expr)                                                                                   \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess) return fail(set_err(GSR_ERR_DEVICE, "%s: %s (%s)", stage, hipGetErrorString(_e), #expr)); \
+  } while (0)
+#define F_LAUNCH(stage)                                                                                            \
+  do {                                                                                                             \
+    hipError_t _e = hipGetLastError();                                                                             \
+    if (_e != hipSuccess) return fail(set_err(GSR_ERR_DEVICE, "%s: launch failed: %s", stage, hipGetErrorString(_e))); \
+  } while (0)
+
+  const ViewArgs va = view_args(*s);
+  const dim3 blk(256);
+  const dim3 gridP((unsigned)((Pp + 255) / 256));
+  uint32_t N = 0;
+  if (P > 0) {
+    {
+      StageTimer t(GSR_STAGE_PREPROCESS, st);
+      hipLaunchKernelGGL(k_preprocess, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
+                         opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA);
+      F_LAUNCH("preprocess");
+    }
+    uint32_t* skey;
+    {
+      StageTimer t(GSR_STAGE_DEPTH_SORT, st);
+      // stable argsort of the depth keys: order[r] = Gaussian index of depth rank r
+      const int res = radix_sort_pairs(dkeyA, c->order, dkeyB, orderB, (uint32_t)P, 0, 32, true, table, tsums, st);
+      F_LAUNCH("depth sort");
+      // 4 passes => result back in (dkeyA, c->order); keep the code honest if the pass count changes
+      skey = res ? dkeyB : dkeyA;
+      if (res) F_TRY("depth sort", hipMemcpyAsync(c->order, orderB, sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, st));
+    }
+    {
+      StageTimer t(GSR_STAGE_BIN, st);
+      uint32_t* cnt = orderB;   // free again after the sort
+      hipLaunchKernelGGL(k_pack, gridP, blk, 0, st, P, c->order, skey, G0, G1, G2, c->R0, c->R1, c->R2, cnt);
+      scan_exclusive_u32(cnt, c->off, (uint32_t)P, psums, c->off + P, st);
+      F_LAUNCH("pack/scan");
+      uint32_t* pinned = pinned_word(dev);
+      if (!pinned) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host allocation failed"));
+      F_TRY("read pair count", hipMemcpyAsync(pinned, c->off + P, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      F_TRY("read pair count", hipStreamSynchronize(st));
+      N = *pinned;
+    }
+  } else {
+    F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
+  }
+  c->N = N;
+  F_TRY("ranges", hipMemsetAsync(c->ranges, 0, sizeof(uint2) * ntiles, st));
+  if (N > 0) {
+    const uint32_t tblN = radix_table_words(N);
+    for (int i = 0; i < 4; ++i) {
+      pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)N, st);
+      if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", N));
+    }
+    void* tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + tblN / SCAN_CHUNK + 4), st);
+    if (!tbl_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: sort table allocation failed"));
+    uint32_t* tileA = static_cast<uint32_t*>(pairs_blk[0]); uint32_t* rankA = static_cast<uint32_t*>(pairs_blk[1]);
+    uint32_t* tileB = static_cast<uint32_t*>(pairs_blk[2]); uint32_t* rankB = static_cast<uint32_t*>(pairs_blk[3]);
+    uint32_t* tableN = static_cast<uint32_t*>(tbl_blk);
+    uint32_t* tsumsN = tableN + tblN;
+    {
+      StageTimer t(GSR_STAGE_BIN, st);
+      hipLaunchKernelGGL(k_emit, dim3((N + EMIT_SLOTS - 1) / EMIT_SLOTS), blk, 0, st, c->off, (uint32_t)P, N, c->R2, gridx,
+                         tileA, rankA);
+      F_LAUNCH("emit");
+    }
+    int res;
+    {
+      StageTimer t(GSR_STAGE_TILE_SORT, st);
+      res = radix_sort_pairs(tileA, rankA, tileB, rankB, N, 0, ceil_log2((uint32_t)ntiles), false, tableN, tsumsN, st);
+      hipLaunchKernelGGL(k_ranges, dim3((N + 255) / 256), blk, 0, st, N, res ? tileB : tileA, c->ranges);
+      F_LAUNCH("tile sort");
+    }
+    c->pair_rank = res ? rankB : rankA;
+    c->rank_blk = res ? pairs_blk[3] : pairs_blk[1];
+    pool_free(dev, tbl_blk);
+    for (void* b : pairs_blk) if (b != c->rank_blk) pool_free(dev, b);
+    for (void*& b : pairs_blk) b = nullptr;
+  }
+  {
+    StageTimer t(GSR_STAGE_RENDER_FWD, st);
+    RenderArgs ra;
+    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
+    ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
+    ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
+    const dim3 gridT((ntiles + 3) / 4);
+    if (out_objects && sh_objs) {
+      hipLaunchKernelGGL(k_render_fwd<true>, gridT, blk, 0, st, ra);
+    } else {
+      if (out_objects) F_TRY("objects", hipMemsetAsync(out_objects, 0, sizeof(float) * NUM_OBJ * HW, st));
+      hipLaunchKernelGGL(k_render_fwd<false>, gridT, blk, 0, st, ra);
+    }
+    F_LAUNCH("render forward");
+  }
+  pool_free(dev, scratch_blk);
+  if (num_rendered) *num_rendered = (int64_t)N;
+  if (ctx_out) *ctx_out = c; else gsr_ctx_free(c);
+  return GSR_OK;
+#undef F_TRY
+#undef F_LAUNCH
+}
+
+int gsr_backward(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
+                 float* dshs, float* dsh_objs, float* dcolors_precomp, float* dopacities, float* dscales,
+                 float* drotations, float* dcov3D, void* stream) {
+  if (!c) return set_err(GSR_ERR_STATE, "gsr_backward: null context");
+  if (!grad_color) return set_err(GSR_ERR_INVALID, "gsr_backward: grad_color is null");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = c->dev;
+  const int P = c->P;
+  if (P == 0) return GSR_OK;
+  const bool obj = grad_objects != nullptr && c->sh_objs != nullptr;
+  const uint32_t N = c->N;
+  void* part_blk = nullptr;
+  void* pobj_blk = nullptr;
+  float4* part = nullptr;
+  float4* part_obj = nullptr;
+  if (N > 0) {
+    part_blk = pool_alloc(dev, sizeof(float4) * PART_F4 * (size_t)N, st);
+    if (obj) pobj_blk = pool_alloc(dev, sizeof(float4) * 4 * (size_t)N, st);
+    if (!part_blk || (obj && !pobj_blk)) {
+      pool_free(dev, part_blk); pool_free(dev, pobj_blk);
+      return set_err(GSR_ERR_NOMEM, "gsr_backward: partial-gradient buffer (N=%u) allocation failed", N);
+    }
+    part = static_cast<float4*>(part_blk);
+    part_obj = static_cast<float4*>(pobj_blk);
+  }
+  auto done = [&](int code) { pool_free(dev, part_blk); pool_free(dev, pobj_blk); return code; };
+  if (N > 0) {
+    StageTimer t(GSR_STAGE_RENDER_BWD, st);
+    // rows of (tile, Gaussian) pairs that contribute nothing are never written: start from zero
+    if (hipMemsetAsync(part, 0, sizeof(float4) * PART_F4 * (size_t)N, st) != hipSuccess ||
+        (obj && hipMemsetAsync(part_obj, 0, sizeof(float4) * 4 * (size_t)N, st) != hipSuccess))
+      return done(set_err(GSR_ERR_DEVICE, "render backward: memset failed: %s", hipGetErrorString(hipGetLastError())));
+    RenderBwdArgs ra;
+    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.off = c->off; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
+    ra.sh_objs = c->sh_objs; ra.bg = c->st.bg; ra.W = c->st.image_width; ra.H = c->st.image_height;
+    ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
+    ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
+    const dim3 gridT((c->ntiles + 3) / 4), blk(256);
+    if (obj) hipLaunchKernelGGL(k_render_bwd<true>, gridT, blk, 0, st, ra);
+    else hipLaunchKernelGGL(k_render_bwd<false>, gridT, blk, 0, st, ra);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "render backward: launch failed: %s", hipGetErrorString(e)));
+  }
+  {
+    StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
+    PreBwdArgs pa;
+    pa.P = P; pa.K = c->K; pa.va = view_args(c->st);
+    pa.order = c->order; pa.off = c->off; pa.R0 = c->R0; pa.R1 = c->R1; pa.R2 = c->R2;
+    pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
+    pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
+    pa.dmeans3D = dmeans3D; pa.dmeans2D = dmeans2D; pa.dsh = c->shs ? dshs : nullptr; pa.dsh_objs = dsh_objs;
+    pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
+    pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
+    pa.dcov3d = c->cov3d ? dcov3D : nullptr;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
+  }
+  return done(GSR_OK);
+}
+
+int gsr_mark_visible(const GsrSettings* s, int32_t P, const float* means3D, uint8_t* present, void* stream) {
+  if (!s || !s->viewmatrix || !means3D || !present) return set_err(GSR_ERR_INVALID, "gsr_mark_visible: null argument");
+  if (P <= 0) return GSR_OK;
+  hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), P,
+                     s->viewmatrix, means3D, present);
+  LAUNCH_CHECK("mark_visible");
+  return GSR_OK;
+}
+
+int gsr_query(int32_t what, int64_t* out) {
+  if (!out) return set_err(GSR_ERR_INVALID, "gsr_query: null out");
+  switch (what) {
+    case 0: *out = GSR_VERSION; return GSR_OK;
+    case 1: {
+      Pool& pl = g_pool[cur_dev()];
+      std::lock_guard<std::mutex> lk(pl.mu);
+      *out = (int64_t)pl.total;
+      return GSR_OK;
+    }
+    default: return set_err(GSR_ERR_INVALID, "gsr_query: unknown item %d", what);
+  }
+}
+
+int gsr_ctx_info(const GsrCtx* c, int32_t what, int64_t* out) {
+  if (!c || !out) return set_err(GSR_ERR_INVALID, "gsr_ctx_info: null argument");
+  switch (what) {
+    case 0: *out = (int64_t)c->N; return GSR_OK;
+    case 1: *out = -1; return GSR_OK;
+    case 2: *out = (int64_t)(c->keep_bytes + sizeof(uint32_t) * (size_t)c->N); return GSR_OK;
+    default: return set_err(GSR_ERR_INVALID, "gsr_ctx_info: unknown item %d", what);
+  }
+}
+
+void gsr_trim_pool(void) {
+  const int dev = cur_dev();
+  (void)hipDeviceSynchronize();
+  Pool& pl = g_pool[dev];
+  std::lock_guard<std::mutex> lk(pl.mu);
+  std::vector<Block> keep;
+  for (Block& b : pl.blocks) {
+    if (b.used) keep.push_back(b);
+    else { (void)hipFree(b.p); pl.total -= b.bytes; }
+  }
+  pl.blocks.swap(keep);
+}
+
+int gsr_test_scan(const uint32_t* in, uint32_t* out, uint32_t n, void* stream) {
+  if (!in || !out) return set_err(GSR_ERR_INVALID, "gsr_test_scan: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)n / SCAN_CHUNK + 2), st);
+  if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_test_scan: allocation failed");
+  scan_exclusive_u32(in, out, n, static_cast<uint32_t*>(blk), out + n, st);
+  pool_free(dev, blk);
+  LAUNCH_CHECK("test scan");
+  return GSR_OK;
+}
+
+int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begin_bit, int32_t end_bit, int32_t iota,
+                        void* stream) {
+  if (!keys || !vals) return set_err(GSR_ERR_INVALID, "gsr_test_sort_pairs: null argument");
+  if (n == 0) return GSR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  const uint32_t tbl = radix_table_words(n);
+  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)2 * n + tbl + tbl / SCAN_CHUNK + 8), st);
+  if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_test_sort_pairs: allocation failed");
+  uint32_t* k1 = static_cast<uint32_t*>(blk);
+  uint32_t* v1 = k1 + n;
+  uint32_t* table = v1 + n;
+  uint32_t* sums = table + tbl;
+  const int res = radix_sort_pairs(keys, vals, k1, v1, n, begin_bit, end_bit, iota != 0, table, sums, st);
+  if (res) {
+    (void)hipMemcpyAsync(keys, k1, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(vals, v1, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st);
+  }
+  pool_free(dev, blk);
+  LAUNCH_CHECK("test sort");
+  return GSR_OK;
+}
+
+void gsr_profile(int32_t enable) {
+  t_prof = enable != 0;
+  for (ProfSpan& s : t_spans) { t_free_events.push_back(s.a); t_free_events.push_back(s.b); }
+  t_spans.clear();
+  for (int i = 0; i < GSR_STAGE_COUNT; ++i) { t_ms[i] = 0.f; t_calls[i] = 0; }
+}
+
+int gsr_profile_read(float* ms, int64_t* calls) {
+  for (ProfSpan& s : t_spans) {
+    hipError_t e = hipEventSynchronize(s.b);
+    if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_profile_read: %s", hipGetErrorString(e));
+    float m = 0.f;
+    if (hipEventElapsedTime(&m, s.a, s.b) == hipSuccess) { t_ms[s.stage] += m; t_calls[s.stage] += 1; }
+    t_free_events.push_back(s.a); t_free_events.push_back(s.b);
+  }
+  t_spans.clear();
+  for (int i = 0; i < GSR_STAGE_COUNT; ++i) {
+    if (ms) ms[i] = t_ms[i];
+    if (calls) calls[i] = t_calls[i];
+  }
+  return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,608 @@
+// gsr_kernels.hip.h -- the raster path's kernels, hand-written for gfx950 (wave64, LDS-staged tile
+// lists, DPP wave reductions).  Stage names follow SURVEY.md section 2.2 (K1..K10).
+//
+// Data layout in HBM (all float32 / uint32):
+//   G0,G1,G2[g]   per-Gaussian screen geometry written by K1, 3 x float4:
+//                 G0=(px,py,A,B)  G1=(C,opacity,r,g)  G2=(b, depth, rectx_bits, recty_bits)
+//                 rectx_bits = minx | maxx<<12 | clampbits<<24,  recty_bits = miny | maxy<<12   (tile units)
+//   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF when culled
+//   order[r]      Gaussian index of depth rank r (stable radix argsort of dkey)
+//   R0,R1,R2[r]   the same records gathered into depth order; R2.y = bits(g)
+//   off[r]        exclusive scan of tiles touched, off[P] = N
+//   pair_tile/pair_rank[N]  (tile id, rank) pairs, emitted rank-major, then stably sorted by tile id
+//   ranges[t]     [start,end) of tile t in the sorted pair list
+//   final_T, n_contrib [H*W]  per-pixel transmittance / last contributing list position (1-based)
+//   part[N][12]   backward: per-(tile,Gaussian) partial sums written at the pair's EMISSION slot, so
+//                 that the rows of one Gaussian are contiguous and K8/K9 reduces them without atomics
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gsr_math.h"
+
+namespace gsr {
+
+struct ViewArgs {
+  const float* vm;
+  const float* pm;
+  const float* cam;
+  int H, W;
+  float tanfovx, tanfovy, mod;
+  int deg;
+};
+
+__device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
+  make_view(v, a.vm, a.pm, a.cam, a.H, a.W, a.tanfovx, a.tanfovy, a.mod, a.deg);
+}
+
+constexpr uint32_t RECT_MASK = 0xFFFu;
+
+// ------------------------------------------------------------------------------------------------
+// K1: per-Gaussian preprocess
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, const float* __restrict__ means,
+                                                    const float* __restrict__ scales, const float* __restrict__ rots,
+                                                    const float* __restrict__ cov3d, const float* __restrict__ opac,
+                                                    const float* __restrict__ sh, const float* __restrict__ colors,
+                                                    int32_t* __restrict__ radii, float4* __restrict__ G0,
+                                                    float4* __restrict__ G1, float4* __restrict__ G2,
+                                                    uint32_t* __restrict__ dkey) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+  View v;
+  load_view(v, va);
+  const float p[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+  float c6[6];
+  if (cov3d) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c6[i] = cov3d[6 * g + i];
+  } else {
+    const float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    cov3d_from_scale_rot(s, va.mod, q, c6);
+  }
+  Splat s;
+  const bool ok = project_splat(v, p, c6, s);
+  if (!ok) {
+    radii[g] = 0;
+    dkey[g] = 0xFFFFFFFFu;
+    G2[g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
+    return;
+  }
+  float rgb[3];
+  uint32_t cl = 0;
+  if (colors) {
+    rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2];
+  } else {
+    cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
+  }
+  radii[g] = s.radius;
+  dkey[g] = __float_as_uint(s.depth);
+  const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
+  const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
+  G0[g] = make_float4(s.px, s.py, s.A, s.B);
+  G1[g] = make_float4(s.C, opac[g], rgb[0], rgb[1]);
+  G2[g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
+}
+
+// K10
+__global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __restrict__ vm,
+                                                      const float* __restrict__ means, uint8_t* __restrict__ present) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P) return;
+  const float z = means[3 * g] * vm[2] + means[3 * g + 1] * vm[6] + means[3 * g + 2] * vm[10] + vm[14];
+  present[g] = z > NEAR_Z ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather the records into depth order and count the tiles each rank touches
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack(int P, const uint32_t* __restrict__ order,
+                                              const uint32_t* __restrict__ skey, const float4* __restrict__ G0,
+                                              const float4* __restrict__ G1, const float4* __restrict__ G2,
+                                              float4* __restrict__ R0, float4* __restrict__ R1,
+                                              float4* __restrict__ R2, uint32_t* __restrict__ cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P) return;
+  const uint32_t g = order[r];
+  if (skey[r] == 0xFFFFFFFFu) {   // culled: all such ranks sit at the tail
+    cnt[r] = 0;
+    R2[r] = make_float4(0.f, __uint_as_float(g), 0.f, 0.f);
+    return;
+  }
+  const float4 a = G0[g], b = G1[g], c = G2[g];
+  const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
+  const uint32_t wx = ((rx >> 12) & RECT_MASK) - (rx & RECT_MASK);
+  const uint32_t wy = ((ry >> 12) & RECT_MASK) - (ry & RECT_MASK);
+  cnt[r] = wx * wy;
+  R0[r] = a;
+  R1[r] = b;
+  R2[r] = make_float4(c.x, __uint_as_float(g), c.z, c.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: emit (tile, rank) pairs, one thread per OUTPUT slot (perfectly balanced, coalesced writes)
+// ------------------------------------------------------------------------------------------------
+constexpr int EMIT_SLOTS = 1024;
+
+__device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo, uint32_t hi, uint32_t target) {
+  // largest r in [lo,hi) with off[r] <= target   (off is non-decreasing, off[lo] <= target)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= target) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, uint32_t P, uint32_t N,
+                                              const float4* __restrict__ R2, int gridx,
+                                              uint32_t* __restrict__ pair_tile, uint32_t* __restrict__ pair_rank) {
+  __shared__ uint32_t s_off[EMIT_SLOTS + 1];
+  __shared__ uint32_t s_r[2];
+  const uint32_t e0 = blockIdx.x * EMIT_SLOTS;
+  const uint32_t e1 = min(e0 + (uint32_t)EMIT_SLOTS, N);
+  if (threadIdx.x < 2) s_r[threadIdx.x] = upper_rank(off, 0, P + 1, threadIdx.x == 0 ? e0 : e1 - 1);
+  __syncthreads();
+  const uint32_t r_lo = s_r[0], r_hi = s_r[1];
+  const uint32_t span = r_hi - r_lo + 1;
+  const bool in_lds = span <= (uint32_t)(EMIT_SLOTS + 1);
+  if (in_lds)
+    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_off[i] = off[r_lo + i];
+  __syncthreads();
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    uint32_t r, o;
+    if (in_lds) {
+      const uint32_t i = upper_rank(s_off, 0, span, e);
+      r = r_lo + i; o = s_off[i];
+    } else {
+      r = upper_rank(off, r_lo, r_hi + 1, e); o = off[r];
+    }
+    const float4 c = R2[r];
+    const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
+    const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
+    const uint32_t local = e - o;
+    const uint32_t dy = local / wx, dx = local - dy * wx;
+    pair_tile[e] = (miny + dy) * (uint32_t)gridx + minx + dx;
+    pair_rank[e] = r;
+  }
+}
+
+// K5
+__global__ void __launch_bounds__(256) k_ranges(uint32_t N, const uint32_t* __restrict__ tiles,
+                                                uint2* __restrict__ ranges) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t t = tiles[i];
+  if (i == 0 || tiles[i - 1] != t) ranges[t].x = i;
+  if (i == N - 1 || tiles[i + 1] != t) ranges[t].y = i + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: forward composite.  One WAVE per 16x16 tile, 4 pixels per lane (rows y0+{0,4,8,12}+lane/16):
+// an entry staged once in LDS is broadcast to 256 pixels, no block barrier anywhere (each wave owns
+// its LDS slice), early-out by wave ballot.
+// ------------------------------------------------------------------------------------------------
+struct RenderArgs {
+  const uint2* ranges;
+  const uint32_t* pair_rank;
+  const float4* R0;
+  const float4* R1;
+  const float4* R2;
+  const float* sh_objs;   // [P,16] or null
+  const float* bg;
+  int W, H, gridx, ntiles;
+  float* out_color;       // [3,H,W]
+  float* out_objects;     // [16,H,W] or null
+  float* final_T;         // [H*W]
+  uint32_t* n_contrib;    // [H*W]
+};
+
+constexpr int PXL = 4;   // pixels per lane
+
+template <bool OBJ>
+__global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
+  __shared__ float4 s0[4][64];
+  __shared__ float4 s1[4][64];
+  __shared__ float s2[4][64];
+  __shared__ float so[OBJ ? 4 : 1][OBJ ? 64 : 1][NUM_OBJ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= a.ntiles) return;
+  const int tx = tile % a.gridx, ty = tile / a.gridx;
+  const uint2 rg = a.ranges[tile];
+  const int x = tx * TILE + (lane & 15);
+  const float pxf = (float)x;
+  int y[PXL];
+  float pyf[PXL], T[PXL], C[PXL][3];
+  float O[OBJ ? PXL : 1][NUM_OBJ];
+  uint32_t last[PXL];
+  bool done[PXL];
+#pragma unroll
+  for (int k = 0; k < PXL; ++k) {
+    y[k] = ty * TILE + (lane >> 4) + 4 * k;
+    pyf[k] = (float)y[k];
+    T[k] = 1.f; C[k][0] = C[k][1] = C[k][2] = 0.f;
+    last[k] = 0;
+    done[k] = !(x < a.W && y[k] < a.H);
+    if (OBJ) {
+#pragma unroll
+      for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = 0.f;
+    }
+  }
+  for (uint32_t base = rg.x; base < rg.y; base += 64) {
+    if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
+    const uint32_t i = base + lane;
+    if (i < rg.y) {
+      const uint32_t r = a.pair_rank[i];
+      const float4 c = a.R2[r];
+      s0[wave][lane] = a.R0[r];
+      s1[wave][lane] = a.R1[r];
+      s2[wave][lane] = c.x;
+      if (OBJ) {
+        const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
+        float4* dst = reinterpret_cast<float4*>(&so[wave][lane][0]);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int cnt = min(64u, rg.y - base);
+    for (int j = 0; j < cnt; ++j) {
+      const float4 e0 = s0[wave][j];
+      const float4 e1 = s1[wave][j];
+      const float eb = s2[wave][j];
+      const uint32_t pos = base - rg.x + j + 1;
+      const float dx = e0.x - pxf;
+      bool live = false;
+#pragma unroll
+      for (int k = 0; k < PXL; ++k) {
+        if (!done[k]) {
+          const float dy = e0.y - pyf[k];
+          float alpha, G;
+          if (splat_alpha(dx, dy, e0.z, e0.w, e1.x, e1.y, alpha, G)) {
+            const float Tn = T[k] * (1.f - alpha);
+            if (Tn < T_STOP) {
+              done[k] = true;
+            } else {
+              const float w = alpha * T[k];
+              C[k][0] += e1.z * w; C[k][1] += e1.w * w; C[k][2] += eb * w;
+              if (OBJ) {
+#pragma unroll
+                for (int c = 0; c < NUM_OBJ; ++c) O[k][c] += so[wave][j][c] * w;
+              }
+              T[k] = Tn;
+              last[k] = pos;
+            }
+          }
+          live = live || !done[k];
+        }
+      }
+      if (!__any(live)) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const size_t HW = (size_t)a.H * a.W;
+#pragma unroll
+  for (int k = 0; k < PXL; ++k) {
+    if (x < a.W && y[k] < a.H) {
+      const size_t pix = (size_t)y[k] * a.W + x;
+      a.out_color[pix] = C[k][0] + T[k] * bg0;
+      a.out_color[HW + pix] = C[k][1] + T[k] * bg1;
+      a.out_color[2 * HW + pix] = C[k][2] + T[k] * bg2;
+      a.final_T[pix] = T[k];
+      a.n_contrib[pix] = last[k];
+      if (OBJ) {
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) a.out_objects[c * HW + pix] = O[k][c];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 sum via DPP: after the call lanes 48..63 hold the total
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_to_hi(float v) {
+  v += dpp_mov<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_mov<0x140, 0xF>(v);   // row_mirror  -> every lane holds its row's sum
+  v += dpp_mov<0x142, 0xA>(v);   // row_bcast15 into rows 1,3
+  v += dpp_mov<0x143, 0xC>(v);   // row_bcast31 into rows 2,3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: backward composite, same tiling, list walked back to front.  Per (tile, entry) the wave reduces
+// nine sums over its 256 pixels in registers + DPP and stores ONE 48-byte row at the pair's emission
+// slot: no global atomics, bitwise reproducible.  Row = (Sq dx, Sq dy, Sq dx^2, Sq dx dy, Sq dy^2,
+// S G dL/dalpha, S w g_r, S w g_g, S w g_b, 0,0,0) with q = o G dL/dalpha.
+// ------------------------------------------------------------------------------------------------
+struct RenderBwdArgs {
+  const uint2* ranges;
+  const uint32_t* pair_rank;
+  const uint32_t* off;
+  const float4* R0;
+  const float4* R1;
+  const float4* R2;
+  const float* sh_objs;
+  const float* bg;
+  int W, H, gridx, ntiles;
+  const float* final_T;
+  const uint32_t* n_contrib;
+  const float* grad_color;    // [3,H,W]
+  const float* grad_objects;  // [16,H,W] or null
+  float4* part;               // [N][3]
+  float4* part_obj;           // [N][4] or null
+};
+
+constexpr int PART_F4 = 3;
+
+template <bool OBJ>
+__global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
+  __shared__ float4 s0[4][64];
+  __shared__ float4 s1[4][64];
+  __shared__ float s2[4][64];
+  __shared__ uint32_t sslot[4][64];
+  __shared__ float so[OBJ ? 4 : 1][OBJ ? 64 : 1][NUM_OBJ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= a.ntiles) return;
+  const int tx = tile % a.gridx, ty = tile / a.gridx;
+  const uint2 rg = a.ranges[tile];
+  const int x = tx * TILE + (lane & 15);
+  const float pxf = (float)x;
+  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const size_t HW = (size_t)a.H * a.W;
+  float pyf[PXL], T[PXL], Acc[PXL], la[PXL], lcg[PXL], g0[PXL], g1[PXL], g2[PXL], bgd[PXL];
+  float gO[OBJ ? PXL : 1][NUM_OBJ];
+  uint32_t ncon[PXL];
+  uint32_t maxc = 0;
+#pragma unroll
+  for (int k = 0; k < PXL; ++k) {
+    const int y = ty * TILE + (lane >> 4) + 4 * k;
+    pyf[k] = (float)y;
+    Acc[k] = 0.f; la[k] = 0.f; lcg[k] = 0.f;
+    if (x < a.W && y < a.H) {
+      const size_t pix = (size_t)y * a.W + x;
+      const float Tf = a.final_T[pix];
+      T[k] = Tf;
+      ncon[k] = a.n_contrib[pix];
+      g0[k] = a.grad_color[pix]; g1[k] = a.grad_color[HW + pix]; g2[k] = a.grad_color[2 * HW + pix];
+      bgd[k] = Tf * (bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k]);
+      if (OBJ) {
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = a.grad_objects[c * HW + pix];
+      }
+    } else {
+      T[k] = 1.f; ncon[k] = 0; g0[k] = g1[k] = g2[k] = 0.f; bgd[k] = 0.f;
+      if (OBJ) {
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = 0.f;
+      }
+    }
+    maxc = max(maxc, ncon[k]);
+  }
+  maxc = wave_max_u32(maxc);
+  maxc = __builtin_amdgcn_readfirstlane(maxc);
+  for (int hi = (int)maxc; hi > 0; hi -= 64) {
+    const int lo = max(hi - 64, 0);
+    const int cnt = hi - lo;
+    if (lane < cnt) {
+      const uint32_t r = a.pair_rank[rg.x + lo + lane];
+      const float4 c = a.R2[r];
+      s0[wave][lane] = a.R0[r];
+      s1[wave][lane] = a.R1[r];
+      s2[wave][lane] = c.x;
+      const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
+      const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
+      sslot[wave][lane] = a.off[r] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx);
+      if (OBJ) {
+        const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
+        float4* dst = reinterpret_cast<float4*>(&so[wave][lane][0]);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = cnt - 1; j >= 0; --j) {
+      const float4 e0 = s0[wave][j];
+      const float4 e1 = s1[wave][j];
+      const float eb = s2[wave][j];
+      const uint32_t pos = (uint32_t)(lo + j + 1);
+      const float dx = e0.x - pxf;
+      float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+      float dobj[OBJ ? NUM_OBJ : 1];
+      if (OBJ) {
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = 0.f;
+      }
+      bool hit = false;
+#pragma unroll
+      for (int k = 0; k < PXL; ++k) {
+        if (pos <= ncon[k]) {
+          const float dy = e0.y - pyf[k];
+          float alpha, G;
+          if (splat_alpha(dx, dy, e0.z, e0.w, e1.x, e1.y, alpha, G)) {
+            hit = true;
+            const float inv1m = 1.0f / (1.f - alpha);
+            T[k] *= inv1m;
+            const float w = alpha * T[k];
+            float cg = e1.z * g0[k] + e1.w * g1[k] + eb * g2[k];
+            if (OBJ) {
+#pragma unroll
+              for (int c = 0; c < NUM_OBJ; ++c) {
+                const float f = so[wave][j][c];
+                cg += f * gO[k][c];
+                dobj[c] += w * gO[k][c];
+              }
+            }
+            Acc[k] = la[k] * lcg[k] + (1.f - la[k]) * Acc[k];
+            lcg[k] = cg;
+            la[k] = alpha;
+            const float dLda = T[k] * (cg - Acc[k]) - bgd[k] * inv1m;
+            dr += w * g0[k]; dg += w * g1[k]; db += w * g2[k];
+            dop += G * dLda;
+            const float q = e1.y * G * dLda;
+            const float qx = q * dx, qy = q * dy;
+            mx += qx; my += qy; mxx += qx * dx; mxy += qx * dy; myy += qy * dy;
+          }
+        }
+      }
+      if (__any(hit)) {
+        mx = wave_sum_to_hi(mx); my = wave_sum_to_hi(my); mxx = wave_sum_to_hi(mxx);
+        mxy = wave_sum_to_hi(mxy); myy = wave_sum_to_hi(myy); dop = wave_sum_to_hi(dop);
+        dr = wave_sum_to_hi(dr); dg = wave_sum_to_hi(dg); db = wave_sum_to_hi(db);
+        if (OBJ) {
+#pragma unroll
+          for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = wave_sum_to_hi(dobj[c]);
+        }
+        if (lane == 63) {
+          const uint32_t slot = sslot[wave][j];
+          float4* row = a.part + (size_t)slot * PART_F4;
+          row[0] = make_float4(mx, my, mxx, mxy);
+          row[1] = make_float4(myy, dop, dr, dg);
+          row[2] = make_float4(db, 0.f, 0.f, 0.f);
+          if (OBJ) {
+            float4* ro = a.part_obj + (size_t)slot * 4;
+            ro[0] = make_float4(dobj[0], dobj[1], dobj[2], dobj[3]);
+            ro[1] = make_float4(dobj[4], dobj[5], dobj[6], dobj[7]);
+            ro[2] = make_float4(dobj[8], dobj[9], dobj[10], dobj[11]);
+            ro[3] = make_float4(dobj[12], dobj[13], dobj[14], dobj[15]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8+K9 fused with the per-Gaussian reduction of the partial rows: one thread per depth rank.
+// ------------------------------------------------------------------------------------------------
+struct PreBwdArgs {
+  int P, K;
+  ViewArgs va;
+  const uint32_t* order;
+  const uint32_t* off;
+  const float4* R0;
+  const float4* R1;
+  const float4* R2;
+  const float4* part;
+  const float4* part_obj;
+  const float* means;
+  const float* scales;
+  const float* rots;
+  const float* cov3d;
+  const float* sh;
+  float* dmeans3D;
+  float* dmeans2D;
+  float* dsh;
+  float* dsh_objs;
+  float* dcolors;
+  float* dopac;
+  float* dscales;
+  float* drots;
+  float* dcov3d;
+};
+
+__global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.P) return;
+  const uint32_t g = a.order[r];
+  const uint32_t o0 = a.off[r], o1 = a.off[r + 1];
+  const int K = a.K;
+  if (o1 == o0) {   // culled: zero gradients
+    if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
+    if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
+    if (a.dsh) for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] = 0.f;
+    if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
+    if (a.dcolors) { a.dcolors[3 * g] = 0.f; a.dcolors[3 * g + 1] = 0.f; a.dcolors[3 * g + 2] = 0.f; }
+    if (a.dopac) a.dopac[g] = 0.f;
+    if (a.dscales) { a.dscales[3 * g] = 0.f; a.dscales[3 * g + 1] = 0.f; a.dscales[3 * g + 2] = 0.f; }
+    if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
+    if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
+    return;
+  }
+  float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+  for (uint32_t e = o0; e < o1; ++e) {
+    const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+    mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+  }
+  if (a.dsh_objs) {
+    float acc[NUM_OBJ];
+#pragma unroll
+    for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
+    if (a.part_obj) {
+      for (uint32_t e = o0; e < o1; ++e) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = a.part_obj[(size_t)e * 4 + q];
+          acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
+  }
+  View v;
+  load_view(v, a.va);
+  const float4 e0 = a.R0[r], e1 = a.R1[r], e2 = a.R2[r];
+  const float A = e0.z, B = e0.w, C = e1.x;
+  // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
+  const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
+  const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
+  const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
+  if (a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
+  if (a.dopac) a.dopac[g] = dop;
+  const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+  float dp[3] = {0.f, 0.f, 0.f};
+  if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
+  if (a.sh) {
+    const uint32_t cl = __float_as_uint(e2.z) >> 24;
+    const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
+    if (a.dsh) {
+      sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
+    } else {
+      float scratch[48];
+      sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
+    }
+  }
+  float c6[6];
+  float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.cov3d) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
+  } else {
+    s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
+    const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    cov3d_from_scale_rot(s, a.va.mod, q, c6);
+  }
+  float dc6[6];
+  project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+  if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
+  if (a.cov3d) {
+    if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
+  } else if (a.dscales || a.drots) {
+    float ds[3], dq[4];
+    cov3d_bwd(s, a.va.mod, q, dc6, ds, dq);
+    if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
+    if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+  }
+}
+
+}  // namespace gsr

@@ -1,0 +1,229 @@
+// gsr_sort.hip.h -- wave64 scan, exclusive scan over u32 arrays and a stable LSD radix sort of
+// (u32 key, u32 value) pairs, hand-written for gfx950.
+//
+// Replaces what the absent reference extension gets from a vendor scan/sort library (SURVEY.md section
+// 2.2, K2/K4).  Design for MI355X rather than a translation: the depth order and the tile binning are
+// two SEPARATE small-key sorts (32-bit depth over P Gaussians, then ceil(log2 T) bits of tile id over
+// the N duplicated pairs) instead of one 64-bit (tile<<32|depth) sort over N pairs -- ~4.5x less HBM
+// traffic -- and every pass ranks with wave64 ballots (no per-thread digit counters), stages its
+// 4096-element chunk in LDS and writes digit runs back coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsr {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;   // 4096
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the block total in `total`.
+// `tmp` is 4 words of LDS.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* tmp, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan_u32(v);
+  if (lane == 63) tmp[w] = incl;
+  __syncthreads();
+  const uint32_t t0 = tmp[0], t1 = tmp[1], t2 = tmp[2], t3 = tmp[3];
+  total = t0 + t1 + t2 + t3;
+  const uint32_t wbase = (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+  __syncthreads();
+  return wbase + incl - v;
+}
+
+// ---- exclusive scan over n u32 (three launches; the middle one is a single block) ----------------
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial(const uint32_t* __restrict__ in, uint32_t n,
+                                                               uint32_t* __restrict__ sums) {
+  __shared__ uint32_t tmp[4];
+  const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) s += (base + i < n) ? in[base + i] : 0u;
+  uint32_t total;
+  block_excl_scan_256(s, tmp, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// in-place exclusive scan of sums[nb] by one block; total -> *total_out (may be null)
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict__ sums, uint32_t nb,
+                                                            uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t tmp[4];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += SCAN_THREADS) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = (i < nb) ? sums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_256(v, tmp, total);
+    if (i < nb) sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* in, uint32_t* out,
+                                                             uint32_t n, const uint32_t* __restrict__ sums) {
+  __shared__ uint32_t tmp[4];
+  const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+  uint32_t total;
+  uint32_t run = block_excl_scan_256(s, tmp, total) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+}
+
+// out may alias in.  sums must hold ceil(n/4096) words.  total_out (device) receives the grand total.
+inline void scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out,
+                               hipStream_t st) {
+  if (n == 0) {
+    if (total_out) (void)hipMemsetAsync(total_out, 0, sizeof(uint32_t), st);
+    return;
+  }
+  const uint32_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb, total_out);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, sums);
+}
+
+// ---- stable LSD radix sort pass over (key,val) pairs ------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = 4;
+constexpr int RS_ROUNDS = 16;                       // 64-element rounds per wave
+constexpr int RS_CHUNK = RS_WAVES * RS_ROUNDS * 64; // 4096 elements per block
+constexpr int RS_BINS = 256;
+
+__global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                           uint32_t mask, uint32_t* __restrict__ table, uint32_t nb) {
+  __shared__ uint32_t h[RS_BINS];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * RS_CHUNK;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < RS_CHUNK; i += RS_THREADS) {
+    const uint32_t idx = base + i;
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  table[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];   // digit-major: one linear scan gives global bases
+}
+
+// table: exclusive-scanned [256][nb].  iota != 0: values are the element indices (first pass of an argsort).
+__global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in,
+                                                              const uint32_t* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                              uint32_t mask, const uint32_t* __restrict__ table,
+                                                              uint32_t nb, int iota) {
+  __shared__ uint32_t wcnt[RS_WAVES][RS_BINS];
+  __shared__ uint32_t gbase[RS_BINS];
+  __shared__ uint32_t tmp[4];
+  __shared__ uint32_t skey[RS_CHUNK];
+  __shared__ uint32_t sval[RS_CHUNK];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t base = blockIdx.x * RS_CHUNK + w * (RS_ROUNDS * 64);
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) wcnt[i][tid] = 0;
+  __syncthreads();
+
+  uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rnk[RS_ROUNDS];
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const uint32_t idx = base + j * 64 + lane;
+    const bool ok = idx < n;
+    key[j] = ok ? keys_in[idx] : 0xFFFFFFFFu;     // padding sorts last inside its digit and is never written
+    val[j] = ok ? (iota ? idx : vals_in[idx]) : 0u;
+  }
+  const uint64_t lt = (1ull << lane) - 1ull;
+  volatile uint32_t* myc = wcnt[w];
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const uint32_t d = (key[j] >> shift) & mask;
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t before = __popcll(peers & lt);
+    const uint32_t pre = myc[d];
+    __builtin_amdgcn_wave_barrier();
+    if (before == 0) myc[d] = pre + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rnk[j] = pre + before;
+  }
+  __syncthreads();
+  {
+    // thread = digit: start of this digit in the block-local order, then per-wave bases
+    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+    uint32_t total;
+    const uint32_t ds = block_excl_scan_256(c0 + c1 + c2 + c3, tmp, total);
+    wcnt[0][tid] = ds;
+    wcnt[1][tid] = ds + c0;
+    wcnt[2][tid] = ds + c0 + c1;
+    wcnt[3][tid] = ds + c0 + c1 + c2;
+    gbase[tid] = table[tid * nb + blockIdx.x] - ds;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const uint32_t d = (key[j] >> shift) & mask;
+    const uint32_t p = wcnt[w][d] + rnk[j];
+    skey[p] = key[j];
+    sval[p] = val[j];
+  }
+  __syncthreads();
+  const uint32_t blk0 = blockIdx.x * RS_CHUNK;
+  const uint32_t nvalid = (n - blk0 < (uint32_t)RS_CHUNK) ? (n - blk0) : (uint32_t)RS_CHUNK;
+  for (uint32_t p = tid; p < nvalid; p += RS_THREADS) {
+    const uint32_t k = skey[p];
+    const uint32_t g = gbase[(k >> shift) & mask] + p;
+    keys_out[g] = k;
+    vals_out[g] = sval[p];
+  }
+}
+
+inline uint32_t radix_table_words(uint32_t n) { return RS_BINS * ((n + RS_CHUNK - 1) / RS_CHUNK); }
+
+// Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong; returns 0 if the result is in (k0,v0), 1 if in
+// (k1,v1).  iota_first: the values of the first pass are the element indices (v0 is then never read).
+// table: radix_table_words(n) words; sums: ceil(table_words/4096) words.
+inline int radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n, int begin_bit,
+                            int end_bit, bool iota_first, uint32_t* table, uint32_t* sums, hipStream_t st) {
+  if (n == 0 || end_bit <= begin_bit) return 0;
+  const int bits = end_bit - begin_bit;
+  const int passes = (bits + 7) / 8;
+  const uint32_t nb = (n + RS_CHUNK - 1) / RS_CHUNK;
+  int cur = 0, bit = begin_bit;
+  for (int p = 0; p < passes; ++p) {
+    // spread the bits evenly over the passes (13 bits -> 7 + 6): longer digit runs per block
+    const int w = (bits - (bit - begin_bit) + (passes - p) - 1) / (passes - p);
+    const uint32_t mask = (1u << w) - 1u;
+    uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
+    uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
+    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, bit, mask, table, nb);
+    scan_exclusive_u32(table, table, RS_BINS * nb, sums, nullptr, st);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask, table, nb,
+                       (iota_first && p == 0) ? 1 : 0);
+    cur ^= 1;
+    bit += w;
+  }
+  return cur;
+}
+
+}  // namespace gsr

@@ -1,0 +1,343 @@
+"""diff_gaussian_rasterization -- MI355X-native drop-in for the rasteriser the reference imports.
+
+The reference does ``from diff_gaussian_rasterization import GaussianRasterizationSettings,
+GaussianRasterizer`` (reference gaussian_renderer/__init__.py:14), builds the settings with the 12
+keyword fields of :36-49, constructs ``GaussianRasterizer(raster_settings=...)`` (:51) and calls it with
+the keyword arguments of :86-95, getting ``(color[3,H,W], radii[P] int32, objects[16,H,W])``.  This
+package provides exactly that surface on top of ``libgsraster.so`` (hand-written HIP for gfx950, C ABI
+declared in include/gsraster.h), bound with ctypes: PyTorch only supplies device memory, the current
+stream and autograd plumbing.
+
+There is NO fallback: without the compiled library or without a HIP device every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+NUM_OBJECTS = 16
+_LIB_NAME = "libgsraster.so"
+_lib = None
+
+GSR_STAGES = ("preprocess", "depth_sort", "bin", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
+
+
+class _CSettings(ctypes.Structure):
+    # field order and types mirror `struct GsrSettings` in include/gsraster.h
+    _fields_ = [
+        ("image_height", ctypes.c_int32),
+        ("image_width", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float),
+        ("tanfovy", ctypes.c_float),
+        ("bg", ctypes.c_void_p),
+        ("scale_modifier", ctypes.c_float),
+        ("viewmatrix", ctypes.c_void_p),
+        ("projmatrix", ctypes.c_void_p),
+        ("sh_degree", ctypes.c_int32),
+        ("campos", ctypes.c_void_p),
+        ("prefiltered", ctypes.c_int32),
+        ("debug", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+    ]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def _load():
+    """Load libgsraster.so once; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"diff_gaussian_rasterization: {path} is missing. Build it with "
+            f"`make -C {os.path.join(os.path.dirname(os.path.dirname(path)), 'csrc')}` (hipcc, gfx950); "
+            "there is no CPU or PyTorch fallback for the raster path.")
+    lib = ctypes.CDLL(path)
+    vp, i32, i64p = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)
+    lib.gsr_forward.restype = ctypes.c_int
+    lib.gsr_forward.argtypes = [ctypes.POINTER(_CSettings), i32, i32] + [vp] * 8 + [vp, vp, vp,
+                                ctypes.POINTER(vp), i64p, vp]
+    lib.gsr_backward.restype = ctypes.c_int
+    lib.gsr_backward.argtypes = [vp] * 13
+    lib.gsr_ctx_free.restype = None
+    lib.gsr_ctx_free.argtypes = [vp]
+    lib.gsr_mark_visible.restype = ctypes.c_int
+    lib.gsr_mark_visible.argtypes = [ctypes.POINTER(_CSettings), i32, vp, vp, vp]
+    lib.gsr_query.restype = ctypes.c_int
+    lib.gsr_query.argtypes = [i32, i64p]
+    lib.gsr_ctx_info.restype = ctypes.c_int
+    lib.gsr_ctx_info.argtypes = [vp, i32, i64p]
+    lib.gsr_trim_pool.restype = None
+    lib.gsr_trim_pool.argtypes = []
+    lib.gsr_profile.restype = None
+    lib.gsr_profile.argtypes = [i32]
+    lib.gsr_profile_read.restype = ctypes.c_int
+    lib.gsr_profile_read.argtypes = [ctypes.POINTER(ctypes.c_float), i64p]
+    lib.gsr_test_scan.restype = ctypes.c_int
+    lib.gsr_test_scan.argtypes = [vp, vp, ctypes.c_uint32, vp]
+    lib.gsr_test_sort_pairs.restype = ctypes.c_int
+    lib.gsr_test_sort_pairs.argtypes = [vp, vp, ctypes.c_uint32, i32, i32, i32, vp]
+    lib.gsr_last_error.restype = ctypes.c_char_p
+    lib.gsr_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def _err(lib) -> str:
+    msg = lib.gsr_last_error()
+    return msg.decode("utf-8", "replace") if msg else "unknown error"
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    """The 12 fields of the call site, in its order (reference gaussian_renderer/__init__.py:36-49)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
+
+
+class _SettingsPack:
+    """C settings + the device tensors it points into (kept alive as long as the pack lives)."""
+
+    def __init__(self, rs: GaussianRasterizationSettings, device):
+        self.device = device
+        self.bg = _f32c(rs.bg.detach().flatten(), device)
+        if self.bg.numel() < 3:
+            raise ValueError("bg must hold at least 3 values")
+        self.vm = _f32c(rs.viewmatrix.detach(), device)
+        self.pm = _f32c(rs.projmatrix.detach(), device)
+        self.cam = _f32c(rs.campos.detach().flatten(), device)
+        if self.vm.numel() != 16 or self.pm.numel() != 16 or self.cam.numel() < 3:
+            raise ValueError("viewmatrix / projmatrix must be 4x4 and campos must hold 3 values")
+        self.c = _CSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+                            self.bg.data_ptr(), float(rs.scale_modifier), self.vm.data_ptr(), self.pm.data_ptr(),
+                            int(rs.sh_degree), self.cam.data_ptr(), int(bool(rs.prefiltered)), int(bool(rs.debug)), 0)
+
+
+class _CtxHolder:
+    """Owns one GsrCtx; the workspace returns to the library's pool when the autograd graph dies."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def info(self, what: int) -> int:
+        out = ctypes.c_int64(0)
+        self.lib.gsr_ctx_info(self.handle, what, ctypes.byref(out))
+        return out.value
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                self.lib.gsr_ctx_free(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+def _empty_like_or_none(t):
+    return None if t is None else torch.empty_like(t)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        lib = _load()
+        if not means3D.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
+                               f"{means3D.device}); there is no CPU path")
+        device = means3D.device
+        P = int(means3D.shape[0])
+
+        def prep(t):
+            return None if t is None or t.numel() == 0 else _f32c(t.detach(), device)
+        m3, shc, shoc, colc = prep(means3D), prep(sh), prep(sh_objs), prep(colors_precomp)
+        opc, scc, roc, covc = prep(opacities), prep(scales), prep(rotations), prep(cov3Ds_precomp)
+        K = 0
+        if shc is not None:
+            if shc.dim() != 3 or shc.shape[2] != 3 or shc.shape[0] != P:
+                raise ValueError(f"shs must be [P,K,3], got {tuple(shc.shape)}")
+            K = int(shc.shape[1])
+        if shoc is not None and shoc.numel() != P * NUM_OBJECTS:
+            raise ValueError(f"sh_objs must hold P*{NUM_OBJECTS} values, got {tuple(shoc.shape)}")
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        pack = _SettingsPack(raster_settings, device)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+        objects = torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device)
+        radii = torch.empty(P, dtype=torch.int32, device=device)
+        handle = ctypes.c_void_p(None)
+        nren = ctypes.c_int64(0)
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            rc = lib.gsr_forward(ctypes.byref(pack.c), P, K, _ptr(m3), _ptr(shc), _ptr(shoc), _ptr(colc), _ptr(opc),
+                                 _ptr(scc), _ptr(roc), _ptr(covc), _ptr(color), _ptr(objects), _ptr(radii),
+                                 ctypes.byref(handle), ctypes.byref(nren), stream)
+        if rc != 0:
+            msg = _err(lib)
+            if raster_settings.debug:
+                torch.save({"means3D": m3, "sh": shc, "sh_objs": shoc, "colors_precomp": colc, "opacities": opc,
+                            "scales": scc, "rotations": roc, "cov3D_precomp": covc,
+                            "settings": raster_settings._asdict()}, "snapshot_fw.dump")
+                msg += " (inputs saved to snapshot_fw.dump)"
+            if rc == 1:
+                raise Exception(msg)
+            raise RuntimeError(msg)
+        ctx.holder = _CtxHolder(lib, handle)
+        ctx.pack = pack
+        ctx.num_rendered = nren.value
+        ctx.shapes = (means3D.shape, means2D.shape if means2D is not None else None,
+                      None if sh is None else sh.shape, None if sh_objs is None else sh_objs.shape,
+                      None if colors_precomp is None else colors_precomp.shape, opacities.shape,
+                      None if scales is None else scales.shape, None if rotations is None else rotations.shape,
+                      None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
+        # the library reads these again in backward: keep the exact (contiguous fp32) buffers alive
+        ctx.kept = (m3, shc, shoc, colc, opc, scc, roc, covc)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, objects
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_objects):
+        lib = ctx.holder.lib
+        m3, shc, shoc, colc, opc, scc, roc, covc = ctx.kept
+        device = m3.device
+        P = int(m3.shape[0])
+        H, W = ctx.pack.c.image_height, ctx.pack.c.image_width
+        if grad_color is None:
+            grad_color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
+        gcol = _f32c(grad_color, device)
+        gobj = None if (grad_objects is None or shoc is None) else _f32c(grad_objects, device)
+        need = ctx.needs_input_grad
+
+        def out(cond, *shape):
+            return torch.empty(*shape, dtype=torch.float32, device=device) if cond else None
+        d_m3 = out(need[0], P, 3)
+        d_m2 = out(need[1], P, 3)
+        d_sh = out(need[2] and shc is not None, *(shc.shape if shc is not None else (0,)))
+        d_obj = out(need[3] and shoc is not None, P, NUM_OBJECTS)
+        d_col = out(need[4] and colc is not None, P, 3)
+        d_op = out(need[5], P)
+        d_sc = out(need[6] and scc is not None, P, 3)
+        d_ro = out(need[7] and roc is not None, P, 4)
+        d_cov = out(need[8] and covc is not None, P, 6)
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            rc = lib.gsr_backward(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_m3), _ptr(d_m2), _ptr(d_sh),
+                                  _ptr(d_obj), _ptr(d_col), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), _ptr(d_cov), stream)
+        if rc != 0:
+            msg = _err(lib)
+            if ctx.pack.c.debug:
+                torch.save({"grad_color": gcol, "grad_objects": gobj}, "snapshot_bw.dump")
+                msg += " (gradients saved to snapshot_bw.dump)"
+            raise RuntimeError(msg)
+        if P == 0:
+            for t in (d_m3, d_m2, d_sh, d_obj, d_col, d_op, d_sc, d_ro, d_cov):
+                if t is not None:
+                    t.zero_()
+        s = ctx.shapes
+
+        def shaped(t, shape):
+            return None if t is None else t.reshape(shape)
+        return (shaped(d_m3, s[0]), shaped(d_m2, s[1]), shaped(d_sh, s[2]), shaped(d_obj, s[3]), shaped(d_col, s[4]),
+                shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test (view-space z > 0.2) -> bool[P]."""
+        lib = _load()
+        if not positions.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization: positions must live on a HIP device; there is no CPU path")
+        with torch.no_grad():
+            device = positions.device
+            pos = _f32c(positions, device)
+            pack = _SettingsPack(self.raster_settings, device)
+            present = torch.empty(pos.shape[0], dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                rc = lib.gsr_mark_visible(ctypes.byref(pack.c), int(pos.shape[0]), _ptr(pos), _ptr(present), stream)
+            if rc != 0:
+                raise RuntimeError(_err(lib))
+            return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, sh_objs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, sh_objs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
+
+
+# ---- introspection used by the benchmark / tests -----------------------------------------------------------
+def last_num_rendered(output: torch.Tensor) -> int:
+    """Number of (tile, Gaussian) pairs of the forward that produced `output` (its grad_fn's context)."""
+    fn = output.grad_fn
+    return int(getattr(fn, "num_rendered", -1)) if fn is not None else -1
+
+
+def profile(enable: bool) -> None:
+    _load().gsr_profile(1 if enable else 0)
+
+
+def profile_read() -> dict:
+    lib = _load()
+    ms = (ctypes.c_float * len(GSR_STAGES))()
+    calls = (ctypes.c_int64 * len(GSR_STAGES))()
+    if lib.gsr_profile_read(ms, calls) != 0:
+        raise RuntimeError(_err(lib))
+    return {n: (float(ms[i]), int(calls[i])) for i, n in enumerate(GSR_STAGES)}
+
+
+def pool_bytes() -> int:
+    out = ctypes.c_int64(0)
+    _load().gsr_query(1, ctypes.byref(out))
+    return out.value
+
+
+def trim_pool() -> None:
+    _load().gsr_trim_pool()
+
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "NUM_OBJECTS",
+           "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered"]

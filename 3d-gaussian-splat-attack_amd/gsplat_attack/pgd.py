@@ -1,0 +1,58 @@
+"""Projected-gradient steps on raw Gaussian attributes (the DAGGER update rules).
+
+Counterpart of the reference's ``attack.py:25-173``: one L-inf and one L2 rule, applied to position,
+rotation, opacity, scaling or SH colour.  Semantics kept exactly:
+  * steps are TARGETED (the perturbation is multiplied by -1: attack.py:28,63,127-128,159-160);
+  * L-inf: ``x += -alpha*sign(grad)`` then ``clamp(x - x0, -eps, eps) + x0``;
+  * L2: ``x += -alpha*grad/||grad||_2`` with the norm over the WHOLE tensor (zero step when the norm is
+    0), then ``(x - x0).renorm(p=2, dim=0, maxnorm=eps)`` -- i.e. each Gaussian's row is clipped to an
+    eps-ball on its own;
+  * colour steps treat ``_features_rest`` and ``_features_dc`` separately (attack.py:138-173);
+  * updates act in place on the raw (pre-activation) parameters and read ``.grad``.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def linf_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
+    with torch.no_grad():
+        x.add_(torch.sign(grad), alpha=-alpha)
+        x.sub_(x0).clamp_(-epsilon, epsilon).add_(x0)
+
+
+def l2_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
+    with torch.no_grad():
+        norm = torch.linalg.vector_norm(grad.reshape(-1), ord=2)
+        # branch-free form of "if norm > 0 ... else zero step" (no host sync on the device path)
+        step = torch.where(norm > 0, grad / norm.clamp_min(torch.finfo(grad.dtype).tiny), torch.zeros_like(grad))
+        x.add_(step, alpha=-alpha)
+        delta = (x - x0).renorm(p=2, dim=0, maxnorm=epsilon)
+        x.copy_(x0 + delta)
+
+
+def _single(attr):
+    def linf(gaussian, alpha, epsilon, original):
+        t = getattr(gaussian, attr)
+        linf_step_(t, t.grad, alpha, epsilon, original)
+
+    def l2(gaussian, alpha, epsilon, original):
+        t = getattr(gaussian, attr)
+        l2_step_(t, t.grad, alpha, epsilon, original)
+    return linf, l2
+
+
+gaussian_position_linf_attack, gaussian_position_l2_attack = _single("_xyz")
+gaussian_rotation_linf_attack, gaussian_rotation_l2_attack = _single("_rotation")
+gaussian_opacity_linf_attack, gaussian_opacity_l2_attack = _single("_opacity")
+gaussian_scaling_linf_attack, gaussian_scaling_l2_attack = _single("_scaling")
+
+
+def gaussian_color_linf_attack(gaussian, alpha, epsilon, features_rest, features_dc):
+    linf_step_(gaussian._features_rest, gaussian._features_rest.grad, alpha, epsilon, features_rest)
+    linf_step_(gaussian._features_dc, gaussian._features_dc.grad, alpha, epsilon, features_dc)
+
+
+def gaussian_color_l2_attack(gaussian, alpha, epsilon, features_rest, features_dc):
+    l2_step_(gaussian._features_rest, gaussian._features_rest.grad, alpha, epsilon, features_rest)
+    l2_step_(gaussian._features_dc, gaussian._features_dc.grad, alpha, epsilon, features_dc)

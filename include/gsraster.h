@@ -1,0 +1,149 @@
+/* gsraster.h -- C ABI of libgsraster.so, the MI355X (gfx950) differentiable 3D-Gaussian-splat rasteriser.
+ *
+ * This is the drop-in boundary for the one hot path of poloclub/3d-gaussian-splat-attack: what the
+ * reference reaches through `from diff_gaussian_rasterization import GaussianRasterizationSettings,
+ * GaussianRasterizer` (reference gaussian_renderer/__init__.py:14) and calls at
+ * gaussian_renderer/__init__.py:36-49 (settings), :51 (constructor) and :86-95 (forward); the backward
+ * is reached by `loss.backward()` at attack.py:494.  The third-party CUDA extension behind that import
+ * is not vendored in the reference; the entry points below are what a Python binding for it needs.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw DEVICE pointers (float32 / int32, contiguous) + sizes + a hipStream_t
+ *     passed as void*;
+ *   - every call enqueues on the given stream of the CURRENT hip device; the only host synchronisation is
+ *     inside gsr_forward (one 4-byte read of the number of tile/Gaussian pairs, to size the sort buffers);
+ *   - return value 0 = success, otherwise a GSR_ERR_* code and gsr_last_error() describes it
+ *     (thread-local string);
+ *   - the caller owns all inputs / outputs / gradient buffers and must keep the INPUT tensors of
+ *     gsr_forward alive and unmodified until gsr_backward / gsr_ctx_free for that context;
+ *     the library owns an internal caching workspace pool per device and the opaque GsrCtx.
+ *   - gradient outputs are fully written (zeros for culled Gaussians): no pre-zeroing needed.
+ */
+#ifndef GSRASTER_H_
+#define GSRASTER_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 100 /* 0.1.0 */
+#define GSR_NUM_OBJECTS 16 /* object-feature channels, reference scene/gaussian_model.py:52 */
+
+enum {
+  GSR_OK = 0,
+  GSR_ERR_INVALID = 1,  /* bad argument combination / sizes */
+  GSR_ERR_DEVICE = 2,   /* a HIP call failed (message names the stage) */
+  GSR_ERR_NOMEM = 3,
+  GSR_ERR_STATE = 4     /* e.g. backward called twice on a released context */
+};
+
+/* flags */
+#define GSR_FLAG_NONE 0u
+
+/* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
+ * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the
+ * kernels themselves (no host copy, no sync):
+ *   bg          >= 3 floats (the reference passes 4 for black, attack.py:396: only the first 3 are read)
+ *   viewmatrix  16 floats, row-major as stored by the reference, i.e. the TRANSPOSED world->view matrix:
+ *               p_view = [x y z 1] * viewmatrix          (reference scene/cameras.py:54)
+ *   projmatrix  16 floats, full projection in the same convention (reference scene/cameras.py:56)
+ *   campos      3 floats                                  (reference scene/cameras.py:57)            */
+typedef struct GsrSettings {
+  int32_t image_height;
+  int32_t image_width;
+  float tanfovx;
+  float tanfovy;
+  const float* bg;
+  float scale_modifier;
+  const float* viewmatrix;
+  const float* projmatrix;
+  int32_t sh_degree; /* active degree, 0..3 */
+  const float* campos;
+  int32_t prefiltered;
+  int32_t debug;
+  uint32_t flags; /* GSR_FLAG_* (extension; 0 reproduces the reference) */
+} GsrSettings;
+
+typedef struct GsrCtx GsrCtx; /* opaque: geometry / binning / per-pixel state of one forward */
+
+/* Forward: replaces GaussianRasterizer.forward (call site reference gaussian_renderer/__init__.py:86-95).
+ *   P              number of Gaussians
+ *   K              SH coefficients stored per Gaussian and channel in `shs` (16 for max degree 3)
+ *   means3D        [P,3]
+ *   shs            [P,K,3] coefficient-major then channel (reference scene/gaussian_model.py:113-116), or NULL
+ *   sh_objs        [P,16] object features (reference scene/gaussian_model.py:118-120), or NULL (objects = 0)
+ *   colors_precomp [P,3] or NULL            (exactly one of shs / colors_precomp)
+ *   opacities      [P]   (already sigmoid-activated)
+ *   scales         [P,3] (already exp-activated), rotations [P,4] (w,x,y,z, used as given), or both NULL
+ *   cov3D_precomp  [P,6] xx,xy,xz,yy,yz,zz or NULL     (exactly one of (scales,rotations) / cov3D_precomp)
+ *   out_color      [3,H,W]  (background blended in, not clamped)
+ *   out_objects    [16,H,W] or NULL
+ *   radii          [P] int32, 0 for culled Gaussians
+ *   ctx_out        receives the context for gsr_backward (pass NULL for a forward-only call: nothing is kept)
+ *   num_rendered   receives the number of (tile, Gaussian) pairs, may be NULL                               */
+int gsr_forward(const GsrSettings* settings, int32_t P, int32_t K, const float* means3D, const float* shs,
+                const float* sh_objs, const float* colors_precomp, const float* opacities, const float* scales,
+                const float* rotations, const float* cov3D_precomp, float* out_color, float* out_objects,
+                int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream);
+
+/* Backward: what loss.backward() (reference attack.py:494) reaches through the extension's autograd function.
+ *   grad_color   [3,H,W]; grad_objects [16,H,W] or NULL (treated as zero)
+ *   outputs (any may be NULL = not wanted):
+ *   dmeans3D [P,3], dmeans2D [P,3] (gradient w.r.t. the screen-space means in NDC units, z = 0; this is what
+ *   lands in viewspace_points.grad, reference gaussian_renderer/__init__.py:26-30), dshs [P,K,3],
+ *   dsh_objs [P,16], dcolors_precomp [P,3], dopacities [P], dscales [P,3], drotations [P,4], dcov3D [P,6].
+ * May be called more than once on a context (retain_graph).                                                  */
+int gsr_backward(GsrCtx* ctx, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
+                 float* dshs, float* dsh_objs, float* dcolors_precomp, float* dopacities, float* dscales,
+                 float* drotations, float* dcov3D, void* stream);
+
+/* Releases the context's workspace back to the pool (stream-ordered: safe right after enqueueing backward). */
+void gsr_ctx_free(GsrCtx* ctx);
+
+/* Frustum test only (view-space z > 0.2): present[P] = 1/0.  Replaces GaussianRasterizer.markVisible. */
+int gsr_mark_visible(const GsrSettings* settings, int32_t P, const float* means3D, uint8_t* present, void* stream);
+
+/* Introspection. what: 0 version, 1 bytes held by the workspace pool on the current device,
+ * 2 number of pairs of a context (ctx as int64 handle in *out on input is NOT used; see gsr_ctx_info). */
+int gsr_query(int32_t what, int64_t* out);
+
+/* Per-context numbers for roofline accounting: what 0 = num_rendered (N), 1 = visible Gaussians (V; -1 if not
+ * counted), 2 = workspace bytes of this context. */
+int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
+
+/* Frees every cached workspace block of the current device (blocks in use by live contexts are kept). */
+void gsr_trim_pool(void);
+
+/* Per-stage timing of the calls made by THIS thread since the last reset, measured with hip events on the
+ * stream the kernels were launched on.  Enable with gsr_profile(1): every stage is then bracketed by event
+ * records (adds a few microseconds per stage); gsr_profile_read synchronises and fills
+ * ms[GSR_STAGE_COUNT] with accumulated milliseconds and calls[GSR_STAGE_COUNT] with launch counts. */
+enum {
+  GSR_STAGE_PREPROCESS = 0,
+  GSR_STAGE_DEPTH_SORT = 1,
+  GSR_STAGE_BIN = 2,       /* pack + scan + emit */
+  GSR_STAGE_TILE_SORT = 3, /* + tile ranges */
+  GSR_STAGE_RENDER_FWD = 4,
+  GSR_STAGE_RENDER_BWD = 5,
+  GSR_STAGE_PREPROCESS_BWD = 6,
+  GSR_STAGE_COUNT = 7
+};
+void gsr_profile(int32_t enable);
+int gsr_profile_read(float* ms, int64_t* calls);
+
+const char* gsr_last_error(void);
+
+/* Test hooks (used by tests/ only): the scan and sort primitives of the binning stage on caller buffers.
+ * gsr_test_scan: out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total), uint32.
+ * gsr_test_sort_pairs: stable ascending sort of (keys, vals) on key bits [begin_bit, end_bit), in place;
+ *                      iota != 0: vals are ignored on input and the result is the sorting permutation. */
+int gsr_test_scan(const uint32_t* in, uint32_t* out, uint32_t n, void* stream);
+int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begin_bit, int32_t end_bit, int32_t iota,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRASTER_H_ */
