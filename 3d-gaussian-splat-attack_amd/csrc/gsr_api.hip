@@ -142,28 +142,35 @@ uint32_t* pinned_word(int dev) {
   return g_pinned[dev];
 }
 
-// ---- per-stage profiling ----------------------------------------------------------------------
+// ---- per-stage profiling (process-wide: autograd runs backward on its own thread) ------------------
 struct ProfSpan { int stage; hipEvent_t a, b; };
-thread_local bool t_prof = false;
-thread_local std::vector<ProfSpan> t_spans;
-thread_local std::vector<hipEvent_t> t_free_events;
-thread_local float t_ms[GSR_STAGE_COUNT] = {0};
-thread_local int64_t t_calls[GSR_STAGE_COUNT] = {0};
+std::mutex g_prof_mu;
+bool g_prof = false;
+std::vector<ProfSpan> g_spans;
+std::vector<hipEvent_t> g_free_events;
+float g_ms[GSR_STAGE_COUNT] = {0};
+int64_t g_calls[GSR_STAGE_COUNT] = {0};
 
-hipEvent_t get_event() {
-  if (!t_free_events.empty()) { hipEvent_t e = t_free_events.back(); t_free_events.pop_back(); return e; }
+hipEvent_t get_event_locked() {
+  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
   hipEvent_t e;
   (void)hipEventCreate(&e);
   return e;
 }
 
 struct StageTimer {
-  int stage; hipStream_t st; hipEvent_t a{}, b{}; bool on;
-  StageTimer(int s, hipStream_t stream) : stage(s), st(stream), on(t_prof) {
-    if (on) { a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
+  int stage; hipStream_t st; hipEvent_t a{}, b{}; bool on = false;
+  StageTimer(int s, hipStream_t stream) : stage(s), st(stream) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    on = g_prof;
+    if (on) { a = get_event_locked(); b = get_event_locked(); (void)hipEventRecord(a, st); }
   }
   ~StageTimer() {
-    if (on) { (void)hipEventRecord(b, st); t_spans.push_back(ProfSpan{stage, a, b}); }
+    if (on) {
+      (void)hipEventRecord(b, st);
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      g_spans.push_back(ProfSpan{stage, a, b});
+    }
   }
 };
 
@@ -222,16 +229,19 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
                 const float* rotations, const float* cov3D_precomp, float* out_color, float* out_objects,
                 int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream) {
   if (ctx_out) *ctx_out = nullptr;
-  if (!s || !out_color || !radii || !means3D || !opacities)
-    return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / means3D / opacities / out_color / radii");
-  if ((shs == nullptr) == (colors_precomp == nullptr))
-    return set_err(GSR_ERR_INVALID, "gsr_forward: provide exactly one of shs / colors_precomp");
-  const bool has_sr = scales != nullptr && rotations != nullptr;
-  if (((scales != nullptr) != (rotations != nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
-    return set_err(GSR_ERR_INVALID, "gsr_forward: provide exactly one of (scales, rotations) / cov3D_precomp");
+  if (!s || !out_color) return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / out_color");
   if (P < 0 || s->image_height <= 0 || s->image_width <= 0)
     return set_err(GSR_ERR_INVALID, "gsr_forward: bad sizes P=%d H=%d W=%d", P, s->image_height, s->image_width);
-  if (shs && (s->sh_degree < 0 || s->sh_degree > 3 || K < (s->sh_degree + 1) * (s->sh_degree + 1)))
+  if (P > 0) {   // an empty scene carries no data pointers: it renders the background
+    if (!radii || !means3D || !opacities)
+      return set_err(GSR_ERR_INVALID, "gsr_forward: null means3D / opacities / radii");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+      return set_err(GSR_ERR_INVALID, "gsr_forward: provide exactly one of shs / colors_precomp");
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if (((scales != nullptr) != (rotations != nullptr)) || (has_sr == (cov3D_precomp != nullptr)))
+      return set_err(GSR_ERR_INVALID, "gsr_forward: provide exactly one of (scales, rotations) / cov3D_precomp");
+  }
+  if (P > 0 && shs && (s->sh_degree < 0 || s->sh_degree > 3 || K < (s->sh_degree + 1) * (s->sh_degree + 1)))
     return set_err(GSR_ERR_INVALID, "gsr_forward: sh_degree %d needs K >= %d, got K=%d (degree must be 0..3)",
                    s->sh_degree, (s->sh_degree + 1) * (s->sh_degree + 1), K);
   if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
@@ -536,24 +546,26 @@ int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begi
 }
 
 void gsr_profile(int32_t enable) {
-  t_prof = enable != 0;
-  for (ProfSpan& s : t_spans) { t_free_events.push_back(s.a); t_free_events.push_back(s.b); }
-  t_spans.clear();
-  for (int i = 0; i < GSR_STAGE_COUNT; ++i) { t_ms[i] = 0.f; t_calls[i] = 0; }
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof = enable != 0;
+  for (ProfSpan& s : g_spans) { g_free_events.push_back(s.a); g_free_events.push_back(s.b); }
+  g_spans.clear();
+  for (int i = 0; i < GSR_STAGE_COUNT; ++i) { g_ms[i] = 0.f; g_calls[i] = 0; }
 }
 
 int gsr_profile_read(float* ms, int64_t* calls) {
-  for (ProfSpan& s : t_spans) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (ProfSpan& s : g_spans) {
     hipError_t e = hipEventSynchronize(s.b);
     if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_profile_read: %s", hipGetErrorString(e));
     float m = 0.f;
-    if (hipEventElapsedTime(&m, s.a, s.b) == hipSuccess) { t_ms[s.stage] += m; t_calls[s.stage] += 1; }
-    t_free_events.push_back(s.a); t_free_events.push_back(s.b);
+    if (hipEventElapsedTime(&m, s.a, s.b) == hipSuccess) { g_ms[s.stage] += m; g_calls[s.stage] += 1; }
+    g_free_events.push_back(s.a); g_free_events.push_back(s.b);
   }
-  t_spans.clear();
+  g_spans.clear();
   for (int i = 0; i < GSR_STAGE_COUNT; ++i) {
-    if (ms) ms[i] = t_ms[i];
-    if (calls) calls[i] = t_calls[i];
+    if (ms) ms[i] = g_ms[i];
+    if (calls) calls[i] = g_calls[i];
   }
   return GSR_OK;
 }

@@ -1,0 +1,62 @@
+"""View-sharded data parallelism for the PGD loop: one process per GPU, one view per rank, gradients of the
+(replicated) Gaussian attributes summed across ranks.
+
+The reference is single-process: its "batch" is a Python loop over cameras whose gradients add up in .grad at
+``loss.backward()`` (reference attack.py:476-494).  Here rank r renders views r, r+G, ... of the batch and the
+per-step attribute gradients are all-reduced (RCCL over xGMI through torch.distributed's "nccl" backend; gloo
+on CPU for tests) -- the only exchange the path has.  Every rank then applies the identical PGD step, so the
+replicas stay bit-identical (an all-reduce returns the same bits on every rank).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+# raw parameters whose gradients the attack consumes (59 floats per Gaussian at SH degree 3)
+ATTACK_PARAMS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def init_from_env(backend: Optional[str] = None):
+    """-> (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* set by torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def views_of_rank(n_views: int, rank: int, world: int) -> List[int]:
+    """Indices of the batch's views this rank renders (round-robin, like one view per GPU at n_views == world)."""
+    return list(range(rank, n_views, world))
+
+
+def allreduce_attribute_grads(model, names: Iterable[str] = ATTACK_PARAMS, group=None) -> int:
+    """Sum the per-step gradients over ranks, in place.  Returns the number of bytes reduced.
+    A parameter that got no gradient on this rank (e.g. no view assigned) contributes zeros."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    works, nbytes = [], 0
+    for n in names:
+        p = getattr(model, n)
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        g = p.grad
+        if not g.is_contiguous():
+            g = p.grad = g.contiguous()
+        works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        nbytes += g.numel() * g.element_size()
+    for w in works:
+        w.wait()
+    return nbytes

@@ -19,10 +19,14 @@ from .sh import eval_sh
 class PipelineParams:
     """The three switches render() reads (reference attack.py:254-256, configs/config.yaml:61-63)."""
 
-    def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False):
+    def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False,
+                 skip_objects: bool = False):
         self.convert_SHs_python = convert_SHs_python
         self.compute_cov3D_python = compute_cov3D_python
         self.debug = debug
+        # extension (default off = reference behaviour): do not composite the 16 object-feature channels,
+        # which the attack never reads (``render_object`` is then all zeros)
+        self.skip_objects = skip_objects
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
@@ -64,7 +68,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # The reference leaves `sh_objs` unbound on the two Python-colour branches;
     # here the object features are always passed, which is what its only working branch does.
     shs = colors_precomp = None
-    sh_objs = pc.get_objects
+    sh_objs = None if getattr(pipe, "skip_objects", False) else pc.get_objects
     if override_color is None:
         if pipe.convert_SHs_python:
             shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)

@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd views/sec @1080p, 1M Gaussians (BASELINE.json metric) on N MI355X GPUs of one node.
+
+One "step" = one view: ``render()`` forward of the S-nyc-1M synthetic scene (1,000,000 Gaussians, SH degree 3,
+1920x1080) through the drop-in ``diff_gaussian_rasterization`` package (libgsraster.so,
+hand-written HIP) + one backward from a fixed dL/dC[3,H,W] down to .grad on all seven raw attribute tensors
+(59 attack-relevant floats per Gaussian), object channels off.  With N > 1 every rank renders its own view of
+the ring (weak scaling) and the attribute gradients are sum-all-reduced over RCCL each step, inside the timed
+region.  Inputs are resident in HBM before the timed region starts.
+
+    python bench.py                       # N=1, defaults finish in ~2 minutes incl. the CPU baseline
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel stage against the 8 TB/s HBM peak with the
+algorithmic bytes of SURVEY.md section 8(d) and its live HIP-event duration over the timed region;
+`cpu_baseline` times oracle-R (pure PyTorch, CPU) on a bounded sample of the same scene.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "3d-gaussian-splat-attack_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def stage_bytes(P: int, V: int, N: int, HW: int) -> dict:
+    """Algorithmic bytes per launch of each stage (SURVEY.md section 8d derivation; objects off)."""
+    return {
+        "preprocess": 48 * P + 240 * V,          # K1: 44P in + 192V SH in, 48V geometry + 4P radii out
+        "depth_sort": 0,                         # (the reference's single 64-bit pair sort is priced under tile_sort)
+        "bin": 8 * P + 12 * N,                   # K2 scan + K3 emit
+        "tile_sort": 24 * N,                     # K4 counted as ONE read + one write of the pairs (lower bound)
+        "render_fwd": 40 * N + 20 * HW,          # K6
+        "render_bwd": 20 * HW + 40 * N + 36 * V,  # K7
+        "preprocess_bwd": 272 * V + 248 * P,     # K8+K9
+    }
+
+
+def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
+    """oracle-R (the checker, a CPU port -- never the product path) timed on the host cores of this node."""
+    from gsplat_attack.scenes import make_scene
+    from oracle import oracle_r as O
+    import math
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # a 1-GPU box shares its host: 16 worker threads is this pool's CPU share
+    torch.set_num_threads(cores)
+    model, cams, _ = make_scene("nyc-1M", device="cpu", P=sample_P, width=sample_W, height=sample_H, n_views=1)
+    cam = cams[0]
+    st = O.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                    torch.zeros(3), 1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center,
+                    False, False)
+    inp = dict(means3D=model.get_xyz.detach(), shs=model.get_features.detach(), opacities=model.get_opacity.detach(),
+               scales=model.get_scaling.detach(), rotations=model.get_rotation.detach())
+    gc = torch.randn(3, sample_H, sample_W, generator=torch.Generator().manual_seed(99))
+    t0 = time.perf_counter()
+    out, _ = O.forward_backward(inp, st, gc, dtype=torch.float32)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+            "seconds": dt,
+            "sample": f"oracle-R float32 fwd+bwd, ONE view of S-nyc-1M subsampled to {sample_P} Gaussians at "
+                      f"{sample_W}x{sample_H} (N={out.num_rendered} pairs); not extrapolated to 1M/1080p"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="nyc-1M")
+    ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (parity-size runs)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--objects", action="store_true", help="composite the 16 object channels too")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="100000,1920,1080")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the raster path has no CPU fallback")
+    from gsplat_attack import dist as gdist
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.scenes import make_scene
+    import diff_gaussian_rasterization as D
+
+    rank, world, local = gdist.init_from_env("nccl")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    D._load()
+
+    n_views = max(8, world)
+    if rank == 0:
+        log(f"building scene {args.scene} on {dev}")
+    model, cams, spec = make_scene(args.scene, device=dev, P=args.P, width=args.width, height=args.height,
+                                   n_views=n_views)
+    cam = cams[rank % n_views]
+    H, W = cam.image_height, cam.image_width
+    P = model.get_xyz.shape[0]
+    pipe = PipelineParams(skip_objects=not args.objects)
+    bg = torch.zeros(3, device=dev)
+    gc = torch.randn(3, H, W, generator=torch.Generator().manual_seed(99)).to(dev)
+
+    info = {}
+
+    def step():
+        model.zero_grad()
+        out = render(cam, model, pipe, bg)
+        out["render"].backward(gc)
+        if world > 1:
+            gdist.allreduce_attribute_grads(model)
+        return out
+
+    if rank == 0:
+        log(f"scene ready: P={P}, {W}x{H}; warmup x{args.warmup}")
+    for i in range(args.warmup):
+        out = step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"warmup step {i} done, N={D.last_num_rendered(out['render'])}")
+    info["N"] = D.last_num_rendered(out["render"])
+    info["V"] = int((out["radii"] > 0).sum().item())
+    del out
+
+    D.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
+    stages = D.profile_read()
+    D.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        N, V, HW = info["N"], info["V"], H * W
+        sb = stage_bytes(P, V, N, HW)
+        per = {}
+        for name, (ms, calls) in stages.items():
+            launches = args.steps
+            avg_ms = ms / max(launches, 1)
+            per[name] = {"avg_ms": round(avg_ms, 4),
+                         "GBps": round(sb[name] / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and sb[name] else None}
+        dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd", "tile_sort", "bin"),
+                  key=lambda n: per[n]["avg_ms"])
+        dom_ms = per[dom]["avg_ms"]
+        achieved = sb[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        B_total = 304 * P + 548 * V + 116 * N + 40 * HW
+        t_view = elapsed / args.steps
+        result = {
+            "metric": "fwd+bwd views/sec @1080p, 1M Gaussians",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "views/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(t_view * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{spec.name}: {P} Gaussians (SH degree 3), {W}x{H}, one view per step per GPU, "
+                                   "render() fwd + bwd to all attribute grads"
+                                   + (", 16 object channels on" if args.objects else ", object channels off"),
+                       "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
+                       "parallelism": f"views sharded 1/GPU, dp{world}"
+                                      + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
+                         "note": "K6/K7 are fp32-VALU/exp bound (256*N alpha evaluations), not HBM bound; "
+                                 "HBM is the reporting roofline BASELINE.md section 3 prescribes"},
+            "pipeline": {"bytes_per_view": B_total, "achieved": round(B_total / t_view / 1e9, 1), "unit": "GB/s",
+                         "frac": round(B_total / t_view / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages": per,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sp, sw, sh = (int(x) for x in args.cpu_sample.split(","))
+            log(f"cpu baseline (oracle-R) on a {sp}-Gaussian {sw}x{sh} sample ...")
+            result["cpu_baseline"] = cpu_baseline(sp, sw, sh)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

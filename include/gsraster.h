@@ -116,7 +116,7 @@ int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
 /* Frees every cached workspace block of the current device (blocks in use by live contexts are kept). */
 void gsr_trim_pool(void);
 
-/* Per-stage timing of the calls made by THIS thread since the last reset, measured with hip events on the
+/* Per-stage timing of all calls of this process since the last reset, measured with hip events on the
  * stream the kernels were launched on.  Enable with gsr_profile(1): every stage is then bracketed by event
  * records (adds a few microseconds per stage); gsr_profile_read synchronises and fills
  * ms[GSR_STAGE_COUNT] with accumulated milliseconds and calls[GSR_STAGE_COUNT] with launch counts. */

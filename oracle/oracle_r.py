@@ -312,7 +312,7 @@ def rasterize(means3D, means2D, opacities, st: Settings, shs=None, sh_objs=None,
     gx = (W + TILE - 1) // TILE
     gy = (H + TILE - 1) // TILE
     # relative half-width of the "a float32 implementation may legitimately flip this test" band
-    tol = frag_tol if frag_tol is not None else 1e-4
+    tol = frag_tol if frag_tol is not None else 2e-5
 
     color_rows, obj_rows, T_rows, n_rows, f_rows = [], [], [], [], []
     yy, xx = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")

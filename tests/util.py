@@ -23,8 +23,9 @@ def model_inputs(model, with_objs=True):
     return d
 
 
-def grad_error(g, ref):
-    """(normwise max error / max|ref|,  elementwise max relative error over elements that are not tiny)."""
+def grad_error(g, ref, elem_tol=5e-3):
+    """(normwise max error / max|ref|,  fraction of significant elements whose relative error exceeds
+    elem_tol).  Significant = within 3 decades of the group's largest magnitude."""
     g = g.detach().double().cpu().reshape(-1)
     ref = ref.detach().double().cpu().reshape(-1)
     scale = ref.abs().max().item()
@@ -32,6 +33,6 @@ def grad_error(g, ref):
         return g.abs().max().item(), 0.0
     err = (g - ref).abs()
     norm = (err.max() / scale).item()
-    big = ref.abs() > 1e-3 * scale           # elements within 3 decades of the largest
-    elem = (err[big] / ref.abs()[big]).max().item() if big.any() else 0.0
-    return norm, elem
+    big = ref.abs() > 1e-3 * scale
+    frac = ((err[big] / ref.abs()[big]) > elem_tol).double().mean().item() if big.any() else 0.0
+    return norm, frac
