@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -192,8 +193,9 @@ struct GsrCtx {
   void* keep_blk = nullptr;
   void* rank_blk = nullptr;
   size_t keep_bytes = 0;
-  float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;
-  uint32_t *order = nullptr, *off = nullptr, *pair_rank = nullptr;
+  float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;   // splat records in depth order
+  float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // the same in storage order
+  uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
   float* final_T = nullptr;
   uint32_t* n_contrib = nullptr;
@@ -265,16 +267,16 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
   const size_t Pp = (size_t)std::max(P, 1);
   // ---- kept slab ---------------------------------------------------------------------------
   SlabPlan kp;
-  kp.add<float4>(Pp); kp.add<float4>(Pp); kp.add<float4>(Pp);   // R0..R2
-  kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1);                // order, off
+  kp.add<float4>(Pp); kp.add<float4>(Pp); kp.add<float4>(Pp);   // R0..R2 (depth order)
+  kp.add<float4>(Pp); kp.add<float4>(Pp); kp.add<float4>(Pp);   // G0..G2 (storage order)
+  kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
   const uint32_t tblP = radix_table_words((uint32_t)Pp);
   SlabPlan sp;
-  sp.add<float4>(Pp); sp.add<float4>(Pp); sp.add<float4>(Pp);   // G0..G2
-  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey a/b, order b
+  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey a/b, order b, tcnt
   sp.add<uint32_t>(tblP); sp.add<uint32_t>(tblP / SCAN_CHUNK + 2);
   sp.add<uint32_t>(Pp / SCAN_CHUNK + 2);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
@@ -285,11 +287,13 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
   }
   Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
   c->R0 = ks.take<float4>(Pp); c->R1 = ks.take<float4>(Pp); c->R2 = ks.take<float4>(Pp);
-  c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1);
+  c->G0 = ks.take<float4>(Pp); c->G1 = ks.take<float4>(Pp); c->G2 = ks.take<float4>(Pp);
+  c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
-  float4* G0 = ss.take<float4>(Pp); float4* G1 = ss.take<float4>(Pp); float4* G2 = ss.take<float4>(Pp);
+  float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
+  uint32_t* tcnt = ss.take<uint32_t>(Pp);
   uint32_t* table = ss.take<uint32_t>(tblP); uint32_t* tsums = ss.take<uint32_t>(tblP / SCAN_CHUNK + 2);
   uint32_t* psums = ss.take<uint32_t>(Pp / SCAN_CHUNK + 2);
 
@@ -319,7 +323,9 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
       hipLaunchKernelGGL(k_preprocess, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
-                         opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA);
+                         opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
+      // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
+      scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st);
       F_LAUNCH("preprocess");
     }
     uint32_t* skey;
@@ -346,6 +352,7 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
     }
   } else {
     F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
+    F_TRY("init", hipMemsetAsync(c->offg, 0, sizeof(uint32_t), st));
   }
   c->N = N;
   F_TRY("ranges", hipMemsetAsync(c->ranges, 0, sizeof(uint2) * ntiles, st));
@@ -363,15 +370,17 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
     uint32_t* tsumsN = tableN + tblN;
     {
       StageTimer t(GSR_STAGE_BIN, st);
-      hipLaunchKernelGGL(k_emit, dim3((N + EMIT_SLOTS - 1) / EMIT_SLOTS), blk, 0, st, c->off, (uint32_t)P, N, c->R2, gridx,
-                         tileA, rankA);
+      const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
+      hipLaunchKernelGGL(k_emit, dim3((N + EMIT_SLOTS - 1) / EMIT_SLOTS), blk, 0, st, c->off, (uint32_t)P, N, c->R0, c->R1,
+                         c->R2, gridx, W, H, (uint32_t)ntiles, cull, tileA, rankA);
       F_LAUNCH("emit");
     }
     int res;
     {
       StageTimer t(GSR_STAGE_TILE_SORT, st);
-      res = radix_sort_pairs(tileA, rankA, tileB, rankB, N, 0, ceil_log2((uint32_t)ntiles), false, tableN, tsumsN, st);
-      hipLaunchKernelGGL(k_ranges, dim3((N + 255) / 256), blk, 0, st, N, res ? tileB : tileA, c->ranges);
+      // keys are 0..ntiles (ntiles = culled pair): one more value than there are tiles
+      res = radix_sort_pairs(tileA, rankA, tileB, rankB, N, 0, ceil_log2((uint32_t)ntiles + 1), false, tableN, tsumsN, st);
+      hipLaunchKernelGGL(k_ranges, dim3((N + 255) / 256), blk, 0, st, N, (uint32_t)ntiles, res ? tileB : tileA, c->ranges);
       F_LAUNCH("tile sort");
     }
     c->pair_rank = res ? rankB : rankA;
@@ -386,12 +395,18 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
-    const dim3 gridT((ntiles + 3) / 4);
+    const dim3 blkT(64);
+    static const int fwd_npx = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+    const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
     if (out_objects && sh_objs) {
-      hipLaunchKernelGGL(k_render_fwd<true>, gridT, blk, 0, st, ra);
+      if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
+      else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<true, 2>), gridT, blkT, 0, st, ra);
+      else hipLaunchKernelGGL((k_render_fwd<true, 1>), gridT, blkT, 0, st, ra);
     } else {
       if (out_objects) F_TRY("objects", hipMemsetAsync(out_objects, 0, sizeof(float) * NUM_OBJ * HW, st));
-      hipLaunchKernelGGL(k_render_fwd<false>, gridT, blk, 0, st, ra);
+      if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<false, 4>), gridT, blkT, 0, st, ra);
+      else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<false, 2>), gridT, blkT, 0, st, ra);
+      else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
     }
     F_LAUNCH("render forward");
   }
@@ -436,11 +451,11 @@ int gsr_backward(GsrCtx* c, const float* grad_color, const float* grad_objects, 
         (obj && hipMemsetAsync(part_obj, 0, sizeof(float4) * 4 * (size_t)N, st) != hipSuccess))
       return done(set_err(GSR_ERR_DEVICE, "render backward: memset failed: %s", hipGetErrorString(hipGetLastError())));
     RenderBwdArgs ra;
-    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.off = c->off; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
+    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = c->sh_objs; ra.bg = c->st.bg; ra.W = c->st.image_width; ra.H = c->st.image_height;
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
-    const dim3 gridT((c->ntiles + 3) / 4), blk(256);
+    const dim3 gridT(render_grid(c->ntiles)), blk(64);
     if (obj) hipLaunchKernelGGL(k_render_bwd<true>, gridT, blk, 0, st, ra);
     else hipLaunchKernelGGL(k_render_bwd<false>, gridT, blk, 0, st, ra);
     hipError_t e = hipGetLastError();
@@ -450,14 +465,17 @@ int gsr_backward(GsrCtx* c, const float* grad_color, const float* grad_objects, 
     StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
     PreBwdArgs pa;
     pa.P = P; pa.K = c->K; pa.va = view_args(c->st);
-    pa.order = c->order; pa.off = c->off; pa.R0 = c->R0; pa.R1 = c->R1; pa.R2 = c->R2;
+    pa.offg = c->offg; pa.G0 = c->G0; pa.G1 = c->G1; pa.G2 = c->G2;
     pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
     pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
     pa.dmeans3D = dmeans3D; pa.dmeans2D = dmeans2D; pa.dsh = c->shs ? dshs : nullptr; pa.dsh_objs = dsh_objs;
     pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    // SH rows of 16 coefficients x 3 channels (the only layout the reference uses) go through LDS
+    const bool sh_lds = c->shs != nullptr && pa.dsh != nullptr && c->K == 16;
+    if (sh_lds) hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    else hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, st, pa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
   }
@@ -495,6 +513,30 @@ int gsr_ctx_info(const GsrCtx* c, int32_t what, int64_t* out) {
     case 2: *out = (int64_t)(c->keep_bytes + sizeof(uint32_t) * (size_t)c->N); return GSR_OK;
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_info: unknown item %d", what);
   }
+}
+
+int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, void* stream) {
+  if (!c || !dst) return set_err(GSR_ERR_INVALID, "gsr_ctx_export: null argument");
+  const size_t HW = (size_t)c->st.image_height * c->st.image_width;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  switch (what) {
+    case 0: src = c->ranges; bytes = sizeof(uint2) * (size_t)c->ntiles; break;
+    case 1: src = c->pair_rank; bytes = sizeof(uint32_t) * (size_t)c->N; break;
+    case 2: src = c->n_contrib; bytes = sizeof(uint32_t) * HW; break;
+    case 3: src = c->final_T; bytes = sizeof(float) * HW; break;
+    case 4: src = c->order; bytes = sizeof(uint32_t) * (size_t)c->P; break;
+    case 5: src = c->off; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
+    case 6: src = c->R0; bytes = sizeof(float4) * (size_t)c->P; break;
+    case 7: src = c->R1; bytes = sizeof(float4) * (size_t)c->P; break;
+    case 8: src = c->R2; bytes = sizeof(float4) * (size_t)c->P; break;
+    default: return set_err(GSR_ERR_INVALID, "gsr_ctx_export: unknown item %d", what);
+  }
+  if ((int64_t)bytes > dst_bytes)
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_export: item %d needs %zu bytes, buffer has %lld", what, bytes, (long long)dst_bytes);
+  if (bytes == 0) return GSR_OK;
+  HIP_TRY("ctx export", hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return GSR_OK;
 }
 
 void gsr_trim_pool(void) {

@@ -8,7 +8,8 @@
 //   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF when culled
 //   order[r]      Gaussian index of depth rank r (stable radix argsort of dkey)
 //   R0,R1,R2[r]   the same records gathered into depth order; R2.y = bits(g)
-//   off[r]        exclusive scan of tiles touched, off[P] = N
+//   off[r]        exclusive scan of tiles touched in depth order, off[P] = N (numbers the emitted pairs)
+//   offg[g]       the same scan in storage order (numbers the backward's partial rows)
 //   pair_tile/pair_rank[N]  (tile id, rank) pairs, emitted rank-major, then stably sorted by tile id
 //   ranges[t]     [start,end) of tile t in the sorted pair list
 //   final_T, n_contrib [H*W]  per-pixel transmittance / last contributing list position (1-based)
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
                                                     const float* __restrict__ sh, const float* __restrict__ colors,
                                                     int32_t* __restrict__ radii, float4* __restrict__ G0,
                                                     float4* __restrict__ G1, float4* __restrict__ G2,
-                                                    uint32_t* __restrict__ dkey) {
+                                                    uint32_t* __restrict__ dkey, uint32_t* __restrict__ tcnt) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P) return;
   View v;
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   if (!ok) {
     radii[g] = 0;
     dkey[g] = 0xFFFFFFFFu;
+    tcnt[g] = 0;
     G2[g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
     return;
   }
@@ -79,6 +81,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   }
   radii[g] = s.radius;
   dkey[g] = __float_as_uint(s.depth);
+  tcnt[g] = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
   const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
   const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
   G0[g] = make_float4(s.px, s.py, s.A, s.B);
@@ -135,9 +138,15 @@ __device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo,
   return lo;
 }
 
+// A (tile, Gaussian) pair of the reference's 3-sigma tile rect is kept only if some pixel of the tile can pass
+// the reference's own alpha test (alpha >= 1/255); pairs that cannot are given the key `ntiles`, sort to the
+// tail and are never composited.  The rendered image, radii and gradients are unchanged by construction
+// (tile_can_contribute is conservative); only the work shrinks.  `cull` = 0 keeps every pair.
 __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, uint32_t P, uint32_t N,
-                                              const float4* __restrict__ R2, int gridx,
-                                              uint32_t* __restrict__ pair_tile, uint32_t* __restrict__ pair_rank) {
+                                              const float4* __restrict__ R0, const float4* __restrict__ R1,
+                                              const float4* __restrict__ R2, int gridx, int W, int H,
+                                              uint32_t ntiles, int cull, uint32_t* __restrict__ pair_tile,
+                                              uint32_t* __restrict__ pair_rank) {
   __shared__ uint32_t s_off[EMIT_SLOTS + 1];
   __shared__ uint32_t s_r[2];
   const uint32_t e0 = blockIdx.x * EMIT_SLOTS;
@@ -163,25 +172,38 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
     const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
     const uint32_t local = e - o;
     const uint32_t dy = local / wx, dx = local - dy * wx;
-    pair_tile[e] = (miny + dy) * (uint32_t)gridx + minx + dx;
+    const uint32_t tx = minx + dx, ty = miny + dy;
+    uint32_t key = ty * (uint32_t)gridx + tx;
+    if (cull) {
+      const float4 a = R0[r], b = R1[r];
+      const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+      const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1)), y1 = fminf(y0 + (float)(TILE - 1), (float)(H - 1));
+      if (!tile_can_contribute(a.x, a.y, a.z, a.w, b.x, b.y, x0, y0, x1, y1)) key = ntiles;
+    }
+    pair_tile[e] = key;
     pair_rank[e] = r;
   }
 }
 
-// K5
-__global__ void __launch_bounds__(256) k_ranges(uint32_t N, const uint32_t* __restrict__ tiles,
+// K5 (keys >= ntiles are culled pairs at the tail of the sorted list)
+__global__ void __launch_bounds__(256) k_ranges(uint32_t N, uint32_t ntiles, const uint32_t* __restrict__ tiles,
                                                 uint2* __restrict__ ranges) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const uint32_t t = tiles[i];
+  if (t >= ntiles) return;
   if (i == 0 || tiles[i - 1] != t) ranges[t].x = i;
   if (i == N - 1 || tiles[i + 1] != t) ranges[t].y = i + 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: forward composite.  One WAVE per 16x16 tile, 4 pixels per lane (rows y0+{0,4,8,12}+lane/16):
-// an entry staged once in LDS is broadcast to 256 pixels, no block barrier anywhere (each wave owns
-// its LDS slice), early-out by wave ballot.
+// K6 / K7 common: one WAVE (= one 64-thread workgroup) per 16x16 tile, 4 pixels per lane
+// (rows y0 + {0,4,8,12} + lane/16).  A list entry is staged once in LDS and broadcast to 256 pixels;
+// there is no block barrier anywhere; each 16x4 strip is entered only if a conservative wave-ballot test
+// says some pixel of it can pass the reference's alpha test, and the strip body itself is branch-free
+// (selects), so the exec mask is never juggled.  Blocks b and b+8 land on the same XCD (observed
+// round-robin dispatch): each XCD gets one contiguous band of tiles so neighbouring tiles share their
+// splat records in that XCD's L2.
 // ------------------------------------------------------------------------------------------------
 struct RenderArgs {
   const uint2* ranges;
@@ -199,49 +221,76 @@ struct RenderArgs {
 };
 
 constexpr int PXL = 4;   // pixels per lane
+constexpr float LOG2E = 1.4426950408889634f;
 
-template <bool OBJ>
-__global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
-  __shared__ float4 s0[4][64];
-  __shared__ float4 s1[4][64];
-  __shared__ float s2[4][64];
-  __shared__ float so[OBJ ? 4 : 1][OBJ ? 64 : 1][NUM_OBJ];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= a.ntiles) return;
+__device__ __forceinline__ int tile_of_block(int ntiles) {
+  const int tpx = (ntiles + 7) >> 3;
+  return (int)(blockIdx.x & 7u) * tpx + (int)(blockIdx.x >> 3);
+}
+inline int render_grid(int ntiles) { return 8 * ((ntiles + 7) >> 3); }
+
+// Staged form of a splat: the conic is pre-scaled so that p2 = log2(e) * power comes out of two FMAs,
+// and thr2 is a slightly LOWERED bound on the p2 at which alpha reaches 1/255 (prefilter only: the exact
+// alpha test of the reference is applied inside the strip body).
+struct StagedSplat { float4 a; float4 b; float2 c; };
+__device__ __forceinline__ StagedSplat stage_splat(const float4 r0, const float4 r1, const float bch) {
+  StagedSplat s;
+  s.a = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
+  s.b = make_float4(-0.5f * LOG2E * r1.x, r1.y, r1.z, r1.w);
+  const float t = -__log2f(255.0f * r1.y);             // +inf for opacity 0: never a candidate
+  s.c = make_float2(bch, t - 1e-4f * (fabsf(t) + 1.0f));
+  return s;
+}
+
+// NPX = pixels per lane: 4 -> one wave per tile, 2 -> two waves (16x8 halves), 1 -> four waves (16x4 strips).
+// Fewer pixels per wave = shorter dependent chain per list entry and more, smaller work items for the
+// dispatcher to balance (a tile's list length sets its wave's run time); more = staging amortised further.
+template <bool OBJ, int NPX>
+__global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
+  constexpr int NSUB = PXL / NPX;
+  __shared__ float4 s0[64];
+  __shared__ float4 s1[64];
+  __shared__ float2 s2[64];
+  __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
+  const int lane = threadIdx.x;
+  const int item = tile_of_block(a.ntiles * NSUB);
+  if (item >= a.ntiles * NSUB) return;
+  const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)x;
-  int y[PXL];
-  float pyf[PXL], T[PXL], C[PXL][3];
-  float O[OBJ ? PXL : 1][NUM_OBJ];
-  uint32_t last[PXL];
-  bool done[PXL];
+  int y[NPX];
+  float pyf[NPX], T[NPX], Tfin[NPX], C[NPX][3];
+  float O[OBJ ? NPX : 1][NUM_OBJ];
+  uint32_t last[NPX];
+  bool alive[NPX];
+  bool any_alive = false;
 #pragma unroll
-  for (int k = 0; k < PXL; ++k) {
-    y[k] = ty * TILE + (lane >> 4) + 4 * k;
+  for (int k = 0; k < NPX; ++k) {
+    y[k] = ty * TILE + sub * (4 * NPX) + (lane >> 4) + 4 * k;
     pyf[k] = (float)y[k];
-    T[k] = 1.f; C[k][0] = C[k][1] = C[k][2] = 0.f;
+    T[k] = (x < a.W && y[k] < a.H) ? 1.f : 0.f;   // T == 0 <=> this pixel is finished
+    Tfin[k] = 0.f;
+    C[k][0] = C[k][1] = C[k][2] = 0.f;
     last[k] = 0;
-    done[k] = !(x < a.W && y[k] < a.H);
+    alive[k] = __ballot(T[k] > 0.f) != 0ull;
+    any_alive = any_alive || alive[k];
     if (OBJ) {
 #pragma unroll
       for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = 0.f;
     }
   }
-  for (uint32_t base = rg.x; base < rg.y; base += 64) {
-    if (!__any(!(done[0] && done[1] && done[2] && done[3]))) break;
+  for (uint32_t base = rg.x; base < rg.y && any_alive; base += 64) {
     const uint32_t i = base + lane;
     if (i < rg.y) {
       const uint32_t r = a.pair_rank[i];
       const float4 c = a.R2[r];
-      s0[wave][lane] = a.R0[r];
-      s1[wave][lane] = a.R1[r];
-      s2[wave][lane] = c.x;
+      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x);
+      s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
-        float4* dst = reinterpret_cast<float4*>(&so[wave][lane][0]);
+        float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
     }
@@ -249,50 +298,61 @@ __global__ void __launch_bounds__(256) k_render_fwd(RenderArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int cnt = min(64u, rg.y - base);
-    for (int j = 0; j < cnt; ++j) {
-      const float4 e0 = s0[wave][j];
-      const float4 e1 = s1[wave][j];
-      const float eb = s2[wave][j];
+    float4 n0 = s0[0], n1 = s1[0];
+    float2 n2 = s2[0];
+    for (int j = 0; j < cnt && any_alive; ++j) {
+      const float4 e0 = n0, e1 = n1;
+      const float2 e2 = n2;
+      const int jn = min(j + 1, 63);          // prefetch the next entry while this one is composited
+      n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
       const uint32_t pos = base - rg.x + j + 1;
       const float dx = e0.x - pxf;
-      bool live = false;
+      const float qa = e0.z * dx * dx, bdx = e0.w * dx;
 #pragma unroll
-      for (int k = 0; k < PXL; ++k) {
-        if (!done[k]) {
+      for (int k = 0; k < NPX; ++k) {
+        if (alive[k]) {
           const float dy = e0.y - pyf[k];
-          float alpha, G;
-          if (splat_alpha(dx, dy, e0.z, e0.w, e1.x, e1.y, alpha, G)) {
+          const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
+          const bool cand = (p2 <= 0.f) && (p2 >= e2.y) && (T[k] > 0.f);
+          if (__ballot(cand) != 0ull) {
+            const float G = __builtin_amdgcn_exp2f(p2);
+            const float alpha = fminf(ALPHA_CAP, e1.y * G);
+            const bool valid = cand && (alpha >= ALPHA_MIN);
             const float Tn = T[k] * (1.f - alpha);
-            if (Tn < T_STOP) {
-              done[k] = true;
-            } else {
-              const float w = alpha * T[k];
-              C[k][0] += e1.z * w; C[k][1] += e1.w * w; C[k][2] += eb * w;
-              if (OBJ) {
+            const bool stop = valid && (Tn < T_STOP);
+            const bool contrib = valid && !(Tn < T_STOP);
+            const float w = contrib ? alpha * T[k] : 0.f;
+            C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
+            if (OBJ) {
 #pragma unroll
-                for (int c = 0; c < NUM_OBJ; ++c) O[k][c] += so[wave][j][c] * w;
-              }
-              T[k] = Tn;
-              last[k] = pos;
+              for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[j][c], w, O[k][c]);
+            }
+            Tfin[k] = stop ? T[k] : Tfin[k];
+            T[k] = contrib ? Tn : (stop ? 0.f : T[k]);
+            last[k] = contrib ? pos : last[k];
+            if (__ballot(stop) != 0ull) {
+              alive[k] = __ballot(T[k] > 0.f) != 0ull;
+              any_alive = false;
+#pragma unroll
+              for (int m = 0; m < NPX; ++m) any_alive = any_alive || alive[m];
             }
           }
-          live = live || !done[k];
         }
       }
-      if (!__any(live)) break;
     }
     __builtin_amdgcn_wave_barrier();
   }
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
 #pragma unroll
-  for (int k = 0; k < PXL; ++k) {
+  for (int k = 0; k < NPX; ++k) {
     if (x < a.W && y[k] < a.H) {
       const size_t pix = (size_t)y[k] * a.W + x;
-      a.out_color[pix] = C[k][0] + T[k] * bg0;
-      a.out_color[HW + pix] = C[k][1] + T[k] * bg1;
-      a.out_color[2 * HW + pix] = C[k][2] + T[k] * bg2;
-      a.final_T[pix] = T[k];
+      const float Tf = T[k] + Tfin[k];   // one of the two is zero
+      a.out_color[pix] = C[k][0] + Tf * bg0;
+      a.out_color[HW + pix] = C[k][1] + Tf * bg1;
+      a.out_color[2 * HW + pix] = C[k][2] + Tf * bg2;
+      a.final_T[pix] = Tf;
       a.n_contrib[pix] = last[k];
       if (OBJ) {
 #pragma unroll
@@ -333,7 +393,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 struct RenderBwdArgs {
   const uint2* ranges;
   const uint32_t* pair_rank;
-  const uint32_t* off;
+  const uint32_t* offg;   // [P+1] exclusive scan of tiles touched in STORAGE order: numbers the partial rows
   const float4* R0;
   const float4* R1;
   const float4* R2;
@@ -351,14 +411,14 @@ struct RenderBwdArgs {
 constexpr int PART_F4 = 3;
 
 template <bool OBJ>
-__global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
-  __shared__ float4 s0[4][64];
-  __shared__ float4 s1[4][64];
-  __shared__ float s2[4][64];
-  __shared__ uint32_t sslot[4][64];
-  __shared__ float so[OBJ ? 4 : 1][OBJ ? 64 : 1][NUM_OBJ];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
+__global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
+  __shared__ float4 s0[64];
+  __shared__ float4 s1[64];
+  __shared__ float2 s2[64];
+  __shared__ uint32_t sslot[64];
+  __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
+  const int lane = threadIdx.x;
+  const int tile = tile_of_block(a.ntiles);
   if (tile >= a.ntiles) return;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
@@ -368,7 +428,7 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
   const size_t HW = (size_t)a.H * a.W;
   float pyf[PXL], T[PXL], Acc[PXL], la[PXL], lcg[PXL], g0[PXL], g1[PXL], g2[PXL], bgd[PXL];
   float gO[OBJ ? PXL : 1][NUM_OBJ];
-  uint32_t ncon[PXL];
+  uint32_t ncon[PXL], smax[PXL];
   uint32_t maxc = 0;
 #pragma unroll
   for (int k = 0; k < PXL; ++k) {
@@ -393,25 +453,23 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
         for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = 0.f;
       }
     }
-    maxc = max(maxc, ncon[k]);
+    smax[k] = __builtin_amdgcn_readfirstlane(wave_max_u32(ncon[k]));   // last list position this strip uses
+    maxc = max(maxc, smax[k]);
   }
-  maxc = wave_max_u32(maxc);
-  maxc = __builtin_amdgcn_readfirstlane(maxc);
   for (int hi = (int)maxc; hi > 0; hi -= 64) {
     const int lo = max(hi - 64, 0);
     const int cnt = hi - lo;
     if (lane < cnt) {
       const uint32_t r = a.pair_rank[rg.x + lo + lane];
       const float4 c = a.R2[r];
-      s0[wave][lane] = a.R0[r];
-      s1[wave][lane] = a.R1[r];
-      s2[wave][lane] = c.x;
+      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x);
+      s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
-      sslot[wave][lane] = a.off[r] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx);
+      sslot[lane] = a.offg[__float_as_uint(c.y)] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx);
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
-        float4* dst = reinterpret_cast<float4*>(&so[wave][lane][0]);
+        float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
     }
@@ -419,12 +477,13 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int j = cnt - 1; j >= 0; --j) {
-      const float4 e0 = s0[wave][j];
-      const float4 e1 = s1[wave][j];
-      const float eb = s2[wave][j];
+      const float4 e0 = s0[j];
+      const float4 e1 = s1[j];
+      const float2 e2 = s2[j];
       const uint32_t pos = (uint32_t)(lo + j + 1);
       const float dx = e0.x - pxf;
-      float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+      const float qa = e0.z * dx * dx, bdx = e0.w * dx;
+      float sq = 0.f, sqy = 0.f, sqyy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
       float dobj[OBJ ? NUM_OBJ : 1];
       if (OBJ) {
 #pragma unroll
@@ -433,45 +492,55 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
       bool hit = false;
 #pragma unroll
       for (int k = 0; k < PXL; ++k) {
-        if (pos <= ncon[k]) {
+        if (pos <= smax[k]) {
           const float dy = e0.y - pyf[k];
-          float alpha, G;
-          if (splat_alpha(dx, dy, e0.z, e0.w, e1.x, e1.y, alpha, G)) {
+          const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
+          const bool cand = (p2 <= 0.f) && (p2 >= e2.y) && (pos <= ncon[k]);
+          if (__ballot(cand) != 0ull) {
             hit = true;
-            const float inv1m = 1.0f / (1.f - alpha);
-            T[k] *= inv1m;
-            const float w = alpha * T[k];
-            float cg = e1.z * g0[k] + e1.w * g1[k] + eb * g2[k];
+            const float G = __builtin_amdgcn_exp2f(p2);
+            const float oG = e1.y * G;
+            const float alpha = fminf(ALPHA_CAP, oG);
+            const bool valid = cand && (alpha >= ALPHA_MIN);
+            const float inv1m = __builtin_amdgcn_rcpf(1.f - alpha);
+            T[k] = valid ? T[k] * inv1m : T[k];
+            const float w = valid ? alpha * T[k] : 0.f;
+            float cg = fmaf(e1.z, g0[k], fmaf(e1.w, g1[k], e2.x * g2[k]));
             if (OBJ) {
 #pragma unroll
               for (int c = 0; c < NUM_OBJ; ++c) {
-                const float f = so[wave][j][c];
-                cg += f * gO[k][c];
-                dobj[c] += w * gO[k][c];
+                cg = fmaf(so[j][c], gO[k][c], cg);
+                dobj[c] = fmaf(w, gO[k][c], dobj[c]);
               }
             }
-            Acc[k] = la[k] * lcg[k] + (1.f - la[k]) * Acc[k];
-            lcg[k] = cg;
-            la[k] = alpha;
-            const float dLda = T[k] * (cg - Acc[k]) - bgd[k] * inv1m;
-            dr += w * g0[k]; dg += w * g1[k]; db += w * g2[k];
-            dop += G * dLda;
-            const float q = e1.y * G * dLda;
-            const float qx = q * dx, qy = q * dy;
-            mx += qx; my += qy; mxx += qx * dx; mxy += qx * dy; myy += qy * dy;
+            const float An = fmaf(la[k], lcg[k] - Acc[k], Acc[k]);   // la*lcg + (1-la)*Acc
+            Acc[k] = valid ? An : Acc[k];
+            lcg[k] = valid ? cg : lcg[k];
+            la[k] = valid ? alpha : la[k];
+            const float dLda = valid ? fmaf(T[k], cg - Acc[k], -bgd[k] * inv1m) : 0.f;
+            dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
+            dop = fmaf(G, dLda, dop);
+            const float q = oG * dLda;
+            const float qy = q * dy;
+            sq += q; sqy += qy; sqyy = fmaf(qy, dy, sqyy);
           }
         }
       }
-      if (__any(hit)) {
-        mx = wave_sum_to_hi(mx); my = wave_sum_to_hi(my); mxx = wave_sum_to_hi(mxx);
-        mxy = wave_sum_to_hi(mxy); myy = wave_sum_to_hi(myy); dop = wave_sum_to_hi(dop);
+      if (hit) {
+        float mx = sq * dx;
+        float mxx = wave_sum_to_hi(mx * dx);
+        float mxy = wave_sum_to_hi(sqy * dx);
+        mx = wave_sum_to_hi(mx);
+        const float my = wave_sum_to_hi(sqy);
+        const float myy = wave_sum_to_hi(sqyy);
+        dop = wave_sum_to_hi(dop);
         dr = wave_sum_to_hi(dr); dg = wave_sum_to_hi(dg); db = wave_sum_to_hi(db);
         if (OBJ) {
 #pragma unroll
           for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = wave_sum_to_hi(dobj[c]);
         }
         if (lane == 63) {
-          const uint32_t slot = sslot[wave][j];
+          const uint32_t slot = sslot[j];
           float4* row = a.part + (size_t)slot * PART_F4;
           row[0] = make_float4(mx, my, mxx, mxy);
           row[1] = make_float4(myy, dop, dr, dg);
@@ -491,16 +560,19 @@ __global__ void __launch_bounds__(256) k_render_bwd(RenderBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8+K9 fused with the per-Gaussian reduction of the partial rows: one thread per depth rank.
+// K8+K9 fused with the per-Gaussian reduction of the partial rows: one thread per Gaussian, in STORAGE
+// order, so every attribute read and every gradient write of a wave is one contiguous span; the rows of a
+// Gaussian's (tile, Gaussian) pairs are contiguous too (slots are numbered in storage order).  The 192-byte
+// SH rows go through LDS (coalesced float4 copies in and out, rows padded to 13 float4 => conflict-free
+// ds_read_b128) instead of 64 lanes each walking their own row.
 // ------------------------------------------------------------------------------------------------
 struct PreBwdArgs {
   int P, K;
   ViewArgs va;
-  const uint32_t* order;
-  const uint32_t* off;
-  const float4* R0;
-  const float4* R1;
-  const float4* R2;
+  const uint32_t* offg;   // [P+1] exclusive scan of tiles touched, storage order
+  const float4* G0;
+  const float4* G1;
+  const float4* G2;
   const float4* part;
   const float4* part_obj;
   const float* means;
@@ -519,89 +591,124 @@ struct PreBwdArgs {
   float* dcov3d;
 };
 
+constexpr int SHROW_F4 = 13;   // 12 float4 of payload (K = 16) + 1 pad
+
+template <bool SH_LDS>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= a.P) return;
-  const uint32_t g = a.order[r];
-  const uint32_t o0 = a.off[r], o1 = a.off[r + 1];
+  __shared__ float4 srow[SH_LDS ? 4 * 64 * SHROW_F4 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw0 = blockIdx.x * 256 + wave * 64;          // first Gaussian of this wave
+  const int g = gw0 + lane;
   const int K = a.K;
-  if (o1 == o0) {   // culled: zero gradients
-    if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
-    if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
-    if (a.dsh) for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] = 0.f;
-    if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
-    if (a.dcolors) { a.dcolors[3 * g] = 0.f; a.dcolors[3 * g + 1] = 0.f; a.dcolors[3 * g + 2] = 0.f; }
-    if (a.dopac) a.dopac[g] = 0.f;
-    if (a.dscales) { a.dscales[3 * g] = 0.f; a.dscales[3 * g + 1] = 0.f; a.dscales[3 * g + 2] = 0.f; }
-    if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
-    if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
-    return;
+  float4* wrow = SH_LDS ? &srow[wave * 64 * SHROW_F4] : nullptr;
+  const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
+  if (SH_LDS && nw > 0) {
+    const float4* src = reinterpret_cast<const float4*>(a.sh) + (size_t)gw0 * 12;
+    for (int i = lane; i < nw * 12; i += 64) {
+      const int row = i / 12;
+      wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
+    }
   }
-  float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-  for (uint32_t e = o0; e < o1; ++e) {
-    const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
-    mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
-  }
-  if (a.dsh_objs) {
-    float acc[NUM_OBJ];
-#pragma unroll
-    for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
-    if (a.part_obj) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (g < a.P) {
+    const uint32_t o0 = a.offg[g], o1 = a.offg[g + 1];
+    float* my_sh = SH_LDS ? reinterpret_cast<float*>(&wrow[lane * SHROW_F4]) : nullptr;
+    if (o1 == o0) {   // culled: zero gradients
+      if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
+      if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
+      if (a.dsh) {
+        if (SH_LDS) { for (int i = 0; i < 12; ++i) wrow[lane * SHROW_F4 + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        else for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] = 0.f;
+      }
+      if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
+      if (a.dcolors) { a.dcolors[3 * g] = 0.f; a.dcolors[3 * g + 1] = 0.f; a.dcolors[3 * g + 2] = 0.f; }
+      if (a.dopac) a.dopac[g] = 0.f;
+      if (a.dscales) { a.dscales[3 * g] = 0.f; a.dscales[3 * g + 1] = 0.f; a.dscales[3 * g + 2] = 0.f; }
+      if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
+      if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
+    } else {
+      float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
       for (uint32_t e = o0; e < o1; ++e) {
+        const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+        mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+      }
+      if (a.dsh_objs) {
+        float acc[NUM_OBJ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = a.part_obj[(size_t)e * 4 + q];
-          acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+        for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
+        if (a.part_obj) {
+          for (uint32_t e = o0; e < o1; ++e) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 v = a.part_obj[(size_t)e * 4 + q];
+              acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
+      }
+      View v;
+      load_view(v, a.va);
+      const float4 e0 = a.G0[g], e1 = a.G1[g], e2 = a.G2[g];
+      const float A = e0.z, B = e0.w, C = e1.x;
+      // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
+      const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
+      const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
+      const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
+      if (a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
+      if (a.dopac) a.dopac[g] = dop;
+      const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+      float dp[3] = {0.f, 0.f, 0.f};
+      if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
+      if (a.sh) {
+        const uint32_t cl = __float_as_uint(e2.z) >> 24;
+        const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
+        if (SH_LDS) {
+          // in place on the staged row: sh_to_rgb_bwd reads coefficient k before it writes gradient k
+          sh_to_rgb_bwd(v.sh_degree, 16, my_sh, p, v.cam, drgb, my_sh, dp);
+        } else if (a.dsh) {
+          sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
+        } else {
+          float scratch[48];
+          sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
         }
       }
-    }
+      float c6[6];
+      float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.cov3d) {
 #pragma unroll
-    for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
-  }
-  View v;
-  load_view(v, a.va);
-  const float4 e0 = a.R0[r], e1 = a.R1[r], e2 = a.R2[r];
-  const float A = e0.z, B = e0.w, C = e1.x;
-  // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
-  const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
-  const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
-  const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
-  if (a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
-  if (a.dopac) a.dopac[g] = dop;
-  const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
-  float dp[3] = {0.f, 0.f, 0.f};
-  if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
-  if (a.sh) {
-    const uint32_t cl = __float_as_uint(e2.z) >> 24;
-    const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
-    if (a.dsh) {
-      sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
-    } else {
-      float scratch[48];
-      sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
+        for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
+      } else {
+        s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
+        const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+        q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        cov3d_from_scale_rot(s, a.va.mod, q, c6);
+      }
+      float dc6[6];
+      project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+      if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
+      if (a.cov3d) {
+        if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
+      } else if (a.dscales || a.drots) {
+        float ds[3], dq[4];
+        cov3d_bwd(s, a.va.mod, q, dc6, ds, dq);
+        if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
+        if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+      }
     }
   }
-  float c6[6];
-  float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.cov3d) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
-  } else {
-    s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
-    const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
-    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
-    cov3d_from_scale_rot(s, a.va.mod, q, c6);
-  }
-  float dc6[6];
-  project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
-  if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
-  if (a.cov3d) {
-    if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
-  } else if (a.dscales || a.drots) {
-    float ds[3], dq[4];
-    cov3d_bwd(s, a.va.mod, q, dc6, ds, dq);
-    if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
-    if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+  if (SH_LDS && a.dsh && nw > 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4* dst = reinterpret_cast<float4*>(a.dsh) + (size_t)gw0 * 12;
+    for (int i = lane; i < nw * 12; i += 64) {
+      const int row = i / 12;
+      dst[i] = wrow[row * SHROW_F4 + (i - row * 12)];
+    }
   }
 }
 

@@ -255,9 +255,9 @@ GSR_HD void sh_to_rgb_bwd(int deg, int Kstore, const float* sh, const float p[3]
   sh_basis_grad(deg, x, y, z, gx, gy, gz);
   const int n = sh_count(deg);
   float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-  for (int k = 0; k < n; ++k) {
-    dsh[3 * k] = b[k] * drgb[0]; dsh[3 * k + 1] = b[k] * drgb[1]; dsh[3 * k + 2] = b[k] * drgb[2];
+  for (int k = 0; k < n; ++k) {   // coefficient k is read before gradient k is written: dsh may alias sh
     const float s = sh[3 * k] * drgb[0] + sh[3 * k + 1] * drgb[1] + sh[3 * k + 2] * drgb[2];
+    dsh[3 * k] = b[k] * drgb[0]; dsh[3 * k + 1] = b[k] * drgb[1]; dsh[3 * k + 2] = b[k] * drgb[2];
     ddx += gx[k] * s; ddy += gy[k] * s; ddz += gz[k] * s;
   }
   for (int k = n; k < Kstore; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
@@ -350,6 +350,36 @@ GSR_HD void cov3d_bwd(const float s_in[3], float mod, const float q[4], const fl
   dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
   dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
   dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-footprint test for one (tile, Gaussian) pair.  A pixel contributes only if
+// alpha = o*exp(-Q/2) >= 1/255 with Q = A dx^2 + 2 B dx dy + C dy^2, i.e. Q <= tau = 2 ln(255 o).
+// Returns false only when NO pixel centre of the rectangle [x0,x1]x[y0,y1] can satisfy that: the minimum
+// of the convex Q over the continuous rectangle (0 if the centre is inside, else attained on one of the
+// four edges) is compared with tau widened by a margin far above float32 rounding of the per-pixel test.
+// ---------------------------------------------------------------------------------------------
+GSR_HD float gsr_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+GSR_HD bool tile_can_contribute(float cx, float cy, float A, float B, float C, float o, float x0, float y0, float x1,
+                                float y1) {
+  if (!(A > 0.f) || !(C > 0.f)) return true;          // not a proper conic: leave the pair alone
+  const float tau = 2.0f * logf(255.0f * o);          // -inf / NaN for o <= 0
+  const float bound = tau + 1e-4f * fabsf(tau) + 1e-3f;
+  if (!(bound >= 0.f)) return false;                  // opacity below 1/255: alpha never reaches the floor
+  const float dxl = x0 - cx, dxh = x1 - cx, dyl = y0 - cy, dyh = y1 - cy;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
+  float qmin = 3.0e38f;
+  const float ex[2] = {dxl, dxh}, ey[2] = {dyl, dyh};
+  for (int i = 0; i < 2; ++i) {
+    const float dx = ex[i];
+    const float dy = gsr_clampf(-B * dx / C, dyl, dyh);
+    qmin = fminf(qmin, A * dx * dx + 2.f * B * dx * dy + C * dy * dy);
+    const float dy2 = ey[i];
+    const float dx2 = gsr_clampf(-B * dy2 / A, dxl, dxh);
+    qmin = fminf(qmin, A * dx2 * dx2 + 2.f * B * dx2 * dy2 + C * dy2 * dy2);
+  }
+  return qmin <= bound;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,6 +23,15 @@ NUM_OBJECTS = 16
 _LIB_NAME = "libgsraster.so"
 _lib = None
 
+FLAG_NO_CULL = 1          # GSR_FLAG_NO_CULL (include/gsraster.h)
+_FLAGS = 0
+
+
+def set_flags(flags: int) -> None:
+    """Extension flags passed in GsrSettings.flags by every later call (0 = default behaviour)."""
+    global _FLAGS
+    _FLAGS = int(flags)
+
 GSR_STAGES = ("preprocess", "depth_sort", "bin", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
@@ -75,6 +84,8 @@ def _load():
     lib.gsr_query.argtypes = [i32, i64p]
     lib.gsr_ctx_info.restype = ctypes.c_int
     lib.gsr_ctx_info.argtypes = [vp, i32, i64p]
+    lib.gsr_ctx_export.restype = ctypes.c_int
+    lib.gsr_ctx_export.argtypes = [vp, i32, vp, ctypes.c_int64, vp]
     lib.gsr_trim_pool.restype = None
     lib.gsr_trim_pool.argtypes = []
     lib.gsr_profile.restype = None
@@ -139,7 +150,8 @@ class _SettingsPack:
             raise ValueError("viewmatrix / projmatrix must be 4x4 and campos must hold 3 values")
         self.c = _CSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                             self.bg.data_ptr(), float(rs.scale_modifier), self.vm.data_ptr(), self.pm.data_ptr(),
-                            int(rs.sh_degree), self.cam.data_ptr(), int(bool(rs.prefiltered)), int(bool(rs.debug)), 0)
+                            int(rs.sh_degree), self.cam.data_ptr(), int(bool(rs.prefiltered)), int(bool(rs.debug)),
+                            _FLAGS)
 
 
 class _CtxHolder:
@@ -316,6 +328,28 @@ def last_num_rendered(output: torch.Tensor) -> int:
     return int(getattr(fn, "num_rendered", -1)) if fn is not None else -1
 
 
+_EXPORTS = {"ranges": (0, torch.int32), "pair_rank": (1, torch.int32), "n_contrib": (2, torch.int32),
+            "final_T": (3, torch.float32), "order": (4, torch.int32), "off": (5, torch.int32),
+            "R0": (6, torch.float32), "R1": (7, torch.float32), "R2": (8, torch.float32)}
+
+
+def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
+    """Copy one internal array of the forward that produced `output` (tests / diagnostics only)."""
+    fn = output.grad_fn
+    holder = fn.holder
+    what, dt = _EXPORTS[name]
+    P = int(fn.kept[0].shape[0])
+    H, W = fn.pack.c.image_height, fn.pack.c.image_width
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    n = {"ranges": 2 * T, "pair_rank": holder.info(0), "n_contrib": H * W, "final_T": H * W, "order": P,
+         "off": P + 1, "R0": 4 * P, "R1": 4 * P, "R2": 4 * P}[name]
+    dst = torch.empty(max(n, 1), dtype=dt, device=output.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(output.device).cuda_stream)
+    if holder.lib.gsr_ctx_export(holder.handle, what, dst.data_ptr(), dst.numel() * 4, stream) != 0:
+        raise RuntimeError(_err(holder.lib))
+    return dst[:n]
+
+
 def profile(enable: bool) -> None:
     _load().gsr_profile(1 if enable else 0)
 
@@ -340,4 +374,4 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "NUM_OBJECTS",
-           "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered"]
+           "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--objects", action="store_true", help="composite the 16 object channels too")
+    ap.add_argument("--no-cull", action="store_true", help="keep the full 3-sigma tile rects (A/B of the footprint cull)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
     args = ap.parse_args()
@@ -106,6 +107,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     D._load()
+    if args.no_cull:
+        D.set_flags(D.FLAG_NO_CULL)
 
     n_views = max(8, world)
     if rank == 0:

@@ -41,6 +41,10 @@ enum {
 
 /* flags */
 #define GSR_FLAG_NONE 0u
+/* Keep every (tile, Gaussian) pair of the 3-sigma tile rect.  By default pairs whose Gaussian cannot reach
+ * alpha >= 1/255 on any pixel of the tile are dropped before the sort: outputs are identical, only
+ * num_rendered-internal work shrinks.  The flag exists for A/B tests of exactly that claim. */
+#define GSR_FLAG_NO_CULL 1u
 
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the
@@ -112,6 +116,12 @@ int gsr_query(int32_t what, int64_t* out);
 /* Per-context numbers for roofline accounting: what 0 = num_rendered (N), 1 = visible Gaussians (V; -1 if not
  * counted), 2 = workspace bytes of this context. */
 int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
+
+/* Copies one internal array of a context into a caller DEVICE buffer (tests / diagnostics):
+ * what 0 = tile ranges [T][2] u32, 1 = sorted pair list (depth ranks) [N] u32, 2 = n_contrib [H*W] u32,
+ * 3 = final_T [H*W] f32, 4 = order (rank -> Gaussian) [P] u32, 5 = off [P+1] u32,
+ * 6/7/8 = depth-ordered splat records R0/R1/R2 [P] float4 (layout: csrc/gsr_kernels.hip.h). */
+int gsr_ctx_export(const GsrCtx* ctx, int32_t what, void* dst, int64_t dst_bytes, void* stream);
 
 /* Frees every cached workspace block of the current device (blocks in use by live contexts are kept). */
 void gsr_trim_pool(void);
