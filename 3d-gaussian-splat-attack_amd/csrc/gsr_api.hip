@@ -322,8 +322,12 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
   if (P > 0) {
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
-      hipLaunchKernelGGL(k_preprocess, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
-                         opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
+      if (shs && K == 16)
+        hipLaunchKernelGGL(k_preprocess<true>, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
+                           opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
+      else
+        hipLaunchKernelGGL(k_preprocess<false>, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
+                           opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
       scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st);
       F_LAUNCH("preprocess");

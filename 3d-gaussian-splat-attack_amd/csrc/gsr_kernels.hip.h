@@ -39,8 +39,14 @@ __device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
 constexpr uint32_t RECT_MASK = 0xFFFu;
 
 // ------------------------------------------------------------------------------------------------
-// K1: per-Gaussian preprocess
+// K1: per-Gaussian preprocess, one thread per Gaussian in storage order.  With the reference's SH layout
+// (16 coefficients x 3 channels = 192 B per Gaussian) each wave first copies its 64 rows into LDS with
+// coalesced float4 loads (rows padded to 13 float4: conflict-free ds_read_b128), then every lane reads its
+// own row from LDS instead of 64 lanes striding through HBM 192 bytes apart.
 // ------------------------------------------------------------------------------------------------
+constexpr int SHROW_F4 = 13;   // 12 float4 of payload (K = 16) + 1 pad
+
+template <bool SH_LDS>
 __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, const float* __restrict__ means,
                                                     const float* __restrict__ scales, const float* __restrict__ rots,
                                                     const float* __restrict__ cov3d, const float* __restrict__ opac,
@@ -48,7 +54,24 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
                                                     int32_t* __restrict__ radii, float4* __restrict__ G0,
                                                     float4* __restrict__ G1, float4* __restrict__ G2,
                                                     uint32_t* __restrict__ dkey, uint32_t* __restrict__ tcnt) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float4 srow[SH_LDS ? 4 * 64 * SHROW_F4 : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw0 = blockIdx.x * 256 + wave * 64;
+  const int g = gw0 + lane;
+  if (SH_LDS) {
+    const int nw = min(64, P - gw0);
+    if (nw > 0) {
+      float4* wrow = &srow[wave * 64 * SHROW_F4];
+      const float4* src = reinterpret_cast<const float4*>(sh) + (size_t)gw0 * 12;
+      for (int i = lane; i < nw * 12; i += 64) {
+        const int row = i / 12;
+        wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   if (g >= P) return;
   View v;
   load_view(v, va);
@@ -76,6 +99,8 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   uint32_t cl = 0;
   if (colors) {
     rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2];
+  } else if (SH_LDS) {
+    cl = sh_to_rgb(va.deg, reinterpret_cast<const float*>(&srow[(wave * 64 + lane) * SHROW_F4]), p, v.cam, rgb);
   } else {
     cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
   }
@@ -378,6 +403,28 @@ __device__ __forceinline__ float wave_sum_to_hi(float v) {
   v += dpp_mov<0x143, 0xC>(v);   // row_bcast31 into rows 2,3
   return v;
 }
+// Packed reduction steps (gfx950 lane-swap instructions).  v_permlane32_swap exchanges the upper half of one
+// register with the lower half of another, v_permlane16_swap the odd 16-lane rows of one with the even rows
+// of the other; adding the two registers afterwards leaves value a (summed over the partner lanes) in one
+// half / the even rows and value b in the other: two live values leave each step in ONE register.
+// (The clang builtin returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the
+// VALU-write -> permlane-read wait states, which hipcc does not insert around asm.)
+__device__ __forceinline__ float pack_half(float a, float b) {   // lanes <32: a[l]+a[l+32]; lanes >=32: b[l-32]+b[l]
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float pack_row(float a, float b) {    // even rows: a[row]+a[row+1]; odd rows: b[row-1]+b[row]
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// sum over the 16 lanes of each row; every lane of the row ends with the row's total
+__device__ __forceinline__ float row_sum(float v) {
+  v += dpp_mov<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141, 0xF>(v);   // row_half_mirror
+  v += dpp_mov<0x140, 0xF>(v);   // row_mirror
+  return v;
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -476,10 +523,13 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 n0 = s0[cnt - 1], n1 = s1[cnt - 1];
+    float2 n2 = s2[cnt - 1];
     for (int j = cnt - 1; j >= 0; --j) {
-      const float4 e0 = s0[j];
-      const float4 e1 = s1[j];
-      const float2 e2 = s2[j];
+      const float4 e0 = n0, e1 = n1;
+      const float2 e2 = n2;
+      const int jn = max(j - 1, 0);           // prefetch the next entry while this one is processed
+      n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
       const uint32_t pos = (uint32_t)(lo + j + 1);
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
@@ -527,26 +577,27 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         }
       }
       if (hit) {
-        float mx = sq * dx;
-        float mxx = wave_sum_to_hi(mx * dx);
-        float mxy = wave_sum_to_hi(sqy * dx);
-        mx = wave_sum_to_hi(mx);
-        const float my = wave_sum_to_hi(sqy);
-        const float myy = wave_sum_to_hi(sqyy);
-        dop = wave_sum_to_hi(dop);
-        dr = wave_sum_to_hi(dr); dg = wave_sum_to_hi(dg); db = wave_sum_to_hi(db);
+        const float mx = sq * dx;
+        // nine sums over 256 pixels -> one 48-byte row: pack_half / pack_row each halve the number of live
+        // values, leaving value 4n + 2*(row&1) + (row>>1) in register n of 16-lane row `row`; three row sums.
+        const float c0 = pack_half(mx, sqy);             // values 0,1  : S q dx    | S q dy
+        const float c1 = pack_half(mx * dx, sqy * dx);   // values 2,3  : S q dx^2  | S q dx dy
+        const float c2 = pack_half(sqyy, dop);           // values 4,5  : S q dy^2  | S G dL/dalpha
+        const float c3 = pack_half(dr, dg);              // values 6,7
+        const float c4 = pack_half(db, 0.f);             // values 8,9
+        const float r0 = row_sum(pack_row(c0, c1));
+        const float r1 = row_sum(pack_row(c2, c3));
+        const float r2 = row_sum(pack_row(c4, 0.f));
+        if ((lane & 15) == 0) {
+          const int k = lane >> 4;
+          float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[j] * PART_F4) + 2 * (k & 1) + (k >> 1);
+          row[0] = r0; row[4] = r1; row[8] = r2;
+        }
         if (OBJ) {
 #pragma unroll
           for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = wave_sum_to_hi(dobj[c]);
-        }
-        if (lane == 63) {
-          const uint32_t slot = sslot[j];
-          float4* row = a.part + (size_t)slot * PART_F4;
-          row[0] = make_float4(mx, my, mxx, mxy);
-          row[1] = make_float4(myy, dop, dr, dg);
-          row[2] = make_float4(db, 0.f, 0.f, 0.f);
-          if (OBJ) {
-            float4* ro = a.part_obj + (size_t)slot * 4;
+          if (lane == 63) {
+            float4* ro = a.part_obj + (size_t)sslot[j] * 4;
             ro[0] = make_float4(dobj[0], dobj[1], dobj[2], dobj[3]);
             ro[1] = make_float4(dobj[4], dobj[5], dobj[6], dobj[7]);
             ro[2] = make_float4(dobj[8], dobj[9], dobj[10], dobj[11]);
@@ -590,8 +641,6 @@ struct PreBwdArgs {
   float* drots;
   float* dcov3d;
 };
-
-constexpr int SHROW_F4 = 13;   // 12 float4 of payload (K = 16) + 1 pad
 
 template <bool SH_LDS>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
