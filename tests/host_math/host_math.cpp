@@ -62,4 +62,12 @@ void hm_preprocess_bwd(int P, int K, int H, int W, float tanfovx, float tanfovy,
   }
 }
 
+// geo [n,6]: cx,cy,A,B,C,opacity ; out[n] = tile_can_contribute over the pixel-centre rectangle
+void hm_tile_can_contribute(int n, const float* geo, float x0, float y0, float x1, float y1, int* out) {
+  for (int i = 0; i < n; ++i) {
+    const float* g = geo + 6 * i;
+    out[i] = tile_can_contribute(g[0], g[1], g[2], g[3], g[4], g[5], x0, y0, x1, y1) ? 1 : 0;
+  }
+}
+
 }  // extern "C"

@@ -1,0 +1,86 @@
+"""View-sharded data parallelism on CPU (gloo, world_size 2): the all-reduced attribute gradients equal the
+single-process sum over the batch's views, and replicas stay identical after the PGD step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gsplat_attack import dist as gdist
+from gsplat_attack import pgd
+from gsplat_attack.scenes import make_scene
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _view_grads(model, view: int):
+    """A stand-in for render+backward on CPU: any deterministic per-view gradient will do for the plumbing."""
+    g = torch.Generator().manual_seed(100 + view)
+    return {n: torch.randn(getattr(model, n).shape, generator=g) for n in gdist.ATTACK_PARAMS}
+
+
+def _worker(rank, world, port, n_views, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = gdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    model, _, _ = make_scene("hydrant-1k", P=200, n_views=1)
+    orig = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
+    for step in range(2):
+        model.zero_grad()
+        for v in gdist.views_of_rank(n_views, rank, world):
+            for n, gr in _view_grads(model, v + 10 * step).items():
+                p = getattr(model, n)
+                p.grad = gr if p.grad is None else p.grad + gr
+        nbytes = gdist.allreduce_attribute_grads(model)
+        assert nbytes == sum(getattr(model, n).numel() * 4 for n in gdist.ATTACK_PARAMS)
+        pgd.gaussian_color_l2_attack(model, 0.5, 5.0, orig["_features_rest"], orig["_features_dc"])
+        pgd.gaussian_position_linf_attack(model, 0.01, 0.05, orig["_xyz"])
+    torch.save({n: getattr(model, n).detach() for n in gdist.ATTACK_PARAMS} |
+               {"grad_" + n: getattr(model, n).grad for n in gdist.ATTACK_PARAMS}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_views", [2, 5])
+def test_allreduce_equals_single_process_sum(tmp_path, n_views):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, n_views, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"replicas diverged on {k}"
+    # single-process reference of the same two steps
+    model, _, _ = make_scene("hydrant-1k", P=200, n_views=1)
+    orig = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
+    for step in range(2):
+        model.zero_grad()
+        for v in range(n_views):
+            for n, gr in _view_grads(model, v + 10 * step).items():
+                p = getattr(model, n)
+                p.grad = gr if p.grad is None else p.grad + gr
+        pgd.gaussian_color_l2_attack(model, 0.5, 5.0, orig["_features_rest"], orig["_features_dc"])
+        pgd.gaussian_position_linf_attack(model, 0.01, 0.05, orig["_xyz"])
+    for n in gdist.ATTACK_PARAMS:
+        assert torch.allclose(r0["grad_" + n], getattr(model, n).grad, atol=1e-5), n
+        assert torch.allclose(r0[n], getattr(model, n).detach(), atol=1e-5), n
+
+
+def test_view_partition_covers_batch_once():
+    for world in (1, 2, 4, 8):
+        for n in (1, 5, 8, 13):
+            seen = sorted(v for r in range(world) for v in gdist.views_of_rank(n, r, world))
+            assert seen == list(range(n))
+
+
+def test_single_process_allreduce_is_a_noop():
+    model, _, _ = make_scene("hydrant-1k", P=50, n_views=1)
+    assert gdist.allreduce_attribute_grads(model) == 0
