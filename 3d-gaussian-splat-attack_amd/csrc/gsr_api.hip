@@ -187,6 +187,8 @@ struct GsrCtx {
   int gridx = 0, gridy = 0, ntiles = 0;
   uint32_t N = 0;
   // inputs (owned by the caller)
+  bool raw = false;              // inputs are raw parameters (gsr_forward_raw)
+  const float* sh_dc = nullptr;  // raw: _features_dc
   const float *means3D = nullptr, *shs = nullptr, *sh_objs = nullptr, *colors = nullptr, *opac = nullptr,
               *scales = nullptr, *rots = nullptr, *cov3d = nullptr;
   // kept workspace
@@ -226,10 +228,15 @@ void gsr_ctx_free(GsrCtx* c) {
   delete c;
 }
 
-int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
-                const float* sh_objs, const float* colors_precomp, const float* opacities, const float* scales,
-                const float* rotations, const float* cov3D_precomp, float* out_color, float* out_objects,
-                int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream) {
+}  // extern "C"
+
+// raw != 0: scales / rotations / opacities are the reference model's RAW parameters, shs is _features_rest and
+// sh_dc is _features_dc (K must be 16); activations and their chain rule run inside K1 / K9.
+static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
+                        const float* sh_dc, const float* sh_objs, const float* colors_precomp, const float* opacities,
+                        const float* scales, const float* rotations, const float* cov3D_precomp, float* out_color,
+                        float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream,
+                        bool raw) {
   if (ctx_out) *ctx_out = nullptr;
   if (!s || !out_color) return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / out_color");
   if (P < 0 || s->image_height <= 0 || s->image_width <= 0)
@@ -263,6 +270,7 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
   c->dev = dev; c->st = *s; c->P = P; c->K = K; c->gridx = gridx; c->gridy = gridy; c->ntiles = ntiles;
   c->means3D = means3D; c->shs = shs; c->sh_objs = sh_objs; c->colors = colors_precomp; c->opac = opacities;
   c->scales = scales; c->rots = rotations; c->cov3d = cov3D_precomp;
+  c->raw = raw; c->sh_dc = sh_dc;
 
   const size_t Pp = (size_t)std::max(P, 1);
   // ---- kept slab ---------------------------------------------------------------------------
@@ -322,12 +330,15 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
   if (P > 0) {
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
-      if (shs && K == 16)
-        hipLaunchKernelGGL(k_preprocess<true>, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
-                           opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
+      if (raw)
+        hipLaunchKernelGGL((k_preprocess<true, true>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
+                           cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
+      else if (shs && K == 16)
+        hipLaunchKernelGGL((k_preprocess<true, false>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
+                           cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       else
-        hipLaunchKernelGGL(k_preprocess<false>, gridP, blk, 0, st, P, K, va, means3D, scales, rotations, cov3D_precomp,
-                           opacities, shs, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
+        hipLaunchKernelGGL((k_preprocess<false, false>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
+                           cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
       scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st);
       F_LAUNCH("preprocess");
@@ -400,7 +411,7 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
-    static const int fwd_npx = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+    static const int fwd_npx = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 2; }();
     const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
     if (out_objects && sh_objs) {
       if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
@@ -422,9 +433,31 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
 #undef F_LAUNCH
 }
 
-int gsr_backward(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
-                 float* dshs, float* dsh_objs, float* dcolors_precomp, float* dopacities, float* dscales,
-                 float* drotations, float* dcov3D, void* stream) {
+extern "C" {
+
+int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
+                const float* sh_objs, const float* colors_precomp, const float* opacities, const float* scales,
+                const float* rotations, const float* cov3D_precomp, float* out_color, float* out_objects,
+                int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream) {
+  return forward_impl(s, P, K, means3D, shs, nullptr, sh_objs, colors_precomp, opacities, scales, rotations,
+                      cov3D_precomp, out_color, out_objects, radii, ctx_out, num_rendered, stream, false);
+}
+
+int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const float* features_dc,
+                    const float* features_rest, const float* objects_dc, const float* opacity_logit,
+                    const float* log_scaling, const float* rotation_raw, float* out_color, float* out_objects,
+                    int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream) {
+  if (P > 0 && (!features_dc || !features_rest || !log_scaling || !rotation_raw))
+    return set_err(GSR_ERR_INVALID, "gsr_forward_raw: null features_dc / features_rest / log_scaling / rotation_raw");
+  return forward_impl(s, P, 16, xyz, features_rest, features_dc, objects_dc, nullptr, opacity_logit, log_scaling,
+                      rotation_raw, nullptr, out_color, out_objects, radii, ctx_out, num_rendered, stream, true);
+}
+
+}  // extern "C"
+
+static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
+                         float* dshs, float* dsh_dc, float* dsh_objs, float* dcolors_precomp, float* dopacities,
+                         float* dscales, float* drotations, float* dcov3D, void* stream) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_backward: null context");
   if (!grad_color) return set_err(GSR_ERR_INVALID, "gsr_backward: grad_color is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -472,18 +505,44 @@ int gsr_backward(GsrCtx* c, const float* grad_color, const float* grad_objects, 
     pa.offg = c->offg; pa.G0 = c->G0; pa.G1 = c->G1; pa.G2 = c->G2;
     pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
     pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
+    pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc;
     pa.dmeans3D = dmeans3D; pa.dmeans2D = dmeans2D; pa.dsh = c->shs ? dshs : nullptr; pa.dsh_objs = dsh_objs;
     pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
     // SH rows of 16 coefficients x 3 channels (the only layout the reference uses) go through LDS
     const bool sh_lds = c->shs != nullptr && pa.dsh != nullptr && c->K == 16;
-    if (sh_lds) hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3((P + 255) / 256), dim3(256), 0, st, pa);
-    else hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    if (c->raw) {
+      if (!pa.dsh || !pa.dsh_dc)
+        return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
+      hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    } else if (sh_lds) {
+      hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    } else {
+      hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3((P + 255) / 256), dim3(256), 0, st, pa);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
   }
   return done(GSR_OK);
+}
+
+extern "C" {
+
+int gsr_backward(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
+                 float* dshs, float* dsh_objs, float* dcolors_precomp, float* dopacities, float* dscales,
+                 float* drotations, float* dcov3D, void* stream) {
+  if (c && c->raw) return set_err(GSR_ERR_STATE, "gsr_backward: context came from gsr_forward_raw; use gsr_backward_raw");
+  return backward_impl(c, grad_color, grad_objects, dmeans3D, dmeans2D, dshs, nullptr, dsh_objs, dcolors_precomp,
+                       dopacities, dscales, drotations, dcov3D, stream);
+}
+
+int gsr_backward_raw(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dxyz, float* dmeans2D,
+                     float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
+                     float* dlog_scaling, float* drotation_raw, void* stream) {
+  if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw: context came from gsr_forward; use gsr_backward");
+  return backward_impl(c, grad_color, grad_objects, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, dobjects_dc, nullptr,
+                       dopacity_logit, dlog_scaling, drotation_raw, nullptr, stream);
 }
 
 int gsr_mark_visible(const GsrSettings* s, int32_t P, const float* means3D, uint8_t* present, void* stream) {

@@ -46,11 +46,52 @@ constexpr uint32_t RECT_MASK = 0xFFFu;
 // ------------------------------------------------------------------------------------------------
 constexpr int SHROW_F4 = 13;   // 12 float4 of payload (K = 16) + 1 pad
 
-template <bool SH_LDS>
+// Copies the SH rows of one wave's Gaussians into LDS rows of SHROW_F4 float4.  RAW: the row is assembled from the
+// reference model's two tensors, _features_dc [P,1,3] and _features_rest [P,15,3] (what get_features concatenates,
+// reference scene/gaussian_model.py:113-116).
+template <bool RAW>
+__device__ __forceinline__ void stage_sh_rows(float4* wrow, const float* sh, const float* sh_dc, int gw0, int nw, int lane) {
+  if (!RAW) {
+    const float4* src = reinterpret_cast<const float4*>(sh) + (size_t)gw0 * 12;
+    for (int i = lane; i < nw * 12; i += 64) {
+      const int row = i / 12;
+      wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
+    }
+  } else {
+    float* wf = reinterpret_cast<float*>(wrow);
+    const float* dc = sh_dc + (size_t)gw0 * 3;
+    for (int i = lane; i < nw * 3; i += 64) {
+      const int row = i / 3;
+      wf[row * (4 * SHROW_F4) + (i - row * 3)] = dc[i];
+    }
+    const float* rest = sh + (size_t)gw0 * 45;          // 64*45*4 B per wave: 16-byte aligned
+    const int n4 = (nw * 45) >> 2;
+    const float4* rest4 = reinterpret_cast<const float4*>(rest);
+    for (int i = lane; i < n4; i += 64) {
+      const float4 v = rest4[i];
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = 4 * i + c, row = e / 45;
+        wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)] = vv[c];
+      }
+    }
+    for (int e = 4 * n4 + lane; e < nw * 45; e += 64) {
+      const int row = e / 45;
+      wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)] = rest[e];
+    }
+  }
+}
+
+// RAW: scales / rots / opac are the reference model's raw parameters (_scaling = log, _rotation un-normalised,
+// _opacity = logit) and the activation getters (exp, normalize, sigmoid: reference scene/gaussian_model.py:31-39,
+// 97-124) are applied here; `sh` is then _features_rest and `sh_dc` _features_dc.
+template <bool SH_LDS, bool RAW>
 __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, const float* __restrict__ means,
                                                     const float* __restrict__ scales, const float* __restrict__ rots,
                                                     const float* __restrict__ cov3d, const float* __restrict__ opac,
-                                                    const float* __restrict__ sh, const float* __restrict__ colors,
+                                                    const float* __restrict__ sh, const float* __restrict__ sh_dc,
+                                                    const float* __restrict__ colors,
                                                     int32_t* __restrict__ radii, float4* __restrict__ G0,
                                                     float4* __restrict__ G1, float4* __restrict__ G2,
                                                     uint32_t* __restrict__ dkey, uint32_t* __restrict__ tcnt) {
@@ -60,14 +101,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   const int g = gw0 + lane;
   if (SH_LDS) {
     const int nw = min(64, P - gw0);
-    if (nw > 0) {
-      float4* wrow = &srow[wave * 64 * SHROW_F4];
-      const float4* src = reinterpret_cast<const float4*>(sh) + (size_t)gw0 * 12;
-      for (int i = lane; i < nw * 12; i += 64) {
-        const int row = i / 12;
-        wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
-      }
-    }
+    if (nw > 0) stage_sh_rows<RAW>(&srow[wave * 64 * SHROW_F4], sh, sh_dc, gw0, nw, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -81,9 +115,14 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
 #pragma unroll
     for (int i = 0; i < 6; ++i) c6[i] = cov3d[6 * g + i];
   } else {
-    const float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
     const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
-    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    if (RAW) {
+      s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+      float inv_n;
+      act_normalize4(q, q, inv_n);
+    }
     cov3d_from_scale_rot(s, va.mod, q, c6);
   }
   Splat s;
@@ -110,7 +149,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
   const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
   G0[g] = make_float4(s.px, s.py, s.A, s.B);
-  G1[g] = make_float4(s.C, opac[g], rgb[0], rgb[1]);
+  G1[g] = make_float4(s.C, RAW ? act_sigmoid(opac[g]) : opac[g], rgb[0], rgb[1]);
   G2[g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
 }
 
@@ -545,16 +584,20 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         if (pos <= smax[k]) {
           const float dy = e0.y - pyf[k];
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
-          const bool cand = (p2 <= 0.f) && (p2 >= e2.y) && (pos <= ncon[k]);
+          const bool cand = (p2 >= e2.y) && (pos <= ncon[k]);
           if (__ballot(cand) != 0ull) {
             hit = true;
             const float G = __builtin_amdgcn_exp2f(p2);
             const float oG = e1.y * G;
             const float alpha = fminf(ALPHA_CAP, oG);
-            const bool valid = cand && (alpha >= ALPHA_MIN);
-            const float inv1m = __builtin_amdgcn_rcpf(1.f - alpha);
-            T[k] = valid ? T[k] * inv1m : T[k];
-            const float w = valid ? alpha * T[k] : 0.f;
+            const bool valid = cand && (p2 <= 0.f) && (alpha >= ALPHA_MIN);
+            // An entry this pixel skips is carried through the recursions as alpha = 0, which leaves T, the
+            // running colour term and every sum bit-for-bit unchanged (x*1, x+0, 0*x are exact): one select
+            // here instead of one per state variable.
+            const float ae = valid ? alpha : 0.f;
+            const float inv1m = __builtin_amdgcn_rcpf(1.f - ae);
+            T[k] *= inv1m;
+            const float w = ae * T[k];
             float cg = fmaf(e1.z, g0[k], fmaf(e1.w, g1[k], e2.x * g2[k]));
             if (OBJ) {
 #pragma unroll
@@ -563,10 +606,9 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
                 dobj[c] = fmaf(w, gO[k][c], dobj[c]);
               }
             }
-            const float An = fmaf(la[k], lcg[k] - Acc[k], Acc[k]);   // la*lcg + (1-la)*Acc
-            Acc[k] = valid ? An : Acc[k];
-            lcg[k] = valid ? cg : lcg[k];
-            la[k] = valid ? alpha : la[k];
+            Acc[k] = fmaf(la[k], lcg[k] - Acc[k], Acc[k]);   // la*lcg + (1-la)*Acc
+            lcg[k] = cg;
+            la[k] = ae;
             const float dLda = valid ? fmaf(T[k], cg - Acc[k], -bgd[k] * inv1m) : 0.f;
             dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
             dop = fmaf(G, dLda, dop);
@@ -630,10 +672,12 @@ struct PreBwdArgs {
   const float* scales;
   const float* rots;
   const float* cov3d;
-  const float* sh;
+  const float* sh;        // RAW: _features_rest
+  const float* sh_dc;     // RAW: _features_dc
   float* dmeans3D;
   float* dmeans2D;
-  float* dsh;
+  float* dsh;             // RAW: gradient of _features_rest
+  float* dsh_dc;          // RAW: gradient of _features_dc
   float* dsh_objs;
   float* dcolors;
   float* dopac;
@@ -642,7 +686,10 @@ struct PreBwdArgs {
   float* dcov3d;
 };
 
-template <bool SH_LDS>
+// RAW: inputs are the raw parameters as in k_preprocess<.,true>; the gradients written are those of the raw
+// parameters (chain rule of exp / normalize / sigmoid applied here) and a.dsh / a.dsh_dc receive the
+// _features_rest / _features_dc parts of the SH gradient.
+template <bool SH_LDS, bool RAW>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
   __shared__ float4 srow[SH_LDS ? 4 * 64 * SHROW_F4 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -651,13 +698,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
   const int K = a.K;
   float4* wrow = SH_LDS ? &srow[wave * 64 * SHROW_F4] : nullptr;
   const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
-  if (SH_LDS && nw > 0) {
-    const float4* src = reinterpret_cast<const float4*>(a.sh) + (size_t)gw0 * 12;
-    for (int i = lane; i < nw * 12; i += 64) {
-      const int row = i / 12;
-      wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
-    }
-  }
+  if (SH_LDS && nw > 0) stage_sh_rows<RAW>(wrow, a.sh, a.sh_dc, gw0, nw, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -708,7 +749,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
       const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
       if (a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
-      if (a.dopac) a.dopac[g] = dop;
+      if (a.dopac) a.dopac[g] = RAW ? dop * e1.y * (1.f - e1.y) : dop;   // e1.y = sigmoid(raw opacity)
       const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
       float dp[3] = {0.f, 0.f, 0.f};
       if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
@@ -727,6 +768,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       }
       float c6[6];
       float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+      float inv_qn = 1.f;
       if (a.cov3d) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
@@ -734,6 +776,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
         s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
         const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
         q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        if (RAW) {
+          s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+          act_normalize4(q, q, inv_qn);
+        }
         cov3d_from_scale_rot(s, a.va.mod, q, c6);
       }
       float dc6[6];
@@ -744,6 +790,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       } else if (a.dscales || a.drots) {
         float ds[3], dq[4];
         cov3d_bwd(s, a.va.mod, q, dc6, ds, dq);
+        if (RAW) {
+          ds[0] *= s[0]; ds[1] *= s[1]; ds[2] *= s[2];     // d exp(x) = exp(x)
+          act_normalize4_bwd(q, inv_qn, dq, dq);
+        }
         if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
         if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
       }
@@ -753,10 +803,35 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float4* dst = reinterpret_cast<float4*>(a.dsh) + (size_t)gw0 * 12;
-    for (int i = lane; i < nw * 12; i += 64) {
-      const int row = i / 12;
-      dst[i] = wrow[row * SHROW_F4 + (i - row * 12)];
+    if (!RAW) {
+      float4* dst = reinterpret_cast<float4*>(a.dsh) + (size_t)gw0 * 12;
+      for (int i = lane; i < nw * 12; i += 64) {
+        const int row = i / 12;
+        dst[i] = wrow[row * SHROW_F4 + (i - row * 12)];
+      }
+    } else {
+      const float* wf = reinterpret_cast<const float*>(wrow);
+      float* dc = a.dsh_dc + (size_t)gw0 * 3;
+      for (int i = lane; i < nw * 3; i += 64) {
+        const int row = i / 3;
+        dc[i] = wf[row * (4 * SHROW_F4) + (i - row * 3)];
+      }
+      float* rest = a.dsh + (size_t)gw0 * 45;
+      const int n4 = (nw * 45) >> 2;
+      float4* rest4 = reinterpret_cast<float4*>(rest);
+      for (int i = lane; i < n4; i += 64) {
+        float vv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = 4 * i + c, row = e / 45;
+          vv[c] = wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)];
+        }
+        rest4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+      for (int e = 4 * n4 + lane; e < nw * 45; e += 64) {
+        const int row = e / 45;
+        rest[e] = wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)];
+      }
     }
   }
 }

@@ -353,6 +353,28 @@ GSR_HD void cov3d_bwd(const float s_in[3], float mod, const float q[4], const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Activation getters of the reference's GaussianModel (scene/gaussian_model.py:31-39) and their chain rule,
+// for the fused raw-parameter entry points: sigmoid (opacity), exp (scaling, inline at the call sites) and
+// torch.nn.functional.normalize (rotation: v / max(||v||, 1e-12)).
+// ---------------------------------------------------------------------------------------------
+GSR_HD float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+GSR_HD void act_normalize4(const float r[4], float q[4], float& inv_n) {
+  const float n = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+  inv_n = 1.0f / fmaxf(n, 1e-12f);
+  const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  q[0] = r0 * inv_n; q[1] = r1 * inv_n; q[2] = r2 * inv_n; q[3] = r3 * inv_n;
+}
+
+// q = normalised quaternion, inv_n = 1/||raw||, dq = dL/dq  ->  dr = dL/d(raw) = (dq - q (q.dq)) / ||raw||
+GSR_HD void act_normalize4_bwd(const float q[4], float inv_n, const float dq[4], float dr[4]) {
+  const float dot = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+  const float d0 = dq[0], d1 = dq[1], d2 = dq[2], d3 = dq[3];
+  dr[0] = (d0 - q[0] * dot) * inv_n; dr[1] = (d1 - q[1] * dot) * inv_n;
+  dr[2] = (d2 - q[2] * dot) * inv_n; dr[3] = (d3 - q[3] * dot) * inv_n;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact-footprint test for one (tile, Gaussian) pair.  A pixel contributes only if
 // alpha = o*exp(-Q/2) >= 1/255 with Q = A dx^2 + 2 B dx dy + C dy^2, i.e. Q <= tau = 2 ln(255 o).
 // Returns false only when NO pixel centre of the rectangle [x0,x1]x[y0,y1] can satisfy that: the minimum

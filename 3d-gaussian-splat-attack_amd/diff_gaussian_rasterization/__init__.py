@@ -76,6 +76,10 @@ def _load():
                                 ctypes.POINTER(vp), i64p, vp]
     lib.gsr_backward.restype = ctypes.c_int
     lib.gsr_backward.argtypes = [vp] * 13
+    lib.gsr_forward_raw.restype = ctypes.c_int
+    lib.gsr_forward_raw.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [vp, vp, vp, ctypes.POINTER(vp), i64p, vp]
+    lib.gsr_backward_raw.restype = ctypes.c_int
+    lib.gsr_backward_raw.argtypes = [vp] * 12
     lib.gsr_ctx_free.restype = None
     lib.gsr_ctx_free.argtypes = [vp]
     lib.gsr_mark_visible.restype = ctypes.c_int
@@ -282,6 +286,99 @@ class _RasterizeGaussians(torch.autograd.Function):
                 shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None)
 
 
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Same path with the activation getters fused into the kernels (gsr_forward_raw / gsr_backward_raw): takes the
+    RAW parameter tensors of a reference-style GaussianModel."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation, raster_settings):
+        lib = _load()
+        if not xyz.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
+                               f"{xyz.device}); there is no CPU path")
+        device = xyz.device
+        P = int(xyz.shape[0])
+        if tuple(features_dc.shape) != (P, 1, 3) or tuple(features_rest.shape) != (P, 15, 3):
+            raise ValueError("fused path needs _features_dc [P,1,3] and _features_rest [P,15,3] (SH degree 3 storage)")
+
+        def prep(t):
+            return None if t is None or t.numel() == 0 else _f32c(t.detach(), device)
+        x, dc, rest, obj = prep(xyz), prep(features_dc), prep(features_rest), prep(objects_dc)
+        op, sc, ro = prep(opacity), prep(scaling), prep(rotation)
+        if obj is not None and obj.numel() != P * NUM_OBJECTS:
+            raise ValueError(f"objects_dc must hold P*{NUM_OBJECTS} values, got {tuple(obj.shape)}")
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        pack = _SettingsPack(raster_settings, device)
+        color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+        objects = torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device)
+        radii = torch.empty(P, dtype=torch.int32, device=device)
+        handle = ctypes.c_void_p(None)
+        nren = ctypes.c_int64(0)
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
+                                     _ptr(ro), _ptr(color), _ptr(objects), _ptr(radii), ctypes.byref(handle),
+                                     ctypes.byref(nren), stream)
+        if rc != 0:
+            raise Exception(_err(lib)) if rc == 1 else RuntimeError(_err(lib))
+        ctx.holder = _CtxHolder(lib, handle)
+        ctx.pack = pack
+        ctx.num_rendered = nren.value
+        ctx.shapes = (xyz.shape, means2D.shape, features_dc.shape, features_rest.shape,
+                      None if objects_dc is None else objects_dc.shape, opacity.shape, scaling.shape, rotation.shape)
+        ctx.kept = (x, dc, rest, obj, op, sc, ro)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, objects
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_objects):
+        lib = ctx.holder.lib
+        x, dc, rest, obj, op, sc, ro = ctx.kept
+        device = x.device
+        P = int(x.shape[0])
+        H, W = ctx.pack.c.image_height, ctx.pack.c.image_width
+        if grad_color is None:
+            grad_color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
+        gcol = _f32c(grad_color, device)
+        gobj = None if (grad_objects is None or obj is None) else _f32c(grad_objects, device)
+        need = ctx.needs_input_grad
+
+        def out(cond, *shape):
+            return torch.empty(*shape, dtype=torch.float32, device=device) if cond else None
+        d_x = out(need[0], P, 3)
+        d_m2 = out(need[1], P, 3)
+        want_sh = need[2] or need[3]
+        d_dc = out(want_sh, P, 1, 3)
+        d_rest = out(want_sh, P, 15, 3)
+        d_obj = out(need[4] and obj is not None, P, NUM_OBJECTS)
+        d_op = out(need[5], P)
+        d_sc = out(need[6], P, 3)
+        d_ro = out(need[7], P, 4)
+        if P > 0:
+            with torch.cuda.device(device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                rc = lib.gsr_backward_raw(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
+                                          _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), stream)
+            if rc != 0:
+                raise RuntimeError(_err(lib))
+        s = ctx.shapes
+
+        def shaped(t, shape, wanted=True):
+            return None if (t is None or not wanted) else t.reshape(shape)
+        return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
+                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None)
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
+                            raster_settings):
+    """(color[3,H,W], radii[P], objects[16,H,W]) from the RAW parameters of a reference-style GaussianModel
+    (_xyz, _features_dc, _features_rest, _objects_dc or None, _opacity, _scaling, _rotation): equal to the
+    getters (scene/gaussian_model.py:97-124) followed by GaussianRasterizer.forward, in one fused pass."""
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
+                                        raster_settings)
+
+
 def rasterize_gaussians(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
@@ -373,5 +470,6 @@ def trim_pool() -> None:
     _load().gsr_trim_pool()
 
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "NUM_OBJECTS",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
+           "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 
 from .sh import eval_sh
 
@@ -20,13 +20,26 @@ class PipelineParams:
     """The three switches render() reads (reference attack.py:254-256, configs/config.yaml:61-63)."""
 
     def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False,
-                 skip_objects: bool = False):
+                 skip_objects: bool = False, fused_activations: bool = True):
         self.convert_SHs_python = convert_SHs_python
         self.compute_cov3D_python = compute_cov3D_python
         self.debug = debug
+        # extension (results unchanged): hand the model's RAW parameters to the rasteriser and let its kernels apply
+        # exp / sigmoid / normalize / cat and their chain rule, instead of materialising activated copies in HBM
+        self.fused_activations = fused_activations
         # extension (default off = reference behaviour): do not composite the 16 object-feature channels,
         # which the attack never reads (``render_object`` is then all zeros)
         self.skip_objects = skip_objects
+
+
+def _has_raw_layout(pc) -> bool:
+    """The fused path needs the reference model's storage: degree-3 SH split in _features_dc / _features_rest."""
+    try:
+        P = pc._xyz.shape[0]
+        return (pc._xyz.is_cuda and tuple(pc._features_dc.shape) == (P, 1, 3)
+                and tuple(pc._features_rest.shape) == (P, 15, 3) and pc._opacity.numel() == P)
+    except AttributeError:
+        return False
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
@@ -52,6 +65,18 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         prefiltered=False,
         debug=pipe.debug,
     )
+    if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.convert_SHs_python
+            and not pipe.compute_cov3D_python and _has_raw_layout(pc)):
+        rendered_image, radii, rendered_objects = rasterize_gaussians_raw(
+            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
+            None if getattr(pipe, "skip_objects", False) else pc._objects_dc, pc._opacity, pc._scaling, pc._rotation,
+            raster_settings)
+        return {"render": rendered_image,
+                "viewspace_points": screenspace_points,
+                "visibility_filter": radii > 0,
+                "radii": radii,
+                "render_object": rendered_objects}
+
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     means3D = pc.get_xyz

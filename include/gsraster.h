@@ -103,6 +103,21 @@ int gsr_backward(GsrCtx* ctx, const float* grad_color, const float* grad_objects
                  float* dshs, float* dsh_objs, float* dcolors_precomp, float* dopacities, float* dscales,
                  float* drotations, float* dcov3D, void* stream);
 
+/* Fused-activation variants of the same path for callers that hold a reference-style GaussianModel: the seven RAW
+ * parameter tensors go in (reference scene/gaussian_model.py:42-59) and the activation getters the reference's render()
+ * applies first (exp / sigmoid / normalize / cat, scene/gaussian_model.py:97-124, gaussian_renderer/__init__.py:53-83)
+ * and their chain rule run inside the per-Gaussian kernels, so no activated copy of the attributes is written to HBM.
+ *   xyz [P,3]; features_dc [P,1,3]; features_rest [P,15,3]; objects_dc [P,16] or NULL; opacity_logit [P];
+ *   log_scaling [P,3]; rotation_raw [P,4] (un-normalised; normalised as v / max(|v|, 1e-12)).
+ * Results equal gsr_forward / gsr_backward composed with those PyTorch ops; gradients are w.r.t. the RAW tensors. */
+int gsr_forward_raw(const GsrSettings* settings, int32_t P, const float* xyz, const float* features_dc,
+                    const float* features_rest, const float* objects_dc, const float* opacity_logit,
+                    const float* log_scaling, const float* rotation_raw, float* out_color, float* out_objects,
+                    int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream);
+int gsr_backward_raw(GsrCtx* ctx, const float* grad_color, const float* grad_objects, float* dxyz, float* dmeans2D,
+                     float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
+                     float* dlog_scaling, float* drotation_raw, void* stream);
+
 /* Releases the context's workspace back to the pool (stream-ordered: safe right after enqueueing backward). */
 void gsr_ctx_free(GsrCtx* ctx);
 
