@@ -409,6 +409,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     RenderArgs ra;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
+    static const int map_mode_f = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+    ra.map_mode = map_mode_f;
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
     static const int fwd_npx = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 2; }();
@@ -490,6 +492,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     RenderBwdArgs ra;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = c->sh_objs; ra.bg = c->st.bg; ra.W = c->st.image_width; ra.H = c->st.image_height;
+    static const int map_mode_b = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+    ra.map_mode = map_mode_b;
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
     const dim3 gridT(render_grid(c->ntiles)), blk(64);

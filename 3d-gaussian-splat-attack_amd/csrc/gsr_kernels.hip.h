@@ -277,7 +277,7 @@ struct RenderArgs {
   const float4* R2;
   const float* sh_objs;   // [P,16] or null
   const float* bg;
-  int W, H, gridx, ntiles;
+  int W, H, gridx, ntiles, map_mode;
   float* out_color;       // [3,H,W]
   float* out_objects;     // [16,H,W] or null
   float* final_T;         // [H*W]
@@ -287,11 +287,23 @@ struct RenderArgs {
 constexpr int PXL = 4;   // pixels per lane
 constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ int tile_of_block(int ntiles) {
-  const int tpx = (ntiles + 7) >> 3;
-  return (int)(blockIdx.x & 7u) * tpx + (int)(blockIdx.x >> 3);
+// Work-item index of this block.  mode 1: blocks b and b+8 run on one XCD (observed round-robin dispatch), so XCD x
+// is handed the contiguous band [x*ceil(n/8), ...): neighbouring tiles share one L2.  mode 0: identity (items are
+// dealt round-robin over the XCDs: no L2 sharing, but image regions of different cost spread over all XCDs).
+// mode 2: bands of 32 consecutive items are dealt round-robin: local sharing inside a band, global spread.
+__device__ __forceinline__ int item_of_block(int nitems, int mode) {
+  const int b = (int)blockIdx.x;
+  if (mode == 0) return b;
+  if (mode == 1) {
+    const int tpx = (nitems + 7) >> 3;
+    return (b >> 3) < tpx ? (b & 7) * tpx + (b >> 3) : nitems;   // the grid is padded: surplus blocks exit
+  }
+  // mode 2: block b -> XCD x = b&7, slot s = b>>3 on that XCD; XCD x owns bands x, x+8, x+16, ... of 32 items
+  const int x = b & 7, s = b >> 3;
+  return ((s >> 5) * 8 + x) * 32 + (s & 31);
 }
-inline int render_grid(int ntiles) { return 8 * ((ntiles + 7) >> 3); }
+__device__ __forceinline__ int tile_of_block(int ntiles) { return item_of_block(ntiles, 1); }
+inline int render_grid(int nitems) { return 256 * ((nitems + 255) / 256); }   // covers every mapping mode
 
 // Staged form of a splat: the conic is pre-scaled so that p2 = log2(e) * power comes out of two FMAs,
 // and thr2 is a slightly LOWERED bound on the p2 at which alpha reaches 1/255 (prefilter only: the exact
@@ -317,7 +329,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   __shared__ float2 s2[64];
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
   const int lane = threadIdx.x;
-  const int item = tile_of_block(a.ntiles * NSUB);
+  const int item = item_of_block(a.ntiles * NSUB, a.map_mode);
   if (item >= a.ntiles * NSUB) return;
   const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
@@ -485,7 +497,7 @@ struct RenderBwdArgs {
   const float4* R2;
   const float* sh_objs;
   const float* bg;
-  int W, H, gridx, ntiles;
+  int W, H, gridx, ntiles, map_mode;
   const float* final_T;
   const uint32_t* n_contrib;
   const float* grad_color;    // [3,H,W]
@@ -504,7 +516,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   __shared__ uint32_t sslot[64];
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
   const int lane = threadIdx.x;
-  const int tile = tile_of_block(a.ntiles);
+  const int tile = item_of_block(a.ntiles, a.map_mode);
   if (tile >= a.ntiles) return;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
