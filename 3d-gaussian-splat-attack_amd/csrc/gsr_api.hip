@@ -263,6 +263,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const int gridx = (W + TILE - 1) / TILE, gridy = (H + TILE - 1) / TILE;
   const int ntiles = gridx * gridy;
   if (gridx > 4095 || gridy > 4095) return set_err(GSR_ERR_INVALID, "gsr_forward: image larger than 65520 px per side");
+  if ((uint32_t)P > RANK_MASK) return set_err(GSR_ERR_INVALID, "gsr_forward: more than 2^28 Gaussians");
   const size_t HW = (size_t)H * W;
 
   GsrCtx* c = new (std::nothrow) GsrCtx();

@@ -37,6 +37,8 @@ __device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
 }
 
 constexpr uint32_t RECT_MASK = 0xFFFu;
+constexpr int RANK_BITS = 28;                       // pair value = depth rank | strip mask << 28
+constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 
 // ------------------------------------------------------------------------------------------------
 // K1: per-Gaussian preprocess, one thread per Gaussian in storage order.  With the reference's SH layout
@@ -204,7 +206,8 @@ __device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo,
 
 // A (tile, Gaussian) pair of the reference's 3-sigma tile rect is kept only if some pixel of the tile can pass
 // the reference's own alpha test (alpha >= 1/255); pairs that cannot are given the key `ntiles`, sort to the
-// tail and are never composited.  The rendered image, radii and gradients are unchanged by construction
+// tail and are never composited.  The same test per 16x4 strip gives a 4-bit mask that rides in the top bits of
+// the pair's value, so K6/K7 skip strips with scalar bit tests instead of evaluating the splat there.  The rendered image, radii and gradients are unchanged by construction
 // (tile_can_contribute is conservative); only the work shrinks.  `cull` = 0 keeps every pair.
 __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, uint32_t P, uint32_t N,
                                               const float4* __restrict__ R0, const float4* __restrict__ R1,
@@ -238,14 +241,24 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
     const uint32_t dy = local / wx, dx = local - dy * wx;
     const uint32_t tx = minx + dx, ty = miny + dy;
     uint32_t key = ty * (uint32_t)gridx + tx;
+    uint32_t mask = 0xFu;   // one bit per 16x4 strip of the tile that the Gaussian can reach
     if (cull) {
       const float4 a = R0[r], b = R1[r];
-      const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-      const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1)), y1 = fminf(y0 + (float)(TILE - 1), (float)(H - 1));
-      if (!tile_can_contribute(a.x, a.y, a.z, a.w, b.x, b.y, x0, y0, x1, y1)) key = ntiles;
+      const float x0 = (float)(tx * TILE);
+      const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
+      mask = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float y0 = (float)(ty * TILE + 4 * k);
+        if (y0 <= (float)(H - 1)) {
+          const float y1 = fminf(y0 + 3.0f, (float)(H - 1));
+          if (tile_can_contribute(a.x, a.y, a.z, a.w, b.x, b.y, x0, y0, x1, y1)) mask |= 1u << k;
+        }
+      }
+      if (mask == 0) key = ntiles;
     }
     pair_tile[e] = key;
-    pair_rank[e] = r;
+    pair_rank[e] = r | (mask << RANK_BITS);
   }
 }
 
@@ -305,18 +318,22 @@ __device__ __forceinline__ int item_of_block(int nitems, int mode) {
 __device__ __forceinline__ int tile_of_block(int ntiles) { return item_of_block(ntiles, 1); }
 inline int render_grid(int nitems) { return 256 * ((nitems + 255) / 256); }   // covers every mapping mode
 
-// Staged form of a splat: the conic is pre-scaled so that p2 = log2(e) * power comes out of two FMAs,
-// and thr2 is a slightly LOWERED bound on the p2 at which alpha reaches 1/255 (prefilter only: the exact
-// alpha test of the reference is applied inside the strip body).
+// Staged form of a splat: the conic is pre-scaled so that p2 = log2(e) * power comes out of two FMAs.  c.y is a
+// slightly LOWERED bound on the p2 at which alpha reaches 1/255 (a per-pixel prefilter: the reference's exact alpha
+// test is applied afterwards) whose four lowest mantissa bits are replaced by the pair's strip mask (bit k: strip k
+// of the tile can be reached) -- a 2e-6 relative nudge, far inside the bound's own 1e-4 margin.
 struct StagedSplat { float4 a; float4 b; float2 c; };
-__device__ __forceinline__ StagedSplat stage_splat(const float4 r0, const float4 r1, const float bch) {
+__device__ __forceinline__ StagedSplat stage_splat(const float4 r0, const float4 r1, const float bch, uint32_t mask) {
   StagedSplat s;
   s.a = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
   s.b = make_float4(-0.5f * LOG2E * r1.x, r1.y, r1.z, r1.w);
   const float t = -__log2f(255.0f * r1.y);             // +inf for opacity 0: never a candidate
-  s.c = make_float2(bch, t - 1e-4f * (fabsf(t) + 1.0f));
+  const float thr = t - 1e-4f * (fabsf(t) + 1.0f);
+  s.c = make_float2(bch, __uint_as_float((__float_as_uint(thr) & ~0xFu) | (mask & 0xFu)));
   return s;
 }
+
+constexpr float PX_OFF = 1.0e30f;   // y coordinate of a finished / out-of-image pixel: p2 = -inf, alpha = 0
 
 // NPX = pixels per lane: 4 -> one wave per tile, 2 -> two waves (16x8 halves), 1 -> four waves (16x4 strips).
 // Fewer pixels per wave = shorter dependent chain per list entry and more, smaller work items for the
@@ -337,32 +354,31 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)x;
   int y[NPX];
-  float pyf[NPX], T[NPX], Tfin[NPX], C[NPX][3];
+  float pyf[NPX], T[NPX], C[NPX][3];
   float O[OBJ ? NPX : 1][NUM_OBJ];
   uint32_t last[NPX];
-  bool alive[NPX];
-  bool any_alive = false;
+  uint32_t alive = 0;                       // bit k: strip k still has an unfinished pixel (wave-uniform)
 #pragma unroll
   for (int k = 0; k < NPX; ++k) {
     y[k] = ty * TILE + sub * (4 * NPX) + (lane >> 4) + 4 * k;
-    pyf[k] = (float)y[k];
-    T[k] = (x < a.W && y[k] < a.H) ? 1.f : 0.f;   // T == 0 <=> this pixel is finished
-    Tfin[k] = 0.f;
+    const bool inside = x < a.W && y[k] < a.H;
+    pyf[k] = inside ? (float)y[k] : PX_OFF;
+    T[k] = 1.f;
     C[k][0] = C[k][1] = C[k][2] = 0.f;
     last[k] = 0;
-    alive[k] = __ballot(T[k] > 0.f) != 0ull;
-    any_alive = any_alive || alive[k];
+    if (__ballot(inside) != 0ull) alive |= 1u << k;
     if (OBJ) {
 #pragma unroll
       for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = 0.f;
     }
   }
-  for (uint32_t base = rg.x; base < rg.y && any_alive; base += 64) {
+  for (uint32_t base = rg.x; base < rg.y && alive; base += 64) {
     const uint32_t i = base + lane;
     if (i < rg.y) {
-      const uint32_t r = a.pair_rank[i];
+      const uint32_t pv = a.pair_rank[i];
+      const uint32_t r = pv & RANK_MASK;
       const float4 c = a.R2[r];
-      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x);
+      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x, (pv >> RANK_BITS) >> (sub * NPX));
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
@@ -376,43 +392,37 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     const int cnt = min(64u, rg.y - base);
     float4 n0 = s0[0], n1 = s1[0];
     float2 n2 = s2[0];
-    for (int j = 0; j < cnt && any_alive; ++j) {
+    for (int j = 0; j < cnt && alive; ++j) {
       const float4 e0 = n0, e1 = n1;
       const float2 e2 = n2;
       const int jn = min(j + 1, 63);          // prefetch the next entry while this one is composited
       n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+      const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) & alive;
+      if (m == 0) continue;
       const uint32_t pos = base - rg.x + j + 1;
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
 #pragma unroll
       for (int k = 0; k < NPX; ++k) {
-        if (alive[k]) {
+        if (m & (1u << k)) {
           const float dy = e0.y - pyf[k];
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
-          const bool cand = (p2 <= 0.f) && (p2 >= e2.y) && (T[k] > 0.f);
-          if (__ballot(cand) != 0ull) {
-            const float G = __builtin_amdgcn_exp2f(p2);
-            const float alpha = fminf(ALPHA_CAP, e1.y * G);
-            const bool valid = cand && (alpha >= ALPHA_MIN);
-            const float Tn = T[k] * (1.f - alpha);
-            const bool stop = valid && (Tn < T_STOP);
-            const bool contrib = valid && !(Tn < T_STOP);
-            const float w = contrib ? alpha * T[k] : 0.f;
-            C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
-            if (OBJ) {
+          const float G = __builtin_amdgcn_exp2f(p2);
+          const float alpha = fminf(ALPHA_CAP, e1.y * G);
+          const bool valid = (p2 <= 0.f) && (alpha >= ALPHA_MIN);   // finished pixels: p2 = -inf, alpha = 0
+          const float Tn = T[k] * (1.f - alpha);
+          const bool stop = valid && (Tn < T_STOP);
+          const bool contrib = valid && !(Tn < T_STOP);
+          const float w = contrib ? alpha * T[k] : 0.f;
+          C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
+          if (OBJ) {
 #pragma unroll
-              for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[j][c], w, O[k][c]);
-            }
-            Tfin[k] = stop ? T[k] : Tfin[k];
-            T[k] = contrib ? Tn : (stop ? 0.f : T[k]);
-            last[k] = contrib ? pos : last[k];
-            if (__ballot(stop) != 0ull) {
-              alive[k] = __ballot(T[k] > 0.f) != 0ull;
-              any_alive = false;
-#pragma unroll
-              for (int m = 0; m < NPX; ++m) any_alive = any_alive || alive[m];
-            }
+            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[j][c], w, O[k][c]);
           }
+          T[k] = contrib ? Tn : T[k];
+          last[k] = contrib ? pos : last[k];
+          pyf[k] = stop ? PX_OFF : pyf[k];
+          if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
         }
       }
     }
@@ -424,11 +434,10 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   for (int k = 0; k < NPX; ++k) {
     if (x < a.W && y[k] < a.H) {
       const size_t pix = (size_t)y[k] * a.W + x;
-      const float Tf = T[k] + Tfin[k];   // one of the two is zero
-      a.out_color[pix] = C[k][0] + Tf * bg0;
-      a.out_color[HW + pix] = C[k][1] + Tf * bg1;
-      a.out_color[2 * HW + pix] = C[k][2] + Tf * bg2;
-      a.final_T[pix] = Tf;
+      a.out_color[pix] = C[k][0] + T[k] * bg0;
+      a.out_color[HW + pix] = C[k][1] + T[k] * bg1;
+      a.out_color[2 * HW + pix] = C[k][2] + T[k] * bg2;
+      a.final_T[pix] = T[k];
       a.n_contrib[pix] = last[k];
       if (OBJ) {
 #pragma unroll
@@ -558,9 +567,10 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     const int lo = max(hi - 64, 0);
     const int cnt = hi - lo;
     if (lane < cnt) {
-      const uint32_t r = a.pair_rank[rg.x + lo + lane];
+      const uint32_t pv = a.pair_rank[rg.x + lo + lane];
+      const uint32_t r = pv & RANK_MASK;
       const float4 c = a.R2[r];
-      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x);
+      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x, pv >> RANK_BITS);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
@@ -582,6 +592,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       const int jn = max(j - 1, 0);           // prefetch the next entry while this one is processed
       n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
       const uint32_t pos = (uint32_t)(lo + j + 1);
+      const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y));
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
       float sq = 0.f, sqy = 0.f, sqyy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
@@ -593,7 +604,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       bool hit = false;
 #pragma unroll
       for (int k = 0; k < PXL; ++k) {
-        if (pos <= smax[k]) {
+        if ((m & (1u << k)) && pos <= smax[k]) {
           const float dy = e0.y - pyf[k];
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
           const bool cand = (p2 >= e2.y) && (pos <= ncon[k]);
