@@ -276,8 +276,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const size_t Pp = (size_t)std::max(P, 1);
   // ---- kept slab ---------------------------------------------------------------------------
   SlabPlan kp;
-  kp.add<float4>(Pp); kp.add<float4>(Pp); kp.add<float4>(Pp);   // R0..R2 (depth order)
-  kp.add<float4>(Pp); kp.add<float4>(Pp); kp.add<float4>(Pp);   // G0..G2 (storage order)
+  kp.add<float4>(3 * Pp);   // R records (depth order)
+  kp.add<float4>(3 * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW);
   c->keep_bytes = kp.bytes + 256;
@@ -295,8 +295,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     return set_err(GSR_ERR_NOMEM, "gsr_forward: workspace allocation failed (P=%d, %dx%d)", P, W, H);
   }
   Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
-  c->R0 = ks.take<float4>(Pp); c->R1 = ks.take<float4>(Pp); c->R2 = ks.take<float4>(Pp);
-  c->G0 = ks.take<float4>(Pp); c->G1 = ks.take<float4>(Pp); c->G2 = ks.take<float4>(Pp);
+  c->R0 = ks.take<float4>(3 * Pp); c->R1 = c->R0 + 1; c->R2 = c->R0 + 2;   // interleaved 48-byte records
+  c->G0 = ks.take<float4>(3 * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;
   c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
@@ -595,9 +595,8 @@ int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, 
     case 3: src = c->final_T; bytes = sizeof(float) * HW; break;
     case 4: src = c->order; bytes = sizeof(uint32_t) * (size_t)c->P; break;
     case 5: src = c->off; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
-    case 6: src = c->R0; bytes = sizeof(float4) * (size_t)c->P; break;
-    case 7: src = c->R1; bytes = sizeof(float4) * (size_t)c->P; break;
-    case 8: src = c->R2; bytes = sizeof(float4) * (size_t)c->P; break;
+    case 6: src = c->R0; bytes = sizeof(float4) * 3 * (size_t)c->P; break;   // depth-ordered records [P][3] float4
+    case 7: src = c->G0; bytes = sizeof(float4) * 3 * (size_t)c->P; break;   // storage-ordered records
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_export: unknown item %d", what);
   }
   if ((int64_t)bytes > dst_bytes)

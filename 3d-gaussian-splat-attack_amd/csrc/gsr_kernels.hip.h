@@ -2,12 +2,12 @@
 // lists, DPP wave reductions).  Stage names follow SURVEY.md section 2.2 (K1..K10).
 //
 // Data layout in HBM (all float32 / uint32):
-//   G0,G1,G2[g]   per-Gaussian screen geometry written by K1, 3 x float4:
+//   G0,G1,G2[REC * g]   per-Gaussian screen geometry written by K1, 3 x float4:
 //                 G0=(px,py,A,B)  G1=(C,opacity,r,g)  G2=(b, depth, rectx_bits, recty_bits)
 //                 rectx_bits = minx | maxx<<12 | clampbits<<24,  recty_bits = miny | maxy<<12   (tile units)
 //   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF when culled
 //   order[r]      Gaussian index of depth rank r (stable radix argsort of dkey)
-//   R0,R1,R2[r]   the same records gathered into depth order; R2.y = bits(g)
+//   R0,R1,R2[REC * r]   the same records gathered into depth order; R2.y = bits(g)
 //   off[r]        exclusive scan of tiles touched in depth order, off[P] = N (numbers the emitted pairs)
 //   offg[g]       the same scan in storage order (numbers the backward's partial rows)
 //   pair_tile/pair_rank[N]  (tile id, rank) pairs, emitted rank-major, then stably sorted by tile id
@@ -37,6 +37,9 @@ __device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
 }
 
 constexpr uint32_t RECT_MASK = 0xFFFu;
+// The three float4 of a splat record are interleaved (48 contiguous bytes per Gaussian): X0/X1/X2 below are the same
+// array offset by 0/1/2 float4 and are indexed [REC * i], so a record gather touches one or two 64-byte sectors.
+constexpr int REC = 3;
 constexpr int RANK_BITS = 28;                       // pair value = depth rank | strip mask << 28
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
     radii[g] = 0;
     dkey[g] = 0xFFFFFFFFu;
     tcnt[g] = 0;
-    G2[g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
+    G2[REC * g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
     return;
   }
   float rgb[3];
@@ -150,9 +153,9 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   tcnt[g] = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
   const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
   const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
-  G0[g] = make_float4(s.px, s.py, s.A, s.B);
-  G1[g] = make_float4(s.C, RAW ? act_sigmoid(opac[g]) : opac[g], rgb[0], rgb[1]);
-  G2[g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
+  G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
+  G1[REC * g] = make_float4(s.C, RAW ? act_sigmoid(opac[g]) : opac[g], rgb[0], rgb[1]);
+  G2[REC * g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
 }
 
 // K10
@@ -177,17 +180,17 @@ __global__ void __launch_bounds__(256) k_pack(int P, const uint32_t* __restrict_
   const uint32_t g = order[r];
   if (skey[r] == 0xFFFFFFFFu) {   // culled: all such ranks sit at the tail
     cnt[r] = 0;
-    R2[r] = make_float4(0.f, __uint_as_float(g), 0.f, 0.f);
+    R2[REC * r] = make_float4(0.f, __uint_as_float(g), 0.f, 0.f);
     return;
   }
-  const float4 a = G0[g], b = G1[g], c = G2[g];
+  const float4 a = G0[REC * g], b = G1[REC * g], c = G2[REC * g];
   const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
   const uint32_t wx = ((rx >> 12) & RECT_MASK) - (rx & RECT_MASK);
   const uint32_t wy = ((ry >> 12) & RECT_MASK) - (ry & RECT_MASK);
   cnt[r] = wx * wy;
-  R0[r] = a;
-  R1[r] = b;
-  R2[r] = make_float4(c.x, __uint_as_float(g), c.z, c.w);
+  R0[REC * r] = a;
+  R1[REC * r] = b;
+  R2[REC * r] = make_float4(c.x, __uint_as_float(g), c.z, c.w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -234,7 +237,7 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
     } else {
       r = upper_rank(off, r_lo, r_hi + 1, e); o = off[r];
     }
-    const float4 c = R2[r];
+    const float4 c = R2[REC * r];
     const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
     const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
     const uint32_t local = e - o;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
     uint32_t key = ty * (uint32_t)gridx + tx;
     uint32_t mask = 0xFu;   // one bit per 16x4 strip of the tile that the Gaussian can reach
     if (cull) {
-      const float4 a = R0[r], b = R1[r];
+      const float4 a = R0[REC * r], b = R1[REC * r];
       const float x0 = (float)(tx * TILE);
       const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
       mask = 0;
@@ -377,8 +380,8 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     if (i < rg.y) {
       const uint32_t pv = a.pair_rank[i];
       const uint32_t r = pv & RANK_MASK;
-      const float4 c = a.R2[r];
-      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x, (pv >> RANK_BITS) >> (sub * NPX));
+      const float4 c = a.R2[REC * r];
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, (pv >> RANK_BITS) >> (sub * NPX));
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
@@ -569,8 +572,8 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     if (lane < cnt) {
       const uint32_t pv = a.pair_rank[rg.x + lo + lane];
       const uint32_t r = pv & RANK_MASK;
-      const float4 c = a.R2[r];
-      const StagedSplat sp = stage_splat(a.R0[r], a.R1[r], c.x, pv >> RANK_BITS);
+      const float4 c = a.R2[REC * r];
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, pv >> RANK_BITS);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
@@ -765,7 +768,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       }
       View v;
       load_view(v, a.va);
-      const float4 e0 = a.G0[g], e1 = a.G1[g], e2 = a.G2[g];
+      const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
       const float A = e0.z, B = e0.w, C = e1.x;
       // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
       const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;

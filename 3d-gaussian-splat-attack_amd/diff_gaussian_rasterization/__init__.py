@@ -427,7 +427,7 @@ def last_num_rendered(output: torch.Tensor) -> int:
 
 _EXPORTS = {"ranges": (0, torch.int32), "pair_rank": (1, torch.int32), "n_contrib": (2, torch.int32),
             "final_T": (3, torch.float32), "order": (4, torch.int32), "off": (5, torch.int32),
-            "R0": (6, torch.float32), "R1": (7, torch.float32), "R2": (8, torch.float32)}
+            "R": (6, torch.float32), "G": (7, torch.float32)}
 
 
 def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
@@ -439,7 +439,7 @@ def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
     H, W = fn.pack.c.image_height, fn.pack.c.image_width
     T = ((W + 15) // 16) * ((H + 15) // 16)
     n = {"ranges": 2 * T, "pair_rank": holder.info(0), "n_contrib": H * W, "final_T": H * W, "order": P,
-         "off": P + 1, "R0": 4 * P, "R1": 4 * P, "R2": 4 * P}[name]
+         "off": P + 1, "R": 12 * P, "G": 12 * P}[name]
     dst = torch.empty(max(n, 1), dtype=dt, device=output.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(output.device).cuda_stream)
     if holder.lib.gsr_ctx_export(holder.handle, what, dst.data_ptr(), dst.numel() * 4, stream) != 0:

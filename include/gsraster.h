@@ -135,7 +135,7 @@ int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
 /* Copies one internal array of a context into a caller DEVICE buffer (tests / diagnostics):
  * what 0 = tile ranges [T][2] u32, 1 = sorted pair list (depth ranks) [N] u32, 2 = n_contrib [H*W] u32,
  * 3 = final_T [H*W] f32, 4 = order (rank -> Gaussian) [P] u32, 5 = off [P+1] u32,
- * 6/7/8 = depth-ordered splat records R0/R1/R2 [P] float4 (layout: csrc/gsr_kernels.hip.h). */
+ * 6 = depth-ordered splat records [P][3] float4, 7 = storage-ordered records (layout: csrc/gsr_kernels.hip.h). */
 int gsr_ctx_export(const GsrCtx* ctx, int32_t what, void* dst, int64_t dst_bytes, void* stream);
 
 /* Frees every cached workspace block of the current device (blocks in use by live contexts are kept). */
