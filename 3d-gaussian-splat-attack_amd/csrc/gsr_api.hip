@@ -286,7 +286,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const uint32_t tblP = radix_table_words((uint32_t)Pp);
   SlabPlan sp;
   sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey a/b, order b, tcnt
-  sp.add<uint32_t>(tblP); sp.add<uint32_t>(tblP / SCAN_CHUNK + 2);
+  sp.add<uint32_t>(tblP); sp.add<uint32_t>(RS_BINS);
   sp.add<uint32_t>(Pp / SCAN_CHUNK + 2);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
@@ -303,7 +303,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
   uint32_t* tcnt = ss.take<uint32_t>(Pp);
-  uint32_t* table = ss.take<uint32_t>(tblP); uint32_t* tsums = ss.take<uint32_t>(tblP / SCAN_CHUNK + 2);
+  uint32_t* table = ss.take<uint32_t>(tblP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS);
   uint32_t* psums = ss.take<uint32_t>(Pp / SCAN_CHUNK + 2);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -378,7 +378,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)N, st);
       if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", N));
     }
-    void* tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + tblN / SCAN_CHUNK + 4), st);
+    void* tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS), st);
     if (!tbl_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: sort table allocation failed"));
     uint32_t* tileA = static_cast<uint32_t*>(pairs_blk[0]); uint32_t* rankA = static_cast<uint32_t*>(pairs_blk[1]);
     uint32_t* tileB = static_cast<uint32_t*>(pairs_blk[2]); uint32_t* rankB = static_cast<uint32_t*>(pairs_blk[3]);
@@ -638,7 +638,7 @@ int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begi
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int dev = cur_dev();
   const uint32_t tbl = radix_table_words(n);
-  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)2 * n + tbl + tbl / SCAN_CHUNK + 8), st);
+  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)2 * n + tbl + RS_BINS), st);
   if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_test_sort_pairs: allocation failed");
   uint32_t* k1 = static_cast<uint32_t*>(blk);
   uint32_t* v1 = k1 + n;

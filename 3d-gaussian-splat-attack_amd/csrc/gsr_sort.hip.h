@@ -122,13 +122,34 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __res
   table[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];   // digit-major: one linear scan gives global bases
 }
 
-// table: exclusive-scanned [256][nb].  iota != 0: values are the element indices (first pass of an argsort).
+// One block per digit: exclusive scan of that digit's row of per-block counts, in place; the row total goes to
+// rowsum[digit].  (Replaces a generic three-launch scan of the whole table: the scatter kernel adds the digit bases
+// itself from the 256 row totals.)
+__global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restrict__ table, uint32_t nb,
+                                                              uint32_t* __restrict__ rowsum) {
+  __shared__ uint32_t tmp[4];
+  uint32_t* row = table + (size_t)blockIdx.x * nb;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += RS_THREADS) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = (i < nb) ? row[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan_256(v, tmp, total);
+    if (i < nb) row[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) rowsum[blockIdx.x] = carry;
+}
+
+// table: per-digit exclusive-scanned rows [256][nb] + rowsum[256] (k_radix_rowscan).  iota != 0: values are the
+// element indices (first pass of an argsort).
 __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out,
                                                               uint32_t* __restrict__ vals_out, uint32_t n, int shift,
                                                               uint32_t mask, const uint32_t* __restrict__ table,
-                                                              uint32_t nb, int iota) {
+                                                              const uint32_t* __restrict__ rowsum, uint32_t nb,
+                                                              int iota) {
   __shared__ uint32_t wcnt[RS_WAVES][RS_BINS];
   __shared__ uint32_t gbase[RS_BINS];
   __shared__ uint32_t tmp[4];
@@ -177,7 +198,9 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
     wcnt[1][tid] = ds + c0;
     wcnt[2][tid] = ds + c0 + c1;
     wcnt[3][tid] = ds + c0 + c1 + c2;
-    gbase[tid] = table[tid * nb + blockIdx.x] - ds;
+    uint32_t all;
+    const uint32_t dbase = block_excl_scan_256(rowsum[tid], tmp, all);   // elements with a smaller digit, globally
+    gbase[tid] = dbase + table[tid * nb + blockIdx.x] - ds;
   }
   __syncthreads();
 #pragma unroll
@@ -202,7 +225,7 @@ inline uint32_t radix_table_words(uint32_t n) { return RS_BINS * ((n + RS_CHUNK 
 
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong; returns 0 if the result is in (k0,v0), 1 if in
 // (k1,v1).  iota_first: the values of the first pass are the element indices (v0 is then never read).
-// table: radix_table_words(n) words; sums: ceil(table_words/4096) words.
+// table: radix_table_words(n) words; sums: at least 256 words.
 inline int radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint32_t n, int begin_bit,
                             int end_bit, bool iota_first, uint32_t* table, uint32_t* sums, hipStream_t st) {
   if (n == 0 || end_bit <= begin_bit) return 0;
@@ -217,9 +240,9 @@ inline int radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* 
     uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
     uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
     hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, bit, mask, table, nb);
-    scan_exclusive_u32(table, table, RS_BINS * nb, sums, nullptr, st);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask, table, nb,
-                       (iota_first && p == 0) ? 1 : 0);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_BINS), dim3(RS_THREADS), 0, st, table, nb, sums);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask, table, sums,
+                       nb, (iota_first && p == 0) ? 1 : 0);
     cur ^= 1;
     bit += w;
   }
