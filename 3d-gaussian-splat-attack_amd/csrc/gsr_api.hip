@@ -146,7 +146,7 @@ uint32_t* pinned_word(int dev) {
 // ---- per-stage profiling (process-wide: autograd runs backward on its own thread) ------------------
 struct ProfSpan { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
-bool g_prof = false;
+uint32_t g_prof = 0;   // bit i: stage i is timed
 std::vector<ProfSpan> g_spans;
 std::vector<hipEvent_t> g_free_events;
 float g_ms[GSR_STAGE_COUNT] = {0};
@@ -163,7 +163,7 @@ struct StageTimer {
   int stage; hipStream_t st; hipEvent_t a{}, b{}; bool on = false;
   StageTimer(int s, hipStream_t stream) : stage(s), st(stream) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    on = g_prof;
+    on = (g_prof >> stage) & 1u;
     if (on) { a = get_event_locked(); b = get_event_locked(); (void)hipEventRecord(a, st); }
   }
   ~StageTimer() {
@@ -656,7 +656,7 @@ int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begi
 
 void gsr_profile(int32_t enable) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof = enable != 0;
+  g_prof = (uint32_t)enable;
   for (ProfSpan& s : g_spans) { g_free_events.push_back(s.a); g_free_events.push_back(s.b); }
   g_spans.clear();
   for (int i = 0; i < GSR_STAGE_COUNT; ++i) { g_ms[i] = 0.f; g_calls[i] = 0; }

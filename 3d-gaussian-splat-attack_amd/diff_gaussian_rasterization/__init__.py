@@ -207,14 +207,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         pack = _SettingsPack(raster_settings, device)
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
-        objects = torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device)
+        # without object features the 16 object channels are identically zero: hand back a broadcast zero instead of
+        # writing 16*H*W floats per view
+        objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if shoc is not None
+                   else torch.zeros(1, 1, 1, dtype=torch.float32, device=device).expand(NUM_OBJECTS, H, W))
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             rc = lib.gsr_forward(ctypes.byref(pack.c), P, K, _ptr(m3), _ptr(shc), _ptr(shoc), _ptr(colc), _ptr(opc),
-                                 _ptr(scc), _ptr(roc), _ptr(covc), _ptr(color), _ptr(objects), _ptr(radii),
+                                 _ptr(scc), _ptr(roc), _ptr(covc), _ptr(color), _ptr(objects) if shoc is not None else None,
+                                 _ptr(radii),
                                  ctypes.byref(handle), ctypes.byref(nren), stream)
         if rc != 0:
             msg = _err(lib)
@@ -310,14 +314,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         pack = _SettingsPack(raster_settings, device)
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
-        objects = torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device)
+        objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if obj is not None
+                   else torch.zeros(1, 1, 1, dtype=torch.float32, device=device).expand(NUM_OBJECTS, H, W))
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
-                                     _ptr(ro), _ptr(color), _ptr(objects), _ptr(radii), ctypes.byref(handle),
+                                     _ptr(ro), _ptr(color), _ptr(objects) if obj is not None else None, _ptr(radii),
+                                     ctypes.byref(handle),
                                      ctypes.byref(nren), stream)
         if rc != 0:
             raise Exception(_err(lib)) if rc == 1 else RuntimeError(_err(lib))
@@ -447,8 +453,16 @@ def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
     return dst[:n]
 
 
-def profile(enable: bool) -> None:
-    _load().gsr_profile(1 if enable else 0)
+def profile(enable, stages=None) -> None:
+    """Start (and reset) / stop the library's per-stage HIP-event timing.  `stages`: iterable of names from
+    GSR_STAGES to time only those (each timed stage costs two event records per call)."""
+    if not enable:
+        mask = 0
+    elif stages is None:
+        mask = (1 << len(GSR_STAGES)) - 1
+    else:
+        mask = sum(1 << GSR_STAGES.index(s) for s in stages)
+    _load().gsr_profile(mask)
 
 
 def profile_read() -> dict:

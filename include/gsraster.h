@@ -155,7 +155,9 @@ enum {
   GSR_STAGE_PREPROCESS_BWD = 6,
   GSR_STAGE_COUNT = 7
 };
-void gsr_profile(int32_t enable);
+/* gsr_profile(mask): bit i of mask times stage i (0x7F = all stages, 0 = off; also resets the accumulators).  Each
+ * timed stage costs two event records on the stream (a few microseconds of queue time each). */
+void gsr_profile(int32_t stage_mask);
 int gsr_profile_read(float* ms, int64_t* calls);
 
 const char* gsr_last_error(void);
