@@ -129,18 +129,26 @@ struct SlabPlan {
   void add(size_t n) { bytes = ((bytes + 255) & ~size_t(255)) + n * sizeof(T); }
 };
 
-// pinned host word for the one D2H read per forward
-uint32_t* g_pinned[MAX_DEV] = {nullptr};
-std::mutex g_pinned_mu;
+// pinned host word + event for the one D2H read per forward (per calling thread and device)
+thread_local uint32_t* t_pinned[MAX_DEV] = {nullptr};
+thread_local hipEvent_t t_count_event[MAX_DEV] = {nullptr};
 
 uint32_t* pinned_word(int dev) {
-  std::lock_guard<std::mutex> lk(g_pinned_mu);
-  if (!g_pinned[dev]) {
+  if (!t_pinned[dev]) {
     void* p = nullptr;
     if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
-    g_pinned[dev] = static_cast<uint32_t*>(p);
+    t_pinned[dev] = static_cast<uint32_t*>(p);
   }
-  return g_pinned[dev];
+  return t_pinned[dev];
+}
+
+hipEvent_t count_event(int dev) {
+  if (!t_count_event[dev]) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    t_count_event[dev] = e;
+  }
+  return t_count_event[dev];
 }
 
 // ---- per-stage profiling (process-wide: autograd runs backward on its own thread) ------------------
@@ -344,6 +352,14 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st);
       F_LAUNCH("preprocess");
     }
+    // The total of that scan IS the pair count N the host needs to size the sort buffers.  Start its read-back
+    // now and wait for it only after the depth sort / gather / scan below are enqueued: the GPU keeps working
+    // while the host learns N, instead of idling through a stream synchronise later.
+    uint32_t* pinned = pinned_word(dev);
+    hipEvent_t n_ready = count_event(dev);
+    if (!pinned || !n_ready) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host word / event allocation failed"));
+    F_TRY("read pair count", hipMemcpyAsync(pinned, c->offg + P, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    F_TRY("read pair count", hipEventRecord(n_ready, st));
     uint32_t* skey;
     {
       StageTimer t(GSR_STAGE_DEPTH_SORT, st);
@@ -360,10 +376,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       hipLaunchKernelGGL(k_pack, gridP, blk, 0, st, P, c->order, skey, G0, G1, G2, c->R0, c->R1, c->R2, cnt);
       scan_exclusive_u32(cnt, c->off, (uint32_t)P, psums, c->off + P, st);
       F_LAUNCH("pack/scan");
-      uint32_t* pinned = pinned_word(dev);
-      if (!pinned) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host allocation failed"));
-      F_TRY("read pair count", hipMemcpyAsync(pinned, c->off + P, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      F_TRY("read pair count", hipStreamSynchronize(st));
+      F_TRY("read pair count", hipEventSynchronize(n_ready));
       N = *pinned;
     }
   } else {
