@@ -189,6 +189,19 @@ def main():
         if dom == DOMINANT:
             dom_ms = round(dom_ms_timed, 4)      # the duration measured inside the timed region itself
         achieved = sb[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes of the dominant kernel from the committed PMC passes (profiles/collect_r01.sh: FETCH_SIZE and
+        # WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only when they
+        # were taken on this very workload
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            kern = {"render_bwd": "void gsr::k_render_bwd<false>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
+                    "preprocess_bwd": "void gsr::k_preprocess_bwd<true, true>",
+                    "preprocess": "void gsr::k_preprocess<true, true>"}.get(dom)
+            if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
+                traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
+        except Exception:
+            traffic = None
         B_total = 304 * P + 548 * V + 116 * N + 40 * HW
         t_view = elapsed / args.steps
         result = {
@@ -211,7 +224,7 @@ def main():
                        "parallelism": f"views sharded 1/GPU, dp{world}"
                                       + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
                          "note": "K6/K7 are fp32-VALU/exp bound (256*N alpha evaluations), not HBM bound; "
                                  "HBM is the reporting roofline BASELINE.md section 3 prescribes"},
