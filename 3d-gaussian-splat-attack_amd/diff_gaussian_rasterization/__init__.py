@@ -352,15 +352,24 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
         def out(cond, *shape):
             return torch.empty(*shape, dtype=torch.float32, device=device) if cond else None
-        d_x = out(need[0], P, 3)
-        d_m2 = out(need[1], P, 3)
         want_sh = need[2] or need[3]
-        d_dc = out(want_sh, P, 1, 3)
-        d_rest = out(want_sh, P, 15, 3)
+        if need[0] and want_sh and need[5] and need[6] and need[7]:
+            # All 59 attack-relevant floats per Gaussian are wanted (the normal case): carve them out of ONE flat
+            # buffer, in the order xyz | f_dc | f_rest | opacity | scaling | rotation.  autograd hands these views to
+            # .grad as they are, so a data-parallel caller can sum the whole gradient with a single collective
+            # (gsplat_attack.dist.allreduce_attribute_grads) instead of one per tensor.
+            flat = torch.empty(59 * P, dtype=torch.float32, device=device)
+            cuts = [0, 3 * P, 6 * P, 51 * P, 52 * P, 55 * P, 59 * P]
+            d_x, d_dc, d_rest, d_op, d_sc, d_ro = (flat[cuts[i]:cuts[i + 1]] for i in range(6))
+        else:
+            d_x = out(need[0], P, 3)
+            d_dc = out(want_sh, P, 1, 3)
+            d_rest = out(want_sh, P, 15, 3)
+            d_op = out(need[5], P)
+            d_sc = out(need[6], P, 3)
+            d_ro = out(need[7], P, 4)
+        d_m2 = out(need[1], P, 3)
         d_obj = out(need[4] and obj is not None, P, NUM_OBJECTS)
-        d_op = out(need[5], P)
-        d_sc = out(need[6], P, 3)
-        d_ro = out(need[7], P, 4)
         if P > 0:
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -27,7 +27,18 @@ def _view_grads(model, view: int):
     return {n: torch.randn(getattr(model, n).shape, generator=g) for n in gdist.ATTACK_PARAMS}
 
 
-def _worker(rank, world, port, n_views, out_dir):
+def _as_flat_bucket(model):
+    """Re-home the gradients as slices of one buffer, like the fused backward does."""
+    names = gdist.ATTACK_PARAMS
+    flat = torch.cat([getattr(model, n).grad.reshape(-1) for n in names])
+    pos = 0
+    for n in names:
+        p = getattr(model, n)
+        p.grad = flat[pos:pos + p.numel()].view(p.shape)
+        pos += p.numel()
+
+
+def _worker(rank, world, port, n_views, out_dir, flat=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     r, w, _ = gdist.init_from_env("gloo")
@@ -40,6 +51,9 @@ def _worker(rank, world, port, n_views, out_dir):
             for n, gr in _view_grads(model, v + 10 * step).items():
                 p = getattr(model, n)
                 p.grad = gr if p.grad is None else p.grad + gr
+        if flat:
+            _as_flat_bucket(model)
+            assert gdist._flat_view_of([getattr(model, n).grad for n in gdist.ATTACK_PARAMS]) is not None
         nbytes = gdist.allreduce_attribute_grads(model)
         assert nbytes == sum(getattr(model, n).numel() * 4 for n in gdist.ATTACK_PARAMS)
         pgd.gaussian_color_l2_attack(model, 0.5, 5.0, orig["_features_rest"], orig["_features_dc"])
@@ -50,10 +64,10 @@ def _worker(rank, world, port, n_views, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views", [2, 5])
-def test_allreduce_equals_single_process_sum(tmp_path, n_views):
+@pytest.mark.parametrize("n_views,flat", [(2, False), (5, False), (3, True)])
+def test_allreduce_equals_single_process_sum(tmp_path, n_views, flat):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, n_views, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n_views, str(tmp_path), flat), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     for k in r0:
@@ -84,3 +98,19 @@ def test_view_partition_covers_batch_once():
 def test_single_process_allreduce_is_a_noop():
     model, _, _ = make_scene("hydrant-1k", P=50, n_views=1)
     assert gdist.allreduce_attribute_grads(model) == 0
+
+
+def test_flat_bucket_detection():
+    """Gradients carved out of one buffer are recognised (=> one collective); separate tensors are not."""
+    P = 7
+    flat = torch.arange(59 * P, dtype=torch.float32)
+    cuts = [0, 3 * P, 6 * P, 51 * P, 52 * P, 55 * P, 59 * P]
+    views = [flat[cuts[i]:cuts[i + 1]] for i in range(6)]
+    shaped = [views[0].view(P, 3), views[1].view(P, 1, 3), views[2].view(P, 15, 3), views[3].view(P, 1),
+              views[4].view(P, 3), views[5].view(P, 4)]
+    got = gdist._flat_view_of(shaped)
+    assert got is not None and got.numel() == 59 * P and got.data_ptr() == flat.data_ptr()
+    got.mul_(2.0)
+    assert float(shaped[5][-1, -1]) == 2.0 * (59 * P - 1)
+    assert gdist._flat_view_of([torch.zeros(3), torch.zeros(3)]) is None
+    assert gdist._flat_view_of([flat[0:3], flat[4:8]]) is None            # a hole

@@ -59,3 +59,17 @@ def test_batch_gradient_is_the_sum_of_view_gradients():
             continue
         ref = per_view[0][n] + per_view[1][n] + per_view[2][n]
         assert torch.allclose(p.grad, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max())), n
+
+
+def test_fused_backward_hands_out_one_flat_gradient_bucket():
+    """After render()+backward() on the fused path the six attack gradients are back-to-back slices of one
+    buffer of 59 floats per Gaussian: the data-parallel step sums them with a single collective."""
+    from gsplat_attack import dist as gdist
+    from gsplat_attack.renderer import PipelineParams, render
+    model, cams, _ = _scene(n_views=2)
+    for cam in cams:                       # two views accumulate into the same bucket
+        render(cam, model, PipelineParams(skip_objects=True), torch.zeros(3, device="cuda"))["render"].sum().backward()
+    grads = [getattr(model, n).grad for n in gdist.ATTACK_PARAMS]
+    flat = gdist._flat_view_of(grads)
+    assert flat is not None and flat.numel() == 59 * model.get_xyz.shape[0]
+    assert flat.data_ptr() == model._xyz.grad.data_ptr()
