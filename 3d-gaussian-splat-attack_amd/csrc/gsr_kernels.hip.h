@@ -724,12 +724,55 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
   const int K = a.K;
   float4* wrow = SH_LDS ? &srow[wave * 64 * SHROW_F4] : nullptr;
   const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
+  uint32_t o0 = 0, o1 = 0;
+  if (g < a.P) { o0 = a.offg[g]; o1 = a.offg[g + 1]; }
+  // ---- sum this Gaussian's partial rows ---------------------------------------------------------------------
+  // The rows of the wave's 64 Gaussians are one contiguous span: copy it through LDS in chunks of 256 rows with
+  // coalesced float4 loads (48-byte rows read back with ds_read_b128 are bank-conflict free) instead of 64 lanes
+  // each walking their own rows in HBM.  A Gaussian with more than 256 rows is summed by the whole wave.
+  float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+  if (SH_LDS && nw > 0) {
+    const uint32_t S = a.offg[gw0], E = a.offg[gw0 + nw];
+    const bool big = (o1 - o0) > 256u;
+    for (uint32_t c0 = S; c0 < E; c0 += 256u) {
+      const uint32_t rows = min(256u, E - c0);
+      const float4* src = a.part + (size_t)c0 * PART_F4;
+      for (uint32_t i = lane; i < rows * PART_F4; i += 64) wrow[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (!big) {
+        const uint32_t lo = max(o0, c0), hi = min(o1, c0 + rows);
+        for (uint32_t e = lo; e < hi; ++e) {
+          const float4* r = &wrow[(e - c0) * PART_F4];
+          const float4 p0 = r[0], p1 = r[1], p2 = r[2];
+          mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint64_t bm = __ballot(big);
+    while (bm) {
+      const int L = __ffsll((unsigned long long)bm) - 1;
+      bm &= bm - 1;
+      const uint32_t b0 = __shfl(o0, L, 64), b1 = __shfl(o1, L, 64);
+      float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (uint32_t e = b0 + lane; e < b1; e += 64) {
+        const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+        t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w; t[4] += p1.x; t[5] += p1.y; t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) t[i] = __shfl(wave_sum_to_hi(t[i]), 63, 64);
+      if (lane == L) { mx = t[0]; my = t[1]; mxx = t[2]; mxy = t[3]; myy = t[4]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
+    }
+  }
   if (SH_LDS && nw > 0) stage_sh_rows<RAW>(wrow, a.sh, a.sh_dc, gw0, nw, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (g < a.P) {
-    const uint32_t o0 = a.offg[g], o1 = a.offg[g + 1];
     float* my_sh = SH_LDS ? reinterpret_cast<float*>(&wrow[lane * SHROW_F4]) : nullptr;
     if (o1 == o0) {   // culled: zero gradients
       if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
@@ -745,10 +788,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
       if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
     } else {
-      float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-      for (uint32_t e = o0; e < o1; ++e) {
-        const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
-        mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+      if (!SH_LDS) {
+        for (uint32_t e = o0; e < o1; ++e) {
+          const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+          mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+        }
       }
       if (a.dsh_objs) {
         float acc[NUM_OBJ];
