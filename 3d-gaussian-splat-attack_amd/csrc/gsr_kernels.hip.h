@@ -55,24 +55,28 @@ constexpr int SHROW_F4 = 13;   // 12 float4 of payload (K = 16) + 1 pad
 // reference model's two tensors, _features_dc [P,1,3] and _features_rest [P,15,3] (what get_features concatenates,
 // reference scene/gaussian_model.py:113-116).
 template <bool RAW>
-__device__ __forceinline__ void stage_sh_rows(float4* wrow, const float* sh, const float* sh_dc, int gw0, int nw, int lane) {
+__device__ __forceinline__ void stage_sh_rows(float4* wrow, const float* sh, const float* sh_dc, int gw0, int nw, int lane,
+                                              uint64_t rowmask) {
+  // rowmask: bit r set = row r is needed (culled Gaussians' coefficients are never read from HBM)
   if (!RAW) {
     const float4* src = reinterpret_cast<const float4*>(sh) + (size_t)gw0 * 12;
     for (int i = lane; i < nw * 12; i += 64) {
       const int row = i / 12;
-      wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
+      if ((rowmask >> row) & 1ull) wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
     }
   } else {
     float* wf = reinterpret_cast<float*>(wrow);
     const float* dc = sh_dc + (size_t)gw0 * 3;
     for (int i = lane; i < nw * 3; i += 64) {
       const int row = i / 3;
-      wf[row * (4 * SHROW_F4) + (i - row * 3)] = dc[i];
+      if ((rowmask >> row) & 1ull) wf[row * (4 * SHROW_F4) + (i - row * 3)] = dc[i];
     }
     const float* rest = sh + (size_t)gw0 * 45;          // 64*45*4 B per wave: 16-byte aligned
     const int n4 = (nw * 45) >> 2;
     const float4* rest4 = reinterpret_cast<const float4*>(rest);
     for (int i = lane; i < n4; i += 64) {
+      const int ra = (4 * i) / 45, rb = (4 * i + 3) / 45;
+      if (!(((rowmask >> ra) | (rowmask >> rb)) & 1ull)) continue;
       const float4 v = rest4[i];
       const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -105,8 +109,10 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
   const int gw0 = blockIdx.x * 256 + wave * 64;
   const int g = gw0 + lane;
   if (SH_LDS) {
+    // all 64 rows are fetched up front (before the culls are known): issuing the big coalesced loads first and
+    // projecting while they are in flight measured faster than fetching only the survivors' rows afterwards
     const int nw = min(64, P - gw0);
-    if (nw > 0) stage_sh_rows<RAW>(&srow[wave * 64 * SHROW_F4], sh, sh_dc, gw0, nw, lane);
+    if (nw > 0 && colors == nullptr) stage_sh_rows<RAW>(&srow[wave * 64 * SHROW_F4], sh, sh_dc, gw0, nw, lane, ~0ull);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -120,15 +126,15 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
 #pragma unroll
     for (int i = 0; i < 6; ++i) c6[i] = cov3d[6 * g + i];
   } else {
-    float s[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
     const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
     float q[4] = {q4.x, q4.y, q4.z, q4.w};
     if (RAW) {
-      s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+      sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
       float inv_n;
       act_normalize4(q, q, inv_n);
     }
-    cov3d_from_scale_rot(s, va.mod, q, c6);
+    cov3d_from_scale_rot(sc, va.mod, q, c6);
   }
   Splat s;
   const bool ok = project_splat(v, p, c6, s);
@@ -516,6 +522,7 @@ struct RenderBwdArgs {
   const float* grad_objects;  // [16,H,W] or null
   float4* part;               // [N][3]
   float4* part_obj;           // [N][4] or null
+  uint32_t tag_lo, tag_hi;    // stamped into every row written by this call
 };
 
 constexpr int PART_F4 = 3;
@@ -659,7 +666,11 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         if ((lane & 15) == 0) {
           const int k = lane >> 4;
           float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[j] * PART_F4) + 2 * (k & 1) + (k >> 1);
-          row[0] = r0; row[4] = r1; row[8] = r2;
+          // row words 9 and 10 (written by rows 2 and 1 of the wave) carry this backward call's 64-bit tag: rows
+          // that no wave writes keep whatever the workspace held and are recognised as stale by K8/K9, so the
+          // partial-row buffer never has to be cleared
+          const float r2w = k == 2 ? __uint_as_float(a.tag_lo) : (k == 1 ? __uint_as_float(a.tag_hi) : r2);
+          row[0] = r0; row[4] = r1; row[8] = r2w;
         }
         if (OBJ) {
 #pragma unroll
@@ -694,6 +705,7 @@ struct PreBwdArgs {
   const float4* G2;
   const float4* part;
   const float4* part_obj;
+  uint32_t tag_lo, tag_hi;   // rows whose words 9,10 differ are stale (not written by this backward)
   const float* means;
   const float* scales;
   const float* rots;
@@ -746,6 +758,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
         for (uint32_t e = lo; e < hi; ++e) {
           const float4* r = &wrow[(e - c0) * PART_F4];
           const float4 p0 = r[0], p1 = r[1], p2 = r[2];
+          if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
           mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
         }
       }
@@ -761,6 +774,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (uint32_t e = b0 + lane; e < b1; e += 64) {
         const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+        if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
         t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w; t[4] += p1.x; t[5] += p1.y; t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
       }
 #pragma unroll
@@ -768,7 +782,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       if (lane == L) { mx = t[0]; my = t[1]; mxx = t[2]; mxy = t[3]; myy = t[4]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
     }
   }
-  if (SH_LDS && nw > 0) stage_sh_rows<RAW>(wrow, a.sh, a.sh_dc, gw0, nw, lane);
+  {
+    const uint64_t need = __ballot(o1 > o0);            // culled Gaussians: coefficients not needed, gradient = 0
+    if (SH_LDS && nw > 0 && need) stage_sh_rows<RAW>(wrow, a.sh, a.sh_dc, gw0, nw, lane, need);
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -791,6 +808,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
       if (!SH_LDS) {
         for (uint32_t e = o0; e < o1; ++e) {
           const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+          if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
           mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
         }
       }
@@ -800,6 +818,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
         for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
         if (a.part_obj) {
           for (uint32_t e = o0; e < o1; ++e) {
+            const float4 tg = a.part[(size_t)e * PART_F4 + 2];
+            if (__float_as_uint(tg.y) != a.tag_lo || __float_as_uint(tg.z) != a.tag_hi) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float4 v = a.part_obj[(size_t)e * 4 + q];
