@@ -66,6 +66,39 @@ class GaussianModel:
         for p in self.parameters():
             p.grad = None
 
+    _PARAM_ATTRS = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_objects_dc")
+
+    # ---- scene surgery used by the attack set-up (scene/gaussian_model.py:216-262) ------------------------------
+    def removal_setup(self, mask3d: torch.Tensor) -> None:
+        """Keep the Gaussians NOT selected by mask3d (reference :216-241).  As in the reference the survivors are
+        re-wrapped in nn.Parameter, whose default requires_grad=True wins."""
+        keep = ~mask3d.bool().reshape(-1)
+        for n in self._PARAM_ATTRS:
+            setattr(self, n, nn.Parameter(getattr(self, n)[keep].detach().clone()))
+
+    def concat_setup(self, feature_name: str, tensor_to_concat: torch.Tensor, requires_grad: bool) -> None:
+        """Append rows to one attribute and re-wrap it (reference :243-262)."""
+        cur = getattr(self, f"_{feature_name}")
+        cat = torch.cat((cur, tensor_to_concat.to(cur.device)), dim=0).detach().clone().requires_grad_(requires_grad)
+        setattr(self, f"_{feature_name}", nn.Parameter(cat, requires_grad=requires_grad))
+
+    def clone(self) -> "GaussianModel":
+        m = GaussianModel(self.max_sh_degree)
+        m.active_sh_degree = self.active_sh_degree
+        for n in self._PARAM_ATTRS:
+            p = getattr(self, n)
+            setattr(m, n, nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad))
+        return m
+
+    def save_ply(self, path: str) -> None:
+        from .ply import save_gaussians
+        save_gaussians(self, path)
+
+    @classmethod
+    def load_ply(cls, path: str, sh_degree: int = 3, device=None) -> "GaussianModel":
+        from .ply import load_gaussians
+        return load_gaussians(path, sh_degree, device)
+
     # ---- getters (scene/gaussian_model.py:97-124) ---------------------
     @property
     def get_scaling(self):
