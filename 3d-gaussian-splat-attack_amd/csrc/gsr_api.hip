@@ -210,6 +210,7 @@ struct GsrCtx {
   uint2* ranges = nullptr;
   float* final_T = nullptr;
   uint32_t* n_contrib = nullptr;
+  unsigned long long* total64 = nullptr;   // exact (64-bit) number of pairs of the tile rects
 };
 
 static ViewArgs view_args(const GsrSettings& s) {
@@ -219,6 +220,8 @@ static ViewArgs view_args(const GsrSettings& s) {
   va.tanfovx = s.tanfovx; va.tanfovy = s.tanfovy; va.mod = s.scale_modifier; va.deg = s.sh_degree;
   return va;
 }
+
+constexpr unsigned long long MAX_PAIRS = 1ull << 31;   // 32-bit pair numbering with head-room
 
 static int ceil_log2(uint32_t v) {
   int b = 0;
@@ -288,7 +291,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   kp.add<float4>(3 * Pp);   // R records (depth order)
   kp.add<float4>(3 * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
-  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW);
+  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<unsigned long long>(2);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
@@ -296,7 +299,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   SlabPlan sp;
   sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey a/b, order b, tcnt
   sp.add<uint32_t>(tblP); sp.add<uint32_t>(RS_BINS);
-  sp.add<uint32_t>(Pp / SCAN_CHUNK + 2);
+  sp.add<uint32_t>(Pp / SCAN_CHUNK + 2); sp.add<unsigned long long>(Pp / SCAN_CHUNK + 2);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
     pool_free(dev, scratch_blk);
@@ -308,12 +311,14 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->G0 = ks.take<float4>(3 * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;
   c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
+  c->total64 = ks.take<unsigned long long>(2);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
   uint32_t* tcnt = ss.take<uint32_t>(Pp);
   uint32_t* table = ss.take<uint32_t>(tblP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS);
   uint32_t* psums = ss.take<uint32_t>(Pp / SCAN_CHUNK + 2);
+  unsigned long long* psums64 = ss.take<unsigned long long>(Pp / SCAN_CHUNK + 2);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
   auto fail = [&](int code) {
@@ -350,7 +355,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         hipLaunchKernelGGL((k_preprocess<false, false>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
                            cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
-      scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st);
+      scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st, psums64, c->total64);
       F_LAUNCH("preprocess");
     }
     // The total of that scan IS the pair count N the host needs to size the sort buffers.  Start its read-back
@@ -360,6 +365,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     hipEvent_t n_ready = count_event(dev);
     if (!pinned || !n_ready) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host word / event allocation failed"));
     F_TRY("read pair count", hipMemcpyAsync(pinned, c->offg + P, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    F_TRY("read pair count", hipMemcpyAsync(pinned + 2, c->total64, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     F_TRY("read pair count", hipEventRecord(n_ready, st));
     uint32_t* skey;
     {
@@ -379,6 +385,11 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       F_LAUNCH("pack/scan");
       F_TRY("read pair count", hipEventSynchronize(n_ready));
       N = *pinned;
+      unsigned long long exact = 0;
+      memcpy(&exact, pinned + 2, sizeof(exact));
+      if (exact != (unsigned long long)N || exact > MAX_PAIRS)
+        return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: %llu (tile, Gaussian) pairs exceed the supported %llu "
+                            "(splats cover too many tiles: check scales / scale_modifier)", exact, MAX_PAIRS));
     }
   } else {
     F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));

@@ -117,51 +117,56 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (g >= P) return;
-  View v;
-  load_view(v, va);
-  const float p[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
-  float c6[6];
-  if (cov3d) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) c6[i] = cov3d[6 * g + i];
-  } else {
-    float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
-    const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
-    float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    if (RAW) {
-      sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
-      float inv_n;
-      act_normalize4(q, q, inv_n);
+  const auto one = [&]() -> uint32_t {
+    if (g >= P) return 0u;
+    View v;
+    load_view(v, va);
+    const float p[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+    float c6[6];
+    if (cov3d) {
+  #pragma unroll
+      for (int i = 0; i < 6; ++i) c6[i] = cov3d[6 * g + i];
+    } else {
+      float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+      const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
+      float q[4] = {q4.x, q4.y, q4.z, q4.w};
+      if (RAW) {
+        sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+        float inv_n;
+        act_normalize4(q, q, inv_n);
+      }
+      cov3d_from_scale_rot(sc, va.mod, q, c6);
     }
-    cov3d_from_scale_rot(sc, va.mod, q, c6);
-  }
-  Splat s;
-  const bool ok = project_splat(v, p, c6, s);
-  if (!ok) {
-    radii[g] = 0;
-    dkey[g] = 0xFFFFFFFFu;
-    tcnt[g] = 0;
-    G2[REC * g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
-    return;
-  }
-  float rgb[3];
-  uint32_t cl = 0;
-  if (colors) {
-    rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2];
-  } else if (SH_LDS) {
-    cl = sh_to_rgb(va.deg, reinterpret_cast<const float*>(&srow[(wave * 64 + lane) * SHROW_F4]), p, v.cam, rgb);
-  } else {
-    cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
-  }
-  radii[g] = s.radius;
-  dkey[g] = __float_as_uint(s.depth);
-  tcnt[g] = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
-  const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
-  const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
-  G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
-  G1[REC * g] = make_float4(s.C, RAW ? act_sigmoid(opac[g]) : opac[g], rgb[0], rgb[1]);
+    Splat s;
+    const bool ok = project_splat(v, p, c6, s);
+    if (!ok) {
+      radii[g] = 0;
+      dkey[g] = 0xFFFFFFFFu;
+      tcnt[g] = 0;
+      G2[REC * g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
+      return 0u;
+    }
+    float rgb[3];
+    uint32_t cl = 0;
+    if (colors) {
+      rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2];
+    } else if (SH_LDS) {
+      cl = sh_to_rgb(va.deg, reinterpret_cast<const float*>(&srow[(wave * 64 + lane) * SHROW_F4]), p, v.cam, rgb);
+    } else {
+      cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
+    }
+    radii[g] = s.radius;
+    dkey[g] = __float_as_uint(s.depth);
+    const uint32_t cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
+    tcnt[g] = cnt;
+    const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
+    const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
+    G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
+    G1[REC * g] = make_float4(s.C, RAW ? act_sigmoid(opac[g]) : opac[g], rgb[0], rgb[1]);
   G2[REC * g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
+    return cnt;
+  };
+  (void)one();
 }
 
 // K10

@@ -42,32 +42,61 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* tm
 }
 
 // ---- exclusive scan over n u32 (three launches; the middle one is a single block) ----------------
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial(const uint32_t* __restrict__ in, uint32_t n,
-                                                               uint32_t* __restrict__ sums) {
-  __shared__ uint32_t tmp[4];
-  const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
-  uint32_t s = 0;
+// The prefix sums are 32-bit (they number at most 2^31 pairs); next to them the exact 64-bit total is accumulated so
+// that the host can tell a wrapped scan from a valid one.
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* tmp64) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i) s += (base + i < n) ? in[base + i] : 0u;
-  uint32_t total;
-  block_excl_scan_256(s, tmp, total);
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  if (lane == 0) tmp64[w] = v;
+  __syncthreads();
+  const unsigned long long t = tmp64[0] + tmp64[1] + tmp64[2] + tmp64[3];
+  __syncthreads();
+  return t;
 }
 
-// in-place exclusive scan of sums[nb] by one block; total -> *total_out (may be null)
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict__ sums, uint32_t nb,
-                                                            uint32_t* __restrict__ total_out) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial(const uint32_t* __restrict__ in, uint32_t n,
+                                                               uint32_t* __restrict__ sums,
+                                                               unsigned long long* __restrict__ sums64) {
   __shared__ uint32_t tmp[4];
+  __shared__ unsigned long long tmp64[4];
+  const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+  unsigned long long s64 = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    const uint32_t v = (base + i < n) ? in[base + i] : 0u;
+    s += v; s64 += v;
+  }
+  uint32_t total;
+  block_excl_scan_256(s, tmp, total);
+  const unsigned long long t64 = block_sum_u64(s64, tmp64);
+  if (threadIdx.x == 0) { sums[blockIdx.x] = total; if (sums64) sums64[blockIdx.x] = t64; }
+}
+
+// in-place exclusive scan of sums[nb] by one block; total -> *total_out (may be null); exact total -> *total64_out
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict__ sums, uint32_t nb,
+                                                            uint32_t* __restrict__ total_out,
+                                                            const unsigned long long* __restrict__ sums64,
+                                                            unsigned long long* __restrict__ total64_out) {
+  __shared__ uint32_t tmp[4];
+  __shared__ unsigned long long tmp64[4];
   uint32_t carry = 0;
+  unsigned long long acc64 = 0;
   for (uint32_t base = 0; base < nb; base += SCAN_THREADS) {
     const uint32_t i = base + threadIdx.x;
     const uint32_t v = (i < nb) ? sums[i] : 0u;
+    if (sums64 && i < nb) acc64 += sums64[i];
     uint32_t total;
     const uint32_t ex = block_excl_scan_256(v, tmp, total);
     if (i < nb) sums[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
+  const unsigned long long t64 = block_sum_u64(acc64, tmp64);
+  if (threadIdx.x == 0) {
+    if (total_out) *total_out = carry;
+    if (total64_out) *total64_out = t64;
+  }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* in, uint32_t* out,
@@ -87,16 +116,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* in,
   }
 }
 
-// out may alias in.  sums must hold ceil(n/4096) words.  total_out (device) receives the grand total.
+// out may alias in.  sums must hold ceil(n/4096) words (and sums64 as many 64-bit words when total64_out is wanted).
+// total_out (device) receives the grand total modulo 2^32, total64_out the exact one.
 inline void scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* sums, uint32_t* total_out,
-                               hipStream_t st) {
+                               hipStream_t st, unsigned long long* sums64 = nullptr,
+                               unsigned long long* total64_out = nullptr) {
   if (n == 0) {
     if (total_out) (void)hipMemsetAsync(total_out, 0, sizeof(uint32_t), st);
+    if (total64_out) (void)hipMemsetAsync(total64_out, 0, sizeof(unsigned long long), st);
     return;
   }
   const uint32_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-  hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb, total_out);
+  hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums, total64_out ? sums64 : nullptr);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb, total_out,
+                     total64_out ? (const unsigned long long*)sums64 : nullptr, total64_out);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, sums);
 }
 

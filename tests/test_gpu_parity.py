@@ -290,3 +290,24 @@ def test_render_counterpart_against_oracle_through_raw_parameters():
             continue
         rel = ((p.grad.detach().cpu().double() - q.grad).abs().max() / q.grad.abs().max()).item()
         assert rel <= GRAD_TOL, (name, rel)
+
+
+def test_pair_count_overflow_is_reported_not_wrapped():
+    """100k screen-filling splats at 4K touch 3.2e9 tiles: the 32-bit pair numbering would wrap; the library must
+    notice through its exact 64-bit count and refuse, not corrupt memory."""
+    D = _hip()
+    from gsplat_attack.cameras import look_at_camera
+    dev = torch.device("cuda:0")
+    cam = look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), fovx=0.9, width=3840, height=2160, device=dev)
+    st = settings_for(cam, torch.zeros(3), cls=D.GaussianRasterizationSettings, device=dev)
+    P = 100_000
+    g = torch.Generator().manual_seed(0)
+    means = (torch.randn(P, 3, generator=g) * 0.05).to(dev)
+    rast = D.GaussianRasterizer(raster_settings=st)
+    with pytest.raises(RuntimeError, match="pairs exceed"):
+        rast(means3D=means, means2D=torch.zeros(P, 3, device=dev), opacities=torch.full((P, 1), 0.5, device=dev),
+             shs=torch.zeros(P, 16, 3, device=dev), scales=torch.full((P, 3), 50.0, device=dev),
+             rotations=torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(P, 1))
+    # and the library still works afterwards
+    model, cams, _ = _scene(n_views=1)
+    check(model_inputs(model), cams[0], torch.zeros(3))
