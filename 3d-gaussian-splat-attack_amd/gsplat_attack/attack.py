@@ -102,6 +102,26 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
     return history
 
 
+def combine_with_background(attacked, background):
+    """The scene the reference evaluates after every step: the attacked target Gaussians followed by the frozen
+    background (reference attack.py:513-520: deepcopy + seven concat_setup calls).  Here: one concatenation per
+    attribute into a fresh model, no deep copy of the attacked one."""
+    from .gaussian_model import GaussianModel
+    cat = {k: torch.cat((a.detach(), b.detach().to(a.device)), dim=0)
+           for k, a, b in ((n, getattr(attacked, n), getattr(background, n)) for n in GaussianModel._PARAM_ATTRS)}
+    return GaussianModel.from_tensors(cat["_xyz"], cat["_features_dc"], cat["_features_rest"], cat["_scaling"],
+                                      cat["_rotation"], cat["_opacity"], cat["_objects_dc"],
+                                      sh_degree=attacked.max_sh_degree, device=cat["_xyz"].device, requires_grad=False)
+
+
+@torch.no_grad()
+def render_combined(attacked, background, cameras: Sequence, bg: torch.Tensor, pipe: Optional[PipelineParams] = None):
+    """Forward-only renders of target + background for the success check (reference attack.py:522-530)."""
+    pipe = pipe or PipelineParams(skip_objects=True)
+    scene = combine_with_background(attacked, background)
+    return [render(cam, scene, pipe, bg)["render"] for cam in cameras]
+
+
 def main():
     ap = argparse.ArgumentParser(description="PGD over Gaussian attributes with a surrogate detector (synthetic scenes)")
     ap.add_argument("--scene", default="nyc-1M")

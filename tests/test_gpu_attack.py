@@ -73,3 +73,28 @@ def test_fused_backward_hands_out_one_flat_gradient_bucket():
     flat = gdist._flat_view_of(grads)
     assert flat is not None and flat.numel() == 59 * model.get_xyz.shape[0]
     assert flat.data_ptr() == model._xyz.grad.data_ptr()
+
+
+def test_combined_scene_render_equals_render_of_the_concatenated_attributes():
+    """target + frozen background (reference attack.py:513-530): splitting a scene in two and re-combining it must
+    reproduce the render of the whole scene bit for bit (pairs only depend on the multiset of splats and their order)."""
+    from gsplat_attack.attack import render_combined
+    from gsplat_attack.renderer import PipelineParams, render
+    model, cams, _ = _scene(n_views=1)
+    P = model.get_xyz.shape[0]
+    mask = torch.zeros(P, dtype=torch.bool, device="cuda")
+    mask[: P // 3] = True
+    target, background = model.clone(), model.clone()
+    background.removal_setup(~mask)            # keeps the first third ...
+    target.removal_setup(mask)                 # ... and the rest
+    bg = torch.tensor([0.0, 0.1, 0.2], device="cuda")
+    whole = model.clone()
+    whole.removal_setup(torch.zeros(P, dtype=torch.bool, device="cuda"))
+    # same storage order as the combination: target rows first, background rows after
+    order = torch.cat([torch.nonzero(~mask).flatten(), torch.nonzero(mask).flatten()])
+    for n in whole._PARAM_ATTRS:
+        setattr(whole, n, torch.nn.Parameter(getattr(model, n).detach()[order].clone()))
+    with torch.no_grad():
+        ref = render(cams[0], whole, PipelineParams(skip_objects=True), bg)["render"]
+    got = render_combined(target, background, cams[:1], bg)[0]
+    assert torch.equal(ref, got)
