@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cfloat>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,7 @@
 #include "../../include/gsraster.h"
 #include "gsr_kernels.hip.h"
 #include "gsr_sort.hip.h"
+#include "gsr_knn.hip.h"
 
 using namespace gsr;
 
@@ -645,6 +648,71 @@ void gsr_trim_pool(void) {
     else { (void)hipFree(b.p); pl.total -= b.bytes; }
   }
   pl.blocks.swap(keep);
+}
+
+int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* stream) {
+  if (P < 0 || (P > 0 && (!points || !mean_dist2))) return set_err(GSR_ERR_INVALID, "gsr_knn_dist2: null argument");
+  if (P == 0) return GSR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  const uint32_t n = (uint32_t)P;
+  const uint32_t tbl = radix_table_words(n);
+  // ---- bounding box (one small read-back: this routine is scene set-up, not the per-view path) ----------------
+  float host_bb[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  void* bb_blk = pool_alloc(dev, 256, st);
+  if (!bb_blk) return set_err(GSR_ERR_NOMEM, "gsr_knn_dist2: allocation failed");
+  float* bbox = static_cast<float*>(bb_blk);
+  hipError_t e = hipMemcpyAsync(bbox, host_bb, sizeof(host_bb), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_knn_bbox, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), dim3(256), 0, st, points, P, bbox);
+    e = hipMemcpyAsync(host_bb, bbox, sizeof(host_bb), hipMemcpyDeviceToHost, st);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  pool_free(dev, bb_blk);
+  if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_knn_dist2: bounding box: %s", hipGetErrorString(e));
+  // ---- grid: about three points per cell, at most 256 cells per axis ---------------------------------------------
+  double ext[3], vol = 1.0, emax = 0.0;
+  for (int a = 0; a < 3; ++a) { ext[a] = (double)host_bb[3 + a] - (double)host_bb[a]; emax = std::max(emax, ext[a]); }
+  if (!(emax > 0.0)) emax = 1.0;                       // all points coincide
+  for (int a = 0; a < 3; ++a) { ext[a] = std::max(ext[a], 1e-6 * emax); vol *= ext[a]; }
+  const double cell = std::cbrt(vol * 3.0 / (double)P);
+  KnnGrid g;
+  int dims[3];
+  float inv[3], size[3];
+  for (int a = 0; a < 3; ++a) {
+    dims[a] = (int)std::min(256.0, std::max(1.0, std::ceil(ext[a] / cell)));
+    const double c = ext[a] / dims[a];
+    inv[a] = (float)(1.0 / c);
+    size[a] = (float)c;
+  }
+  g.minx = host_bb[0]; g.miny = host_bb[1]; g.minz = host_bb[2];
+  g.inv_cx = inv[0]; g.inv_cy = inv[1]; g.inv_cz = inv[2];
+  g.sx = size[0]; g.sy = size[1]; g.sz = size[2]; g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
+  const uint32_t ncells = (uint32_t)dims[0] * dims[1] * dims[2];
+  // ---- workspace -----------------------------------------------------------------------------------------------
+  const size_t words = (size_t)4 * n + tbl + RS_BINS + 2 * (size_t)ncells + 64;
+  void* blk = pool_alloc(dev, sizeof(uint32_t) * words, st);
+  if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_knn_dist2: workspace allocation failed");
+  uint32_t* k0 = static_cast<uint32_t*>(blk);
+  uint32_t* v0 = k0 + n; uint32_t* k1 = v0 + n; uint32_t* v1 = k1 + n;
+  uint32_t* table = v1 + n; uint32_t* sums = table + tbl;
+  uint2* cell_range = reinterpret_cast<uint2*>(sums + RS_BINS + (((uintptr_t)(sums + RS_BINS) & 4) ? 1 : 0));
+  hipLaunchKernelGGL(k_knn_cells, dim3((n + 255) / 256), dim3(256), 0, st, points, P, g, k0);
+  const int res = radix_sort_pairs(k0, v0, k1, v1, n, 0, ceil_log2(ncells), true, table, sums, st);
+  const uint32_t* skeys = res ? k1 : k0;
+  const uint32_t* sidx = res ? v1 : v0;
+  if (ceil_log2(ncells) == 0) {   // a single cell: no pass ran, build the identity permutation by hand
+    std::vector<uint32_t> iota(n);
+    for (uint32_t i = 0; i < n; ++i) iota[i] = i;
+    (void)hipMemcpyAsync(v0, iota.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, st);
+    (void)hipStreamSynchronize(st);
+  }
+  (void)hipMemsetAsync(cell_range, 0, sizeof(uint2) * ncells, st);
+  hipLaunchKernelGGL(k_knn_ranges, dim3((n + 255) / 256), dim3(256), 0, st, n, skeys, cell_range);
+  hipLaunchKernelGGL(k_knn_search, dim3((n + 255) / 256), dim3(256), 0, st, points, P, g, sidx, cell_range, mean_dist2);
+  pool_free(dev, blk);
+  LAUNCH_CHECK("knn");
+  return GSR_OK;
 }
 
 int gsr_test_scan(const uint32_t* in, uint32_t* out, uint32_t n, void* stream) {

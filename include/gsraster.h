@@ -124,6 +124,12 @@ void gsr_ctx_free(GsrCtx* ctx);
 /* Frustum test only (view-space z > 0.2): present[P] = 1/0.  Replaces GaussianRasterizer.markVisible. */
 int gsr_mark_visible(const GsrSettings* settings, int32_t P, const float* means3D, uint8_t* present, void* stream);
 
+/* Mean squared distance of every point to its 3 nearest other points (exact): replaces the reference's second native
+ * import, simple_knn._C.distCUDA2 (reference scene/gaussian_model.py:17, called at :144 to seed the initial scales).
+ * points [P,3] float32 device, mean_dist2 [P] float32 device.  Synchronises the stream once (scene set-up routine, not
+ * part of the per-view path).  With fewer than 4 points the missing neighbours count as FLT_MAX, like the original. */
+int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* stream);
+
 /* Introspection. what: 0 version, 1 bytes held by the workspace pool on the current device,
  * 2 number of pairs of a context (ctx as int64 handle in *out on input is NOT used; see gsr_ctx_info). */
 int gsr_query(int32_t what, int64_t* out);
