@@ -311,3 +311,60 @@ def test_pair_count_overflow_is_reported_not_wrapped():
     # and the library still works afterwards
     model, cams, _ = _scene(n_views=1)
     check(model_inputs(model), cams[0], torch.zeros(3))
+
+
+def test_giant_and_tiny_splats_mixed():
+    """A few splats that cover the whole 448x320 image (560 tiles each: the whole-wave reduction path of K8/K9 for
+    Gaussians with more than 256 partial rows) among small and sub-pixel ones, opacities from ~0 to ~1."""
+    from gsplat_attack.cameras import look_at_camera
+    g = torch.Generator().manual_seed(17)
+    P = 400
+    xyz = torch.randn(P, 3, generator=g) * 0.4
+    scales = torch.exp(torch.randn(P, 3, generator=g) * 0.8 + math.log(0.02))
+    scales[:6] = torch.rand(6, 3, generator=g) * 2.0 + 1.5            # giants
+    scales[6:40] *= 0.02                                               # sub-pixel
+    rots = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
+    opac = torch.sigmoid(torch.randn(P, 1, generator=g) * 3.0)
+    opac[:6] = torch.tensor([[0.05], [0.3], [0.002], [0.6], [0.02], [0.15]])
+    shs = torch.randn(P, 16, 3, generator=g) * 0.3
+    objs = torch.randn(P, 1, 16, generator=g) * 0.3
+    inp = dict(means3D=xyz, shs=shs, opacities=opac, scales=scales, rotations=rots, sh_objs=objs)
+    cam = look_at_camera((0.0, -0.3, -2.5), (0.0, 0.0, 0.0), fovx=0.9, width=448, height=320)
+    check(inp, cam, torch.tensor([0.05, 0.1, 0.15]), with_gobj=True, frag_frac=2e-2, elem_frac=3e-3)
+
+
+def test_backward_twice_on_one_forward():
+    """retain_graph: the context serves several backward calls, each with its own partial-row tag."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    model, cams, _ = _scene(n_views=1)
+    inp = {k: v.to(dev).requires_grad_(True) for k, v in model_inputs(model).items()}
+    st = settings_for(cams[0], torch.zeros(3), cls=D.GaussianRasterizationSettings, device=dev)
+    color, _, _ = D.GaussianRasterizer(raster_settings=st)(
+        means3D=inp["means3D"], means2D=torch.zeros(1000, 3, device=dev), opacities=inp["opacities"], shs=inp["shs"],
+        sh_objs=inp["sh_objs"], scales=inp["scales"], rotations=inp["rotations"])
+    g1 = torch.randn(3, 128, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    g2 = torch.randn(3, 128, 128, generator=torch.Generator().manual_seed(2)).to(dev)
+    a = torch.autograd.grad(color, [inp["means3D"], inp["shs"]], g1, retain_graph=True)
+    b = torch.autograd.grad(color, [inp["means3D"], inp["shs"]], g2, retain_graph=True)
+    c = torch.autograd.grad(color, [inp["means3D"], inp["shs"]], g1 + g2)
+    for x, y, z in zip(a, b, c):
+        assert torch.allclose(x + y, z, rtol=1e-4, atol=1e-5 * float(z.abs().max()))
+
+
+def test_strided_and_half_precision_inputs_are_accepted():
+    D = _hip()
+    dev = torch.device("cuda:0")
+    model, cams, _ = _scene(n_views=1)
+    inp = {k: v.to(dev) for k, v in model_inputs(model).items()}
+    st = settings_for(cams[0], torch.zeros(3), cls=D.GaussianRasterizationSettings, device=dev)
+    rast = D.GaussianRasterizer(raster_settings=st)
+    m2 = torch.zeros(1000, 3, device=dev)
+    ref, _, _ = rast(means3D=inp["means3D"], means2D=m2, opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                     rotations=inp["rotations"])
+    wide = torch.zeros(1000, 6, device=dev)
+    wide[:, ::2] = inp["means3D"]
+    strided = wide[:, ::2]                                   # non-contiguous view
+    got, _, _ = rast(means3D=strided, means2D=m2, opacities=inp["opacities"].double(), shs=inp["shs"],
+                     scales=inp["scales"], rotations=inp["rotations"])
+    assert torch.equal(ref, got)
