@@ -12,6 +12,8 @@ What is captured (data only -- inputs and the reference's outputs):
   * utils/general_utils.py: inverse_sigmoid
   * scene/gaussian_model.py: the activation getters (:97-124) of a CPU GaussianModel
   * attack.py:25-173: the ten PGD step functions applied to a small fake model with .grad set
+  * scene/colmap_loader.py text readers + qvec2rotmat and the FoV / pose conversion of
+    scene/dataset_readers.py:68-143 on tests/golden/colmap_sample/ (a hand-written COLMAP text model; data, not code)
 
 Third-party modules the reference imports but this image lacks (hydra, omegaconf, plyfile,
 simple_knn, diff_gaussian_rasterization, detectors.factory's dependencies) are replaced by empty
@@ -156,6 +158,28 @@ def main():
                                                         orig["_features_dc"].clone())
         out[f"pgd_color_{norm}_rest"] = f._features_rest.numpy()
         out[f"pgd_color_{norm}_dc"] = f._features_dc.numpy()
+
+    # ---- COLMAP text model -> camera parameters (scene/colmap_loader.py:156-271, scene/dataset_readers.py:68-143) ----
+    from scene.colmap_loader import read_intrinsics_text, read_extrinsics_text, qvec2rotmat
+    from utils.graphics_utils import focal2fov
+    sample = os.path.join(os.path.dirname(os.path.abspath(__file__)), "colmap_sample", "sparse", "0")
+    intr = read_intrinsics_text(os.path.join(sample, "cameras.txt"))
+    extr = read_extrinsics_text(os.path.join(sample, "images.txt"))
+    rows = []
+    for key in extr:
+        e = extr[key]
+        i = intr[e.camera_id]
+        R = np.transpose(qvec2rotmat(e.qvec))
+        name = os.path.basename(e.name).split(".")[0]
+        rows.append((name, i.id, R, np.array(e.tvec), focal2fov(i.params[0], i.width), focal2fov(i.params[1], i.height),
+                     i.width, i.height))
+    rows.sort(key=lambda r: r[0])                                  # readColmapSceneInfo sorts by image_name
+    out["colmap_names"] = np.array([r[0] for r in rows])
+    out["colmap_uid"] = np.array([r[1] for r in rows])
+    out["colmap_R"] = np.stack([r[2] for r in rows])
+    out["colmap_T"] = np.stack([r[3] for r in rows])
+    out["colmap_fov"] = np.array([[r[4], r[5]] for r in rows])
+    out["colmap_wh"] = np.array([[r[6], r[7]] for r in rows])
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays")
