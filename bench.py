@@ -82,8 +82,8 @@ def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="nyc-1M")
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (parity-size runs)")
     ap.add_argument("--width", type=int, default=None)
@@ -193,6 +193,7 @@ def main():
         # WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only when they
         # were taken on this very workload
         traffic = None
+        valu = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             kern = {"render_bwd": "void gsr::k_render_bwd<false>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
@@ -200,6 +201,15 @@ def main():
                     "preprocess": "void gsr::k_preprocess<true, true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
+                n_valu = pmc["per_kernel"][kern].get("SQ_INSTS_VALU")
+                if n_valu:
+                    # secondary roofline of the dominant kernel: wave64 VALU instructions issue at one per 4 cycles per
+                    # SIMD (measured: SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles), 1024 SIMDs, 2.4 GHz max clock
+                    peak = 1024 * 2.4e9 / 4 / 1e9
+                    ach = n_valu / (per[dom]["avg_ms"] * 1e-3) / 1e9
+                    valu = {"bound": "fp32 VALU issue", "wave_instr_per_launch": round(n_valu),
+                            "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                            "frac": round(ach / peak, 4)}
         except Exception:
             traffic = None
         B_total = 304 * P + 548 * V + 116 * N + 40 * HW
@@ -232,6 +242,8 @@ def main():
                          "frac": round(B_total / t_view / 1e9 / HBM_PEAK_GBS, 5)},
             "stages": per,
         }
+        if valu is not None:
+            result["roofline"]["valu"] = valu
         if world == 1 and not args.no_cpu_baseline:
             sp, sw, sh = (int(x) for x in args.cpu_sample.split(","))
             log(f"cpu baseline (oracle-R) on a {sp}-Gaussian {sw}x{sh} sample ...")
