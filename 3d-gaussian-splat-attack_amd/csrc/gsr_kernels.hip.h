@@ -507,10 +507,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 // ------------------------------------------------------------------------------------------------
 // K7: backward composite, same tiling, list walked back to front.  Per (tile, entry) the wave reduces
-// nine sums over its 256 pixels in registers + DPP and stores ONE 48-byte row at the pair's emission
-// slot: no global atomics, bitwise reproducible.  Row = (Sq dx, Sq dy, Sq dx^2, Sq dx dy, Sq dy^2,
-// S G dL/dalpha, S w g_r, S w g_g, S w g_b, 0,0,0) with q = o G dL/dalpha.
+// nine sums over its 256 pixels and stores ONE 48-byte row at the pair's emission slot: no global
+// atomics, bitwise reproducible.  Row = (Sq dx, Sq dy, Sq dx^2, Sq dx dy, Sq dy^2, S G dL/dalpha,
+// S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha.
+// The 64-lane sums are not butterflies (a DPP add issues at half the rate of a plain one and nine values
+// need 9 x 6 of them): one v_permlane32_swap step folds the nine per-lane values into five registers,
+// those are parked in LDS (ds_write does not occupy the VALU), and every RED_B contributing entries the
+// wave sums them TRANSPOSED: lane L adds the 16 floats of chunk L with plain v_add (4 ds_read_b128), one
+// DPP add joins the two chunks of a value, and the lanes store their row words directly.
 // ------------------------------------------------------------------------------------------------
+constexpr int RED_B = 3;          // contributing entries parked between two transposed sums (3 x 20 chunks = 60 lanes)
+constexpr int RED_ROW = 20;       // a 16-float chunk padded to 5 float4: ds_read_b128 at an odd float4 stride is conflict free
+constexpr int RED_REG = 4 * RED_ROW;      // one register: four 16-lane rows
+constexpr int RED_ENTRY = 5 * RED_REG;    // five registers per entry
 struct RenderBwdArgs {
   const uint2* ranges;
   const uint32_t* pair_rank;
@@ -539,11 +548,20 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   __shared__ float2 s2[64];
   __shared__ uint32_t sslot[64];
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
+  __shared__ __attribute__((aligned(16))) float sred[RED_B * RED_ENTRY];
   const int lane = threadIdx.x;
   const int tile = item_of_block(a.ntiles, a.map_mode);
   if (tile >= a.ntiles) return;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
+  // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
+  const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
+  const int red_e = lane / 20, red_v = 2 * ((lane % 20) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
+  // row word this lane stores (value 9 is the unused tenth sum: its two lanes stamp the tag words 9 and 10)
+  const int red_word = red_v == 9 ? 9 + red_sub : (red_sub == 0 ? red_v : -1);
+  const float red_tag = __uint_as_float(red_sub ? a.tag_hi : a.tag_lo);
+  int red_j = 0;       // lane b: batch index j of the b-th parked entry
+  int red_n = 0;       // parked entries (wave uniform)
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)x;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
@@ -657,26 +675,23 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         }
       }
       if (hit) {
-        const float mx = sq * dx;
-        // nine sums over 256 pixels -> one 48-byte row: pack_half / pack_row each halve the number of live
-        // values, leaving value 4n + 2*(row&1) + (row>>1) in register n of 16-lane row `row`; three row sums.
-        const float c0 = pack_half(mx, sqy);             // values 0,1  : S q dx    | S q dy
-        const float c1 = pack_half(mx * dx, sqy * dx);   // values 2,3  : S q dx^2  | S q dx dy
-        const float c2 = pack_half(sqyy, dop);           // values 4,5  : S q dy^2  | S G dL/dalpha
-        const float c3 = pack_half(dr, dg);              // values 6,7
-        const float c4 = pack_half(db, 0.f);             // values 8,9
-        const float r0 = row_sum(pack_row(c0, c1));
-        const float r1 = row_sum(pack_row(c2, c3));
-        const float r2 = row_sum(pack_row(c4, 0.f));
-        if ((lane & 15) == 0) {
-          const int k = lane >> 4;
-          float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[j] * PART_F4) + 2 * (k & 1) + (k >> 1);
-          // row words 9 and 10 (written by rows 2 and 1 of the wave) carry this backward call's 64-bit tag: rows
-          // that no wave writes keep whatever the workspace held and are recognised as stale by K8/K9, so the
-          // partial-row buffer never has to be cleared
-          const float r2w = k == 2 ? __uint_as_float(a.tag_lo) : (k == 1 ? __uint_as_float(a.tag_hi) : r2);
-          row[0] = r0; row[4] = r1; row[8] = r2w;
-        }
+        // nine per-lane sums -> five registers (lanes < 32: value 2n, lanes >= 32: value 2n+1), parked in LDS
+        float a0 = sq * dx, b0 = sqy;                    // values 0,1 : S q dx    | S q dy
+        float a1 = a0 * dx, b1 = sqy * dx;               // values 2,3 : S q dx^2  | S q dx dy
+        float a2 = sqyy, b2 = dop;                       // values 4,5 : S q dy^2  | S G dL/dalpha
+        float a3 = dr, b3 = dg;                          // values 6,7
+        float a4 = db, b4 = 0.f;                         // values 8,9
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane32_swap_b32 %0, %5\n\t"
+                     "v_permlane32_swap_b32 %1, %6\n\t"
+                     "v_permlane32_swap_b32 %2, %7\n\t"
+                     "v_permlane32_swap_b32 %3, %8\n\t"
+                     "v_permlane32_swap_b32 %4, %9"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
+        float* w = &sred[red_n * RED_ENTRY + red_wofs];
+        w[0] = a0 + b0; w[RED_REG] = a1 + b1; w[2 * RED_REG] = a2 + b2; w[3 * RED_REG] = a3 + b3; w[4 * RED_REG] = a4 + b4;
+        red_j = lane == red_n ? j : red_j;
+        ++red_n;
         if (OBJ) {
 #pragma unroll
           for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = wave_sum_to_hi(dobj[c]);
@@ -688,6 +703,29 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
             ro[3] = make_float4(dobj[12], dobj[13], dobj[14], dobj[15]);
           }
         }
+      }
+      if (red_n == RED_B || (j == 0 && red_n > 0)) {     // sslot[] is re-staged after j == 0: drain before that
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int jm = __builtin_amdgcn_ds_bpermute(red_e << 2, red_j);
+        if (red_e < red_n) {
+          const float4* ch = reinterpret_cast<const float4*>(&sred[RED_ROW * lane]);
+          const float4 q0 = ch[0], q1 = ch[1], q2 = ch[2], q3 = ch[3];
+          float t = (((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w))) +
+                    (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
+          t += dpp_mov<0xB1, 0xF>(t);                    // lanes 2m, 2m+1 hold the two chunks of one value
+          if (red_word >= 0) {
+            float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[jm] * PART_F4);
+            // words 9 and 10 carry this backward call's 64-bit tag: rows that no wave writes keep whatever the
+            // workspace held and are recognised as stale by K8/K9, so the partial-row buffer is never cleared
+            row[red_word] = red_v == 9 ? red_tag : t;
+          }
+        }
+        red_n = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
     }
     __builtin_amdgcn_wave_barrier();
