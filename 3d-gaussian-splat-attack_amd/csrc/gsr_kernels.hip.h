@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   const float pxf = (float)x;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
-  float pyf[PXL], T[PXL], Acc[PXL], la[PXL], lcg[PXL], g0[PXL], g1[PXL], g2[PXL], bgd[PXL];
+  float pyf[PXL], T[PXL], Acc[PXL], la[PXL], lcg[PXL], g0[PXL], g1[PXL], g2[PXL];
   float gO[OBJ ? PXL : 1][NUM_OBJ];
   uint32_t ncon[PXL], smax[PXL];
   uint32_t maxc = 0;
@@ -577,17 +577,19 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     Acc[k] = 0.f; la[k] = 0.f; lcg[k] = 0.f;
     if (x < a.W && y < a.H) {
       const size_t pix = (size_t)y * a.W + x;
-      const float Tf = a.final_T[pix];
-      T[k] = Tf;
+      T[k] = a.final_T[pix];
       ncon[k] = a.n_contrib[pix];
       g0[k] = a.grad_color[pix]; g1[k] = a.grad_color[HW + pix]; g2[k] = a.grad_color[2 * HW + pix];
-      bgd[k] = Tf * (bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k]);
+      // the background is the list's last "entry" (alpha 1, colour bg): seeding the running colour term with it
+      // makes T_i (c_i.g - Acc_i) carry the -T_final/(1-alpha_i) (bg.g) term of dL/dalpha_i by itself
+      la[k] = 1.f;
+      lcg[k] = bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k];
       if (OBJ) {
 #pragma unroll
         for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = a.grad_objects[c * HW + pix];
       }
     } else {
-      T[k] = 1.f; ncon[k] = 0; g0[k] = g1[k] = g2[k] = 0.f; bgd[k] = 0.f;
+      T[k] = 1.f; ncon[k] = 0; g0[k] = g1[k] = g2[k] = 0.f;
       if (OBJ) {
 #pragma unroll
         for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = 0.f;
@@ -603,7 +605,13 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       const uint32_t pv = a.pair_rank[rg.x + lo + lane];
       const uint32_t r = pv & RANK_MASK;
       const float4 c = a.R2[REC * r];
-      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, pv >> RANK_BITS);
+      // strips whose last contributor lies in front of this list position are done with it: clear their bits
+      // here, once per staged entry, instead of testing pos <= smax[k] per strip in the walk
+      const uint32_t pos = (uint32_t)(lo + lane + 1);
+      uint32_t live = 0;
+#pragma unroll
+      for (int k = 0; k < PXL; ++k) live |= (pos <= smax[k] ? 1u : 0u) << k;
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, (pv >> RANK_BITS) & live);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
@@ -637,7 +645,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       bool hit = false;
 #pragma unroll
       for (int k = 0; k < PXL; ++k) {
-        if ((m & (1u << k)) && pos <= smax[k]) {
+        if (m & (1u << k)) {
           const float dy = e0.y - pyf[k];
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
           const bool cand = (p2 >= e2.y) && (pos <= ncon[k]);
@@ -665,7 +673,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
             Acc[k] = fmaf(la[k], lcg[k] - Acc[k], Acc[k]);   // la*lcg + (1-la)*Acc
             lcg[k] = cg;
             la[k] = ae;
-            const float dLda = valid ? fmaf(T[k], cg - Acc[k], -bgd[k] * inv1m) : 0.f;
+            const float dLda = valid ? T[k] * (cg - Acc[k]) : 0.f;
             dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
             dop = fmaf(G, dLda, dop);
             const float q = oG * dLda;
