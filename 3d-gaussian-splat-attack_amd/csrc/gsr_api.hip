@@ -211,6 +211,7 @@ struct GsrCtx {
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // the same in storage order
   uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
+  uint32_t* sched = nullptr;      // [ntiles] tiles longest-list-first + priority class
   float* final_T = nullptr;
   uint32_t* n_contrib = nullptr;
   unsigned long long* total64 = nullptr;   // exact (64-bit) number of pairs of the tile rects
@@ -247,6 +248,9 @@ void gsr_ctx_free(GsrCtx* c) {
 
 // raw != 0: scales / rotations / opacities are the reference model's RAW parameters, shs is _features_rest and
 // sh_dc is _features_dc (K must be 16); activations and their chain rule run inside K1 / K9.
+// diagnostic: device buffer [ntiles][2] that the next backward composites stamp with their waves' start/end clocks
+static std::atomic<unsigned long long*> g_wave_clock{nullptr};
+
 static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
                         const float* sh_dc, const float* sh_objs, const float* colors_precomp, const float* opacities,
                         const float* scales, const float* rotations, const float* cov3D_precomp, float* out_color,
@@ -294,7 +298,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   kp.add<float4>(3 * Pp);   // R records (depth order)
   kp.add<float4>(3 * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
-  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<unsigned long long>(2);
+  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<unsigned long long>(2); kp.add<uint32_t>(ntiles);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
@@ -315,6 +319,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   c->total64 = ks.take<unsigned long long>(2);
+  c->sched = ks.take<uint32_t>(ntiles);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
@@ -438,8 +443,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     RenderArgs ra;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
-    static const int map_mode_f = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+    static const int map_mode_f = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 3; return (v >= 0 && v <= 3) ? v : 3; }();
     ra.map_mode = map_mode_f;
+    ra.sched = c->sched;
+    if (map_mode_f == 3) hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
     static const int fwd_npx = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 2; }();
@@ -523,8 +530,10 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.tag_lo = tag_lo; ra.tag_hi = tag_hi;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = c->sh_objs; ra.bg = c->st.bg; ra.W = c->st.image_width; ra.H = c->st.image_height;
-    static const int map_mode_b = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+    static const int map_mode_b = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 3; return (v >= 0 && v <= 3) ? v : 3; }();
     ra.map_mode = map_mode_b;
+    ra.sched = c->sched;
+    ra.wave_clock = g_wave_clock.load();
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
     const dim3 gridT(render_grid(c->ntiles)), blk(64);
@@ -712,6 +721,11 @@ int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* strea
   hipLaunchKernelGGL(k_knn_search, dim3((n + 255) / 256), dim3(256), 0, st, points, P, g, sidx, cell_range, mean_dist2);
   pool_free(dev, blk);
   LAUNCH_CHECK("knn");
+  return GSR_OK;
+}
+
+int gsr_debug_wave_clock(unsigned long long* buf) {
+  g_wave_clock.store(buf);
   return GSR_OK;
 }
 

@@ -305,6 +305,7 @@ struct RenderArgs {
   const float* sh_objs;   // [P,16] or null
   const float* bg;
   int W, H, gridx, ntiles, map_mode;
+  const uint32_t* sched;      // map mode 3: tiles longest-list-first + priority class (k_tile_schedule)
   float* out_color;       // [3,H,W]
   float* out_objects;     // [16,H,W] or null
   float* final_T;         // [H*W]
@@ -330,6 +331,64 @@ __device__ __forceinline__ int item_of_block(int nitems, int mode) {
   return ((s >> 5) * 8 + x) * 32 + (s & 31);
 }
 __device__ __forceinline__ int tile_of_block(int ntiles) { return item_of_block(ntiles, 1); }
+
+// ------------------------------------------------------------------------------------------------
+// Tile schedule (map mode 3, the default).  A tile's list is walked serially by its wave(s), so the longest list
+// is the critical path of K6 and K7 and, sharing its SIMD with three to seven other waves, it sets the kernels'
+// run time long after the average SIMD has run dry.  sched[] lists the tiles longest-first (counting sort on
+// len/4, one block) so long lists start at t = 0 and short ones fill in behind them, and carries a 2-bit
+// priority class (length relative to the longest list) that the render kernels hand to s_setprio: the long
+// lists issue ahead of their SIMD's other waves.  Results do not depend on the schedule.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCHED_BINS = 1024;
+constexpr uint32_t SCHED_TILE_MASK = (1u << 28) - 1u;
+__global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2* __restrict__ ranges,
+                                                        uint32_t* __restrict__ sched) {
+  __shared__ uint32_t hist[SCHED_BINS];
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t smax;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  hist[t] = 0;
+  if (t == 0) smax = 0;
+  __syncthreads();
+  uint32_t mymax = 0;
+  for (int i = t; i < ntiles; i += 1024) {
+    const uint2 r = ranges[i];
+    const uint32_t len = r.y - r.x;
+    atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
+    mymax = max(mymax, len);
+  }
+  atomicMax(&smax, mymax);
+  __syncthreads();
+  // exclusive scan over the bins in DESCENDING length order: thread t owns bin 1023 - t
+  const uint32_t v = hist[SCHED_BINS - 1 - t];
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  __syncthreads();
+  hist[SCHED_BINS - 1 - t] = base + inc - v;      // becomes the bin's cursor
+  __syncthreads();
+  const uint32_t longest = smax + 1u;
+  for (int i = t; i < ntiles; i += 1024) {
+    const uint2 r = ranges[i];
+    const uint32_t len = r.y - r.x;
+    const uint32_t p = atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
+    const uint32_t prio = (uint32_t)(((uint64_t)len * 4u) / longest);      // 0..3
+    sched[p] = (uint32_t)i | (prio << 28);
+  }
+}
+__device__ __forceinline__ void set_wave_priority(uint32_t prio) {
+  if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+  else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 1u) __builtin_amdgcn_s_setprio(1);
+}
 inline int render_grid(int nitems) { return 256 * ((nitems + 255) / 256); }   // covers every mapping mode
 
 // Staged form of a splat: the conic is pre-scaled so that p2 = log2(e) * power comes out of two FMAs.  c.y is a
@@ -360,8 +419,16 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   __shared__ float2 s2[64];
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
   const int lane = threadIdx.x;
-  const int item = item_of_block(a.ntiles * NSUB, a.map_mode);
-  if (item >= a.ntiles * NSUB) return;
+  int item;
+  if (a.map_mode == 3) {
+    if ((int)blockIdx.x >= a.ntiles * NSUB) return;
+    const uint32_t sc = a.sched[blockIdx.x / NSUB];
+    item = (int)(sc & SCHED_TILE_MASK) * NSUB + (int)(blockIdx.x % NSUB);
+    set_wave_priority(sc >> 28);
+  } else {
+    item = item_of_block(a.ntiles * NSUB, a.map_mode);
+    if (item >= a.ntiles * NSUB) return;
+  }
   const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
@@ -530,6 +597,7 @@ struct RenderBwdArgs {
   const float* sh_objs;
   const float* bg;
   int W, H, gridx, ntiles, map_mode;
+  const uint32_t* sched;      // map mode 3: tiles longest-list-first + priority class (k_tile_schedule)
   const float* final_T;
   const uint32_t* n_contrib;
   const float* grad_color;    // [3,H,W]
@@ -537,6 +605,7 @@ struct RenderBwdArgs {
   float4* part;               // [N][3]
   float4* part_obj;           // [N][4] or null
   uint32_t tag_lo, tag_hi;    // stamped into every row written by this call
+  unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock): [ntiles][2] start/end of each tile's wave, 100 MHz
 };
 
 constexpr int PART_F4 = 3;
@@ -550,10 +619,19 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
   __shared__ __attribute__((aligned(16))) float sred[RED_B * RED_ENTRY];
   const int lane = threadIdx.x;
-  const int tile = item_of_block(a.ntiles, a.map_mode);
-  if (tile >= a.ntiles) return;
+  int tile;
+  if (a.map_mode == 3) {
+    if ((int)blockIdx.x >= a.ntiles) return;
+    const uint32_t sc = a.sched[blockIdx.x];
+    tile = (int)(sc & SCHED_TILE_MASK);
+    set_wave_priority(sc >> 28);
+  } else {
+    tile = item_of_block(a.ntiles, a.map_mode);
+    if (tile >= a.ntiles) return;
+  }
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * tile] = wall_clock64();
   // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
   const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
   const int red_e = lane / 20, red_v = 2 * ((lane % 20) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
@@ -738,6 +816,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * tile + 1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -168,6 +168,12 @@ int gsr_profile_read(float* ms, int64_t* calls);
 
 const char* gsr_last_error(void);
 
+/*
+ * gsr_debug_wave_clock: diagnostic.  While `buf` (device, [ntiles][2] uint64) is set, every backward composite (K7)
+ * stamps the 100 MHz wall clock at which each tile's wave started and ended; pass NULL to stop.  Process-wide.
+ */
+int gsr_debug_wave_clock(unsigned long long* buf);
+
 /* Test hooks (used by tests/ only): the scan and sort primitives of the binning stage on caller buffers.
  * gsr_test_scan: out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total), uint32.
  * gsr_test_sort_pairs: stable ascending sort of (keys, vals) on key bits [begin_bit, end_bit), in place;
