@@ -395,7 +395,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       N = *pinned;
       unsigned long long exact = 0;
       memcpy(&exact, pinned + 2, sizeof(exact));
-      if (exact != (unsigned long long)N || exact > MAX_PAIRS)
+      if (exact != (unsigned long long)N || exact >= MAX_PAIRS)   // NSUB * N must stay below 2^32
         return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: %llu (tile, Gaussian) pairs exceed the supported %llu "
                             "(splats cover too many tiles: check scales / scale_modifier)", exact, MAX_PAIRS));
     }
@@ -449,7 +449,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     if (map_mode_f == 3) hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
-    static const int fwd_npx = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 2; return (v == 1 || v == 2 || v == 4) ? v : 2; }();
+    // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
+    // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FWD_NPX=1|2|4 overrides.
+    static const int fwd_npx_env = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+    const int fwd_npx = fwd_npx_env ? fwd_npx_env : (ntiles < 4096 ? 1 : 2);
     const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
     if (out_objects && sh_objs) {
       if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
@@ -508,9 +511,16 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   void* pobj_blk = nullptr;
   float4* part = nullptr;
   float4* part_obj = nullptr;
+  // K7 runs one wave per 16x(4*npx) part of a tile; each writes its own partial row per list entry
+  // (4 pixels per lane: one wave per tile; 2: two).  A tile's list is walked serially, so an image with fewer tiles
+  // than the chip has wave slots (4 waves x 1024 SIMDs at K7's register count) runs faster split finer, even
+  // though K8/K9 then sums twice the rows; GSR_BWD_NPX=2|4 overrides.
+  static const int bwd_npx_env = [] { const char* e = getenv("GSR_BWD_NPX"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 0; }();
+  const int bwd_npx = bwd_npx_env ? bwd_npx_env : (c->ntiles < 4096 ? 2 : 4);
+  const uint32_t nsub = (uint32_t)(PXL / bwd_npx);
   if (N > 0) {
-    part_blk = pool_alloc(dev, sizeof(float4) * PART_F4 * (size_t)N, st);
-    if (obj) pobj_blk = pool_alloc(dev, sizeof(float4) * 4 * (size_t)N, st);
+    part_blk = pool_alloc(dev, sizeof(float4) * PART_F4 * (size_t)N * nsub, st);
+    if (obj) pobj_blk = pool_alloc(dev, sizeof(float4) * 4 * (size_t)N * nsub, st);
     if (!part_blk || (obj && !pobj_blk)) {
       pool_free(dev, part_blk); pool_free(dev, pobj_blk);
       return set_err(GSR_ERR_NOMEM, "gsr_backward: partial-gradient buffer (N=%u) allocation failed", N);
@@ -536,9 +546,14 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.wave_clock = g_wave_clock.load();
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
-    const dim3 gridT(render_grid(c->ntiles)), blk(64);
-    if (obj) hipLaunchKernelGGL(k_render_bwd<true>, gridT, blk, 0, st, ra);
-    else hipLaunchKernelGGL(k_render_bwd<false>, gridT, blk, 0, st, ra);
+    const dim3 gridT(render_grid(c->ntiles * (int)nsub)), blk(64);
+    if (obj) {
+      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4>), gridT, blk, 0, st, ra);
+      else hipLaunchKernelGGL((k_render_bwd<true, 2>), gridT, blk, 0, st, ra);
+    } else {
+      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<false, 4>), gridT, blk, 0, st, ra);
+      else hipLaunchKernelGGL((k_render_bwd<false, 2>), gridT, blk, 0, st, ra);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "render backward: launch failed: %s", hipGetErrorString(e)));
   }
@@ -548,7 +563,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.P = P; pa.K = c->K; pa.va = view_args(c->st);
     pa.offg = c->offg; pa.G0 = c->G0; pa.G1 = c->G1; pa.G2 = c->G2;
     pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
-    pa.tag_lo = tag_lo; pa.tag_hi = tag_hi;
+    pa.tag_lo = tag_lo; pa.tag_hi = tag_hi; pa.nsub = nsub;
     pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
     pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc;
     pa.dmeans3D = dmeans3D; pa.dmeans2D = dmeans2D; pa.dsh = c->shs ? dshs : nullptr; pa.dsh_objs = dsh_objs;

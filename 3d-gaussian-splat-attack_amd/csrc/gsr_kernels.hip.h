@@ -610,8 +610,13 @@ struct RenderBwdArgs {
 
 constexpr int PART_F4 = 3;
 
-template <bool OBJ>
+// NPX = pixels per lane as in K6: 4 -> one wave per tile, 2 -> two waves per tile (16x8 halves), each writing its
+// OWN partial row (row = NSUB * slot + half; K8/K9 sums the NSUB rows of a pair, rows of halves the entry does not
+// reach stay stale and are skipped by their tag).  The serial walk of the longest list is the kernel's critical
+// path: halving the per-entry work of a wave shortens it, and the smaller register state lets six waves share a SIMD.
+template <bool OBJ, int NPX>
 __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
+  constexpr int NSUB = PXL / NPX;
   __shared__ float4 s0[64];
   __shared__ float4 s1[64];
   __shared__ float2 s2[64];
@@ -619,19 +624,20 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
   __shared__ __attribute__((aligned(16))) float sred[RED_B * RED_ENTRY];
   const int lane = threadIdx.x;
-  int tile;
+  int item;
   if (a.map_mode == 3) {
-    if ((int)blockIdx.x >= a.ntiles) return;
-    const uint32_t sc = a.sched[blockIdx.x];
-    tile = (int)(sc & SCHED_TILE_MASK);
+    if ((int)blockIdx.x >= a.ntiles * NSUB) return;
+    const uint32_t sc = a.sched[blockIdx.x / NSUB];
+    item = (int)(sc & SCHED_TILE_MASK) * NSUB + (int)(blockIdx.x % NSUB);
     set_wave_priority(sc >> 28);
   } else {
-    tile = item_of_block(a.ntiles, a.map_mode);
-    if (tile >= a.ntiles) return;
+    item = item_of_block(a.ntiles * NSUB, a.map_mode);
+    if (item >= a.ntiles * NSUB) return;
   }
+  const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
-  if (a.wave_clock && lane == 0) a.wave_clock[2 * tile] = wall_clock64();
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
   const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
   const int red_e = lane / 20, red_v = 2 * ((lane % 20) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
@@ -644,13 +650,13 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   const float pxf = (float)x;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
-  float pyf[PXL], T[PXL], Acc[PXL], la[PXL], lcg[PXL], g0[PXL], g1[PXL], g2[PXL];
-  float gO[OBJ ? PXL : 1][NUM_OBJ];
-  uint32_t ncon[PXL], smax[PXL];
+  float pyf[NPX], T[NPX], Acc[NPX], la[NPX], lcg[NPX], g0[NPX], g1[NPX], g2[NPX];
+  float gO[OBJ ? NPX : 1][NUM_OBJ];
+  uint32_t ncon[NPX], smax[NPX];
   uint32_t maxc = 0;
 #pragma unroll
-  for (int k = 0; k < PXL; ++k) {
-    const int y = ty * TILE + (lane >> 4) + 4 * k;
+  for (int k = 0; k < NPX; ++k) {
+    const int y = ty * TILE + sub * (4 * NPX) + (lane >> 4) + 4 * k;
     pyf[k] = (float)y;
     Acc[k] = 0.f; la[k] = 0.f; lcg[k] = 0.f;
     if (x < a.W && y < a.H) {
@@ -688,12 +694,12 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       const uint32_t pos = (uint32_t)(lo + lane + 1);
       uint32_t live = 0;
 #pragma unroll
-      for (int k = 0; k < PXL; ++k) live |= (pos <= smax[k] ? 1u : 0u) << k;
-      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, (pv >> RANK_BITS) & live);
+      for (int k = 0; k < NPX; ++k) live |= (pos <= smax[k] ? 1u : 0u) << k;
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, ((pv >> RANK_BITS) >> (sub * NPX)) & live);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
-      sslot[lane] = a.offg[__float_as_uint(c.y)] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx);
+      sslot[lane] = (a.offg[__float_as_uint(c.y)] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
         float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
@@ -711,7 +717,8 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       const int jn = max(j - 1, 0);           // prefetch the next entry while this one is processed
       n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
       const uint32_t pos = (uint32_t)(lo + j + 1);
-      const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y));
+      const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) & 0xFu;
+      if (m != 0u) {
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
       float sq = 0.f, sqy = 0.f, sqyy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
@@ -722,7 +729,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       }
       bool hit = false;
 #pragma unroll
-      for (int k = 0; k < PXL; ++k) {
+      for (int k = 0; k < NPX; ++k) {
         if (m & (1u << k)) {
           const float dy = e0.y - pyf[k];
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
@@ -790,6 +797,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
           }
         }
       }
+      }
       if (red_n == RED_B || (j == 0 && red_n > 0)) {     // sslot[] is re-staged after j == 0: drain before that
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -816,7 +824,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (a.wave_clock && lane == 0) a.wave_clock[2 * tile + 1] = wall_clock64();
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -836,6 +844,7 @@ struct PreBwdArgs {
   const float4* part;
   const float4* part_obj;
   uint32_t tag_lo, tag_hi;   // rows whose words 9,10 differ are stale (not written by this backward)
+  uint32_t nsub;             // partial rows per (tile, Gaussian) pair: one per K7 wave of the tile
   const float* means;
   const float* scales;
   const float* rots;
@@ -867,14 +876,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
   float4* wrow = SH_LDS ? &srow[wave * 64 * SHROW_F4] : nullptr;
   const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
   uint32_t o0 = 0, o1 = 0;
-  if (g < a.P) { o0 = a.offg[g]; o1 = a.offg[g + 1]; }
+  if (g < a.P) { o0 = a.offg[g] * a.nsub; o1 = a.offg[g + 1] * a.nsub; }
   // ---- sum this Gaussian's partial rows ---------------------------------------------------------------------
   // The rows of the wave's 64 Gaussians are one contiguous span: copy it through LDS in chunks of 256 rows with
   // coalesced float4 loads (48-byte rows read back with ds_read_b128 are bank-conflict free) instead of 64 lanes
   // each walking their own rows in HBM.  A Gaussian with more than 256 rows is summed by the whole wave.
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
   if (SH_LDS && nw > 0) {
-    const uint32_t S = a.offg[gw0], E = a.offg[gw0 + nw];
+    const uint32_t S = a.offg[gw0] * a.nsub, E = a.offg[gw0 + nw] * a.nsub;
     const bool big = (o1 - o0) > 256u;
     for (uint32_t c0 = S; c0 < E; c0 += 256u) {
       const uint32_t rows = min(256u, E - c0);
