@@ -182,6 +182,17 @@ def _empty_like_or_none(t):
     return None if t is None else torch.empty_like(t)
 
 
+_ZERO = {}
+
+
+def _zero_scalar(device):
+    """One cached 1x1x1 zero per device: the object map handed back when no object features were composited."""
+    z = _ZERO.get(device)
+    if z is None:
+        z = _ZERO[device] = torch.zeros(1, 1, 1, dtype=torch.float32, device=device)
+    return z
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -210,7 +221,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # without object features the 16 object channels are identically zero: hand back a broadcast zero instead of
         # writing 16*H*W floats per view
         objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if shoc is not None
-                   else torch.zeros(1, 1, 1, dtype=torch.float32, device=device).expand(NUM_OBJECTS, H, W))
+                   else _zero_scalar(device).expand(NUM_OBJECTS, H, W))
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
@@ -315,7 +326,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         pack = _SettingsPack(raster_settings, device)
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if obj is not None
-                   else torch.zeros(1, 1, 1, dtype=torch.float32, device=device).expand(NUM_OBJECTS, H, W))
+                   else _zero_scalar(device).expand(NUM_OBJECTS, H, W))
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)

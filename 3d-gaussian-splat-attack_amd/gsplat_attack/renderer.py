@@ -43,11 +43,9 @@ def _has_raw_layout(pc) -> bool:
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # The reference builds `zeros_like(...) + 0` and calls retain_grad() on that non-leaf (:25-29); a zero LEAF gives
+    # callers the same thing (values 0, .grad filled by backward) without an add kernel and a gradient copy per view.
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True)
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
