@@ -68,6 +68,7 @@ struct Pool {
 };
 
 constexpr int MAX_DEV = 32;
+constexpr size_t POOL_SOFT_CAP = size_t(48) << 30;   // of 288 GB: beyond this, free blocks of other streams are re-used
 Pool g_pool[MAX_DEV];
 
 int cur_dev() {
@@ -80,16 +81,23 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
   bytes = std::max<size_t>((bytes + 255) & ~size_t(255), 256);
   Pool& pl = g_pool[dev];
   std::lock_guard<std::mutex> lk(pl.mu);
-  int best = -1;
+  // Best fit among the free blocks last used on THIS stream (work enqueued later on the same stream is ordered
+  // after the old user by the stream itself).  A block last used on another stream would need a host-side wait
+  // for that stream, which would serialise views pipelined over several streams: it is taken only once the pool
+  // already holds POOL_SOFT_CAP bytes, otherwise a new block is allocated for this stream.
+  int best = -1, other = -1;
   for (size_t i = 0; i < pl.blocks.size(); ++i) {
     const Block& b = pl.blocks[i];
-    if (!b.used && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 + (1u << 20) &&
-        (best < 0 || b.bytes < pl.blocks[best].bytes))
-      best = (int)i;
+    if (b.used || b.bytes < bytes || b.bytes > bytes + bytes / 2 + (1u << 20)) continue;
+    int& slot = (b.stream == st) ? best : other;
+    if (slot < 0 || b.bytes < pl.blocks[slot].bytes) slot = (int)i;
+  }
+  if (best < 0 && other >= 0 && pl.total + bytes > POOL_SOFT_CAP) {
+    (void)hipStreamSynchronize(pl.blocks[other].stream);   // cross-stream reuse: wait for the old user
+    best = other;
   }
   if (best >= 0) {
     Block& b = pl.blocks[best];
-    if (b.stream != st) (void)hipStreamSynchronize(b.stream);   // cross-stream reuse: wait for the old user
     b.used = true;
     b.stream = st;
     return b.p;
@@ -99,7 +107,12 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
   const size_t want = bytes + bytes / 8;
   if (hipMalloc(&p, want) != hipSuccess) {
     (void)hipGetLastError();
-    return nullptr;
+    if (other < 0) return nullptr;
+    Block& b = pl.blocks[other];                         // out of memory: fall back to the other stream's block
+    (void)hipStreamSynchronize(b.stream);
+    b.used = true;
+    b.stream = st;
+    return b.p;
   }
   pl.blocks.push_back(Block{p, want, st, true});
   pl.total += want;

@@ -16,6 +16,7 @@ Differences from the reference that are deliberate and documented in SURVEY.md s
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import time
 from typing import Callable, Iterable, List, Optional, Sequence
@@ -25,6 +26,7 @@ from torch import nn
 
 from . import dist as gdist
 from . import pgd
+from .streams import StreamRing
 from .renderer import PipelineParams, render
 
 GROUPS = ("color", "position", "scaling", "rotation", "opacity")
@@ -67,9 +69,10 @@ def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsi
 def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5, epsilon: float = 5.0,
                groups: Iterable[str] = ("color",), norm: str = "l2", bg: Optional[torch.Tensor] = None,
                loss_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, pipe: Optional[PipelineParams] = None,
-               log: Optional[Callable[[dict], None]] = None) -> List[float]:
+               log: Optional[Callable[[dict], None]] = None, streams: int = 3) -> List[float]:
     """Runs `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
-    initialised).  Returns the per-iteration global loss (sum over the batch's views)."""
+    initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
+    pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order."""
     groups = tuple(groups)
     assert all(g in GROUPS for g in groups) and norm in ("l2", "linf")
     dev = model.get_xyz.device
@@ -81,15 +84,20 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
     mine = [cameras[i] for i in gdist.views_of_rank(len(cameras), rank, world)]
     originals = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
     history = []
+    ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" else None
     for it in range(iters):
         t0 = time.perf_counter()
         model.zero_grad()
-        total = torch.zeros((), device=dev)
-        for cam in mine:                                   # one forward+backward per view: peak memory = one view
-            img = render(cam, model, pipe, bg)["render"]
-            loss = loss_fn(img[None])
-            loss.backward()
-            total = total + loss.detach()
+        losses = []
+        for cam in mine:                                   # one forward+backward per view: peak memory = one view per stream
+            with (ring.next() if ring is not None else contextlib.nullcontext()):
+                img = render(cam, model, pipe, bg)["render"]
+                loss = loss_fn(img[None])
+                loss.backward()
+                losses.append(loss.detach())
+        if ring is not None:
+            ring.join()
+        total = torch.stack(losses).sum() if losses else torch.zeros((), device=dev)
         if world > 1:
             gdist.allreduce_attribute_grads(model)
             torch.distributed.all_reduce(total)

@@ -6,7 +6,9 @@ One "step" = one view: ``render()`` forward of the S-nyc-1M synthetic scene (1,0
 hand-written HIP) + one backward from a fixed dL/dC[3,H,W] down to .grad on all seven raw attribute tensors
 (59 attack-relevant floats per Gaussian), object channels off.  With N > 1 every rank renders its own view of
 the ring (weak scaling) and the attribute gradients are sum-all-reduced over RCCL each step, inside the timed
-region.  Inputs are resident in HBM before the timed region starts.
+region.  Inputs are resident in HBM before the timed region starts.  Consecutive views are dealt round-robin over
+--streams HIP streams (default 3; gsplat_attack.streams) so one view's sort/scan kernels run beside another's
+compositing kernels -- exactly K views are still rendered and differentiated inside the timed region.
 
     python bench.py                       # N=1, defaults finish in ~2 minutes incl. the CPU baseline
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
@@ -90,6 +92,9 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--objects", action="store_true", help="composite the 16 object channels too")
     ap.add_argument("--no-cull", action="store_true", help="keep the full 3-sigma tile rects (A/B of the footprint cull)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the views are dealt over (view i runs on stream i %% S): the small sort/scan "
+                         "kernels of one view overlap the compositing kernels of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
     args = ap.parse_args()
@@ -132,6 +137,21 @@ def main():
             gdist.allreduce_attribute_grads(model)
         return out
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+
+    def run_steps(n):
+        if streams is None:
+            for _ in range(n):
+                step()
+            return
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        for i in range(n):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                step()
+        for s_ in streams:
+            torch.cuda.current_stream(dev).wait_stream(s_)
+
     if rank == 0:
         log(f"scene ready: P={P}, {W}x{H}; warmup x{args.warmup}")
     for i in range(args.warmup):
@@ -149,16 +169,18 @@ def main():
     D.profile(True, stages=[DOMINANT])
     if world > 1:
         dist.barrier()
+    if streams is not None:
+        run_steps(2 * len(streams))          # untimed: lets every stream build its own workspace blocks
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if rank == 0:
-        log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
+        log(f"timed region done: {args.steps} steps in {elapsed:.3f} s (host enqueue {t_enq:.3f} s)")
     dom_ms_timed = D.profile_read()[DOMINANT][0] / args.steps
     # Untimed extra pass with every stage bracketed: the per-stage breakdown reported under "stages".
     D.profile(True)
@@ -196,20 +218,21 @@ def main():
         valu = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            kern = {"render_bwd": "void gsr::k_render_bwd<false>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
+            kern = {"render_bwd": "void gsr::k_render_bwd<false, 4>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
                     "preprocess_bwd": "void gsr::k_preprocess_bwd<true, true>",
                     "preprocess": "void gsr::k_preprocess<true, true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
                 n_valu = pmc["per_kernel"][kern].get("SQ_INSTS_VALU")
                 if n_valu:
-                    # secondary roofline of the dominant kernel: wave64 VALU instructions issue at one per 4 cycles per
-                    # SIMD (measured: SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles), 1024 SIMDs, 2.4 GHz max clock
-                    peak = 1024 * 2.4e9 / 4 / 1e9
+                    # secondary roofline of the dominant kernel: a SIMD issues one plain wave64 VALU instruction per
+                    # 2 cycles (MI355X_MICROARCH.md; tests/ubench/valu_rate.hip measures 2.5 for v_add_f32, 2.8 for
+                    # v_fma_f32, 4.1 for DPP forms, ~9.5 for v_exp_f32 at 8 waves/SIMD), 1024 SIMDs, 2.4 GHz
+                    peak = 1024 * 2.4e9 / 2 / 1e9
                     ach = n_valu / (per[dom]["avg_ms"] * 1e-3) / 1e9
                     valu = {"bound": "fp32 VALU issue", "wave_instr_per_launch": round(n_valu),
                             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-                            "frac": round(ach / peak, 4)}
+                            "frac": round(ach / peak, 4), "launch_ms": per[dom]["avg_ms"]}
         except Exception:
             traffic = None
         B_total = 304 * P + 548 * V + 116 * N + 40 * HW
@@ -231,12 +254,18 @@ def main():
                                    "render() fwd + bwd to all attribute grads"
                                    + (", 16 object channels on" if args.objects else ", object channels off"),
                        "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
+                       "streams": args.streams,
                        "parallelism": f"views sharded 1/GPU, dp{world}"
+                                      + (f", consecutive views pipelined over {args.streams} HIP streams per GPU"
+                                         if args.streams > 1 else "")
                                       + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
-                         "note": "K6/K7 are fp32-VALU/exp bound (256*N alpha evaluations), not HBM bound; "
+                         # the same kernel with nothing beside it (untimed one-stream pass): in the timed region its
+                         # launches share the chip with the other streams' kernels
+                         "avg_launch_ms_alone": per[dom]["avg_ms"],
+                         "note": "K6/K7 are bound by VALU instruction issue (256*N alpha evaluations), not by HBM; "
                                  "HBM is the reporting roofline BASELINE.md section 3 prescribes"},
             "pipeline": {"bytes_per_view": B_total, "achieved": round(B_total / t_view / 1e9, 1), "unit": "GB/s",
                          "frac": round(B_total / t_view / 1e9 / HBM_PEAK_GBS, 5)},
