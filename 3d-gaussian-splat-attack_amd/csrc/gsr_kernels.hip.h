@@ -455,11 +455,13 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   }
   for (uint32_t base = rg.x; base < rg.y && alive; base += 64) {
     const uint32_t i = base + lane;
+    uint32_t mine = 0;
     if (i < rg.y) {
       const uint32_t pv = a.pair_rank[i];
       const uint32_t r = pv & RANK_MASK;
       const float4 c = a.R2[REC * r];
-      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, (pv >> RANK_BITS) >> (sub * NPX));
+      mine = ((pv >> RANK_BITS) >> (sub * NPX)) & ((1u << NPX) - 1u);
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
@@ -467,20 +469,27 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
     }
+    // entries of the batch that reach this wave's strips: the walk visits only these (an entry of the tile that
+    // touches only the other waves' strips costs nothing here)
+    uint64_t todo = __ballot(mine != 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int cnt = min(64u, rg.y - base);
-    float4 n0 = s0[0], n1 = s1[0];
-    float2 n2 = s2[0];
-    for (int j = 0; j < cnt && alive; ++j) {
+    if (todo == 0ull) continue;
+    int j = __builtin_ctzll(todo);
+    float4 n0 = s0[j], n1 = s1[j];
+    float2 n2 = s2[j];
+    while (alive) {
       const float4 e0 = n0, e1 = n1;
       const float2 e2 = n2;
-      const int jn = min(j + 1, 63);          // prefetch the next entry while this one is composited
-      n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+      const int jc = j;
+      todo &= todo - 1ull;
+      const bool more = todo != 0ull;
+      j = more ? __builtin_ctzll(todo) : jc;  // prefetch the next entry while this one is composited
+      n0 = s0[j]; n1 = s1[j]; n2 = s2[j];
       const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) & alive;
-      if (m == 0) continue;
-      const uint32_t pos = base - rg.x + j + 1;
+      const uint32_t pos = base - rg.x + jc + 1;
+      if (m != 0u) {
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
 #pragma unroll
@@ -498,7 +507,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
           if (OBJ) {
 #pragma unroll
-            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[j][c], w, O[k][c]);
+            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[jc][c], w, O[k][c]);
           }
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
@@ -506,6 +515,8 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
         }
       }
+      }
+      if (!more) break;
     }
     __builtin_amdgcn_wave_barrier();
   }
