@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   const float pxf = (float)x;
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
-  float pyf[NPX], T[NPX], Acc[NPX], la[NPX], lcg[NPX], g0[NPX], g1[NPX], g2[NPX];
+  float pyf[NPX], T[NPX], Acc[NPX], g0[NPX], g1[NPX], g2[NPX];
   float gO[OBJ ? NPX : 1][NUM_OBJ];
   uint32_t ncon[NPX], smax[NPX];
   uint32_t maxc = 0;
@@ -669,16 +669,16 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   for (int k = 0; k < NPX; ++k) {
     const int y = ty * TILE + sub * (4 * NPX) + (lane >> 4) + 4 * k;
     pyf[k] = (float)y;
-    Acc[k] = 0.f; la[k] = 0.f; lcg[k] = 0.f;
+    Acc[k] = 0.f;
     if (x < a.W && y < a.H) {
       const size_t pix = (size_t)y * a.W + x;
       T[k] = a.final_T[pix];
       ncon[k] = a.n_contrib[pix];
       g0[k] = a.grad_color[pix]; g1[k] = a.grad_color[HW + pix]; g2[k] = a.grad_color[2 * HW + pix];
-      // the background is the list's last "entry" (alpha 1, colour bg): seeding the running colour term with it
-      // makes T_i (c_i.g - Acc_i) carry the -T_final/(1-alpha_i) (bg.g) term of dL/dalpha_i by itself
-      la[k] = 1.f;
-      lcg[k] = bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k];
+      // Acc_i = sum over the entries j behind i of alpha_j (c_j.g) prod_{i<k<j} (1 - alpha_k): what the pixel shows
+      // behind entry i, dotted with dL/dC.  The background is the list's last "entry" (alpha 1, colour bg): seeding
+      // Acc with bg.g makes T_i (c_i.g - Acc_i) carry the -T_final/(1-alpha_i) (bg.g) term of dL/dalpha_i by itself.
+      Acc[k] = bg0 * g0[k] + bg1 * g1[k] + bg2 * g2[k];
       if (OBJ) {
 #pragma unroll
         for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = a.grad_objects[c * HW + pix];
@@ -766,10 +766,9 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
                 dobj[c] = fmaf(w, gO[k][c], dobj[c]);
               }
             }
-            Acc[k] = fmaf(la[k], lcg[k] - Acc[k], Acc[k]);   // la*lcg + (1-la)*Acc
-            lcg[k] = cg;
-            la[k] = ae;
-            const float dLda = valid ? T[k] * (cg - Acc[k]) : 0.f;
+            const float dcg = cg - Acc[k];
+            const float dLda = valid ? T[k] * dcg : 0.f;
+            Acc[k] = fmaf(ae, dcg, Acc[k]);                  // ae*cg + (1-ae)*Acc: now includes this entry
             dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
             dop = fmaf(G, dLda, dop);
             const float q = oG * dLda;
