@@ -362,18 +362,19 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const ViewArgs va = view_args(*s);
   const dim3 blk(256);
   const dim3 gridP((unsigned)((Pp + 255) / 256));
+  const dim3 blkPre(PRE_BLOCK), gridPre((unsigned)((Pp + PRE_BLOCK - 1) / PRE_BLOCK));
   uint32_t N = 0;
   if (P > 0) {
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
       if (raw)
-        hipLaunchKernelGGL((k_preprocess<true, true>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
+        hipLaunchKernelGGL((k_preprocess<true, true>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
                            cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       else if (shs && K == 16)
-        hipLaunchKernelGGL((k_preprocess<true, false>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
+        hipLaunchKernelGGL((k_preprocess<true, false>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
                            cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       else
-        hipLaunchKernelGGL((k_preprocess<false, false>), gridP, blk, 0, st, P, K, va, means3D, scales, rotations,
+        hipLaunchKernelGGL((k_preprocess<false, false>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
                            cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
       scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st, psums64, c->total64);
@@ -588,11 +589,11 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     if (c->raw) {
       if (!pa.dsh || !pa.dsh_dc)
         return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
-      hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3((P + 255) / 256), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, pa);
     } else if (sh_lds) {
-      hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3((P + 255) / 256), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, pa);
     } else {
-      hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3((P + 255) / 256), dim3(256), 0, st, pa);
+      hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, pa);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
@@ -798,6 +799,26 @@ void gsr_profile(int32_t enable) {
   for (ProfSpan& s : g_spans) { g_free_events.push_back(s.a); g_free_events.push_back(s.b); }
   g_spans.clear();
   for (int i = 0; i < GSR_STAGE_COUNT; ++i) { g_ms[i] = 0.f; g_calls[i] = 0; }
+}
+
+int gsr_profile_timeline(float* out, int max_spans) {
+  // diagnostic: (stage, start ms, end ms) of every recorded span, relative to the first span's start; consumes them
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  hipEvent_t base = g_spans.empty() ? nullptr : g_spans[0].a;
+  for (ProfSpan& s : g_spans) {
+    if (hipEventSynchronize(s.b) != hipSuccess) break;
+    float t0 = 0.f, t1 = 0.f;
+    if (n < max_spans && out && hipEventElapsedTime(&t0, base, s.a) == hipSuccess &&
+        hipEventElapsedTime(&t1, base, s.b) == hipSuccess) {
+      out[3 * n] = (float)s.stage; out[3 * n + 1] = t0; out[3 * n + 2] = t1;
+      ++n;
+    }
+  }
+  for (ProfSpan& s : g_spans) { g_free_events.push_back(s.a); g_free_events.push_back(s.b); }
+  g_spans.clear();
+  (void)hipGetLastError();
+  return n;
 }
 
 int gsr_profile_read(float* ms, int64_t* calls) {

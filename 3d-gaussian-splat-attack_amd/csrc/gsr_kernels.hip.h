@@ -95,8 +95,14 @@ __device__ __forceinline__ void stage_sh_rows(float4* wrow, const float* sh, con
 // RAW: scales / rots / opac are the reference model's raw parameters (_scaling = log, _rotation un-normalised,
 // _opacity = logit) and the activation getters (exp, normalize, sigmoid: reference scene/gaussian_model.py:31-39,
 // 97-124) are applied here; `sh` is then _features_rest and `sh_dc` _features_dc.
+// Waves per workgroup of the two per-Gaussian kernels (K1, K8+K9).  Their waves never talk to each other (each stages
+// its own 64 rows in its own LDS slice, wave barriers only), so the workgroup is a dispatch granule, nothing more:
+// one wave + 13 KB of LDS finds room beside another stream's compositing waves far sooner than four + 53 KB.
+constexpr int PRE_WAVES = 1;
+constexpr int PRE_BLOCK = 64 * PRE_WAVES;
+
 template <bool SH_LDS, bool RAW>
-__global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, const float* __restrict__ means,
+__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, int K, ViewArgs va, const float* __restrict__ means,
                                                     const float* __restrict__ scales, const float* __restrict__ rots,
                                                     const float* __restrict__ cov3d, const float* __restrict__ opac,
                                                     const float* __restrict__ sh, const float* __restrict__ sh_dc,
@@ -104,9 +110,9 @@ __global__ void __launch_bounds__(256) k_preprocess(int P, int K, ViewArgs va, c
                                                     int32_t* __restrict__ radii, float4* __restrict__ G0,
                                                     float4* __restrict__ G1, float4* __restrict__ G2,
                                                     uint32_t* __restrict__ dkey, uint32_t* __restrict__ tcnt) {
-  __shared__ float4 srow[SH_LDS ? 4 * 64 * SHROW_F4 : 1];
+  __shared__ float4 srow[SH_LDS ? PRE_WAVES * 64 * SHROW_F4 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw0 = blockIdx.x * 256 + wave * 64;
+  const int gw0 = blockIdx.x * PRE_BLOCK + wave * 64;
   const int g = gw0 + lane;
   if (SH_LDS) {
     // all 64 rows are fetched up front (before the culls are known): issuing the big coalesced loads first and
@@ -877,10 +883,10 @@ struct PreBwdArgs {
 // parameters (chain rule of exp / normalize / sigmoid applied here) and a.dsh / a.dsh_dc receive the
 // _features_rest / _features_dc parts of the SH gradient.
 template <bool SH_LDS, bool RAW>
-__global__ void __launch_bounds__(256) k_preprocess_bwd(PreBwdArgs a) {
-  __shared__ float4 srow[SH_LDS ? 4 * 64 * SHROW_F4 : 1];
+__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
+  __shared__ float4 srow[SH_LDS ? PRE_WAVES * 64 * SHROW_F4 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw0 = blockIdx.x * 256 + wave * 64;          // first Gaussian of this wave
+  const int gw0 = blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
   const int g = gw0 + lane;
   const int K = a.K;
   float4* wrow = SH_LDS ? &srow[wave * 64 * SHROW_F4] : nullptr;

@@ -166,6 +166,10 @@ enum {
 void gsr_profile(int32_t stage_mask);
 int gsr_profile_read(float* ms, int64_t* calls);
 
+/* Diagnostic: writes (stage, start_ms, end_ms) triples of every span recorded since the last read, relative to the
+ * first span's start, into out[3 * max_spans]; returns the number written and clears the spans. */
+int gsr_profile_timeline(float* out, int max_spans);
+
 const char* gsr_last_error(void);
 
 /*
