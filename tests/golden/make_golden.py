@@ -14,6 +14,8 @@ What is captured (data only -- inputs and the reference's outputs):
   * attack.py:25-173: the ten PGD step functions applied to a small fake model with .grad set
   * scene/colmap_loader.py text readers + qvec2rotmat and the FoV / pose conversion of
     scene/dataset_readers.py:68-143 on tests/golden/colmap_sample/ (a hand-written COLMAP text model; data, not code)
+  * scene/colmap_loader.py binary readers on tests/golden/colmap_sample_bin/ (written by this script in COLMAP's
+    published binary layout, with 2D points and tracks present)
 
 Third-party modules the reference imports but this image lacks (hydra, omegaconf, plyfile,
 simple_knn, diff_gaussian_rasterization, detectors.factory's dependencies) are replaced by empty
@@ -180,6 +182,55 @@ def main():
     out["colmap_T"] = np.stack([r[3] for r in rows])
     out["colmap_fov"] = np.array([[r[4], r[5]] for r in rows])
     out["colmap_wh"] = np.array([[r[6], r[7]] for r in rows])
+
+    # ---- COLMAP binary model (scene/colmap_loader.py:125-154, :180-244) ---------------------------------------
+    # The fixture files are written here from the text sample in COLMAP's published binary layout, WITH 2D points and
+    # tracks so that readers have something to skip, then read back by the reference's binary readers.
+    import struct
+    from scene.colmap_loader import read_intrinsics_binary, read_extrinsics_binary, read_points3D_binary
+    bdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "colmap_sample_bin", "sparse", "0")
+    os.makedirs(bdir, exist_ok=True)
+    model_ids = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1}
+    with open(os.path.join(bdir, "cameras.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(intr)))
+        for c in intr.values():
+            f.write(struct.pack("<iiQQ", c.id, model_ids[c.model], c.width, c.height))
+            f.write(struct.pack("<" + "d" * len(c.params), *c.params))
+    with open(os.path.join(bdir, "images.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(extr)))
+        for j, e in enumerate(extr.values()):
+            f.write(struct.pack("<idddddddi", e.id, *e.qvec, *e.tvec, e.camera_id))
+            f.write(e.name.encode("utf-8") + b"\x00")
+            f.write(struct.pack("<Q", j))                          # j 2D points: 0 for the first image
+            for q in range(j):
+                f.write(struct.pack("<ddq", 10.5 * q, 3.25 + q, -1 if q % 2 else 7))
+    pg = torch.Generator().manual_seed(5)
+    pts = torch.randn(5, 3, generator=pg).double().numpy()
+    cols = torch.randint(0, 256, (5, 3), generator=pg).numpy()
+    errs = torch.rand(5, generator=pg).double().numpy()
+    with open(os.path.join(bdir, "points3D.bin"), "wb") as f:
+        f.write(struct.pack("<Q", 5))
+        for i in range(5):
+            f.write(struct.pack("<QdddBBBd", 100 + i, *pts[i], *[int(v) for v in cols[i]], errs[i]))
+            f.write(struct.pack("<Q", i % 3))                      # track length 0, 1, 2
+            for t in range(i % 3):
+                f.write(struct.pack("<ii", 1 + t, 4 * t))
+    bi = read_intrinsics_binary(os.path.join(bdir, "cameras.bin"))
+    be = read_extrinsics_binary(os.path.join(bdir, "images.bin"))
+    ids = sorted(bi)
+    out["colmapbin_cam_ids"] = np.array(ids)
+    out["colmapbin_cam_wh"] = np.array([[bi[k].width, bi[k].height] for k in ids])
+    out["colmapbin_cam_model"] = np.array([bi[k].model for k in ids])
+    out["colmapbin_cam_params"] = np.stack([np.pad(np.array(bi[k].params, dtype=np.float64), (0, 4 - len(bi[k].params)))
+                                            for k in ids])
+    iids = sorted(be)
+    out["colmapbin_img_ids"] = np.array(iids)
+    out["colmapbin_img_q"] = np.stack([be[k].qvec for k in iids])
+    out["colmapbin_img_t"] = np.stack([be[k].tvec for k in iids])
+    out["colmapbin_img_cam"] = np.array([be[k].camera_id for k in iids])
+    out["colmapbin_img_name"] = np.array([be[k].name for k in iids])
+    bx, bc, berr = read_points3D_binary(os.path.join(bdir, "points3D.bin"))
+    out["colmapbin_pts_xyz"], out["colmapbin_pts_rgb"], out["colmapbin_pts_err"] = bx, bc, berr.reshape(-1)
 
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays")
