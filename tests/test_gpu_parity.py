@@ -368,3 +368,28 @@ def test_strided_and_half_precision_inputs_are_accepted():
     got, _, _ = rast(means3D=strided, means2D=m2, opacities=inp["opacities"].double(), shs=inp["shs"],
                      scales=inp["scales"], rotations=inp["rotations"])
     assert torch.equal(ref, got)
+
+
+def test_lists_longer_than_the_schedule_bins():
+    """Nine tiles with 5-8 thousand entries each, low opacities so that the walk goes deep: tile lists longer than
+    the schedule's 4092-entry length bins (clamped top bin), many 64-entry batches per wave, all priority classes."""
+    from gsplat_attack.cameras import look_at_camera
+    import diff_gaussian_rasterization as D
+    g = torch.Generator().manual_seed(23)
+    P = 24000
+    xyz = torch.randn(P, 3, generator=g) * torch.tensor([0.35, 0.35, 0.6])
+    scales = torch.exp(torch.randn(P, 3, generator=g) * 0.5 + math.log(0.05))
+    rots = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
+    opac = torch.sigmoid(torch.randn(P, 1, generator=g) - 4.0)          # ~0.02: transmittance stays above 1e-4 for long
+    shs = torch.randn(P, 16, 3, generator=g) * 0.3
+    inp = dict(means3D=xyz, shs=shs, opacities=opac, scales=scales, rotations=rots)
+    cam = look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), fovx=0.5, width=48, height=48)
+    check(inp, cam, torch.tensor([0.2, 0.1, 0.3]), frag_frac=2e-2, elem_frac=3e-3)
+    # the lists really are that long
+    dev = torch.device("cuda:0")
+    st = settings_for(cam, torch.zeros(3), 3, 1.0, cls=D.GaussianRasterizationSettings, device=dev)
+    color, _, _ = D.GaussianRasterizer(raster_settings=st)(
+        means3D=xyz.to(dev).requires_grad_(True), means2D=torch.zeros(P, 3, device=dev), opacities=opac.to(dev), shs=shs.to(dev),
+        scales=scales.to(dev), rotations=rots.to(dev))
+    rg = D.export_state(color, "ranges").view(-1, 2).long()
+    assert int((rg[:, 1] - rg[:, 0]).max()) > 4092
