@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--norm", default="l2")
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--epsilon", type=float, default=5.0)
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the rank's views are pipelined over")
     args = ap.parse_args()
     from .scenes import make_scene
     rank, world, local = gdist.init_from_env()
@@ -151,7 +152,7 @@ def main():
                                    n_views=max(args.views, 1))
     recs = []
     hist = pgd_attack(model, cams[:args.views], iters=args.iters, alpha=args.alpha, epsilon=args.epsilon,
-                      groups=args.groups.split(","), norm=args.norm, log=recs.append)
+                      groups=args.groups.split(","), norm=args.norm, log=recs.append, streams=args.streams)
     if rank == 0:
         secs = [r["seconds"] for r in recs[2:]] or [r["seconds"] for r in recs]
         print(json.dumps({"scene": spec.name, "P": int(model.get_xyz.shape[0]), "views": args.views, "gpus": world,
