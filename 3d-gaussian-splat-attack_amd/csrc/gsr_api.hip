@@ -263,6 +263,7 @@ void gsr_ctx_free(GsrCtx* c) {
 // sh_dc is _features_dc (K must be 16); activations and their chain rule run inside K1 / K9.
 // diagnostic: device buffer [ntiles][2] that the next backward composites stamp with their waves' start/end clocks
 static std::atomic<unsigned long long*> g_wave_clock{nullptr};
+static std::atomic<unsigned long long*> g_wave_clock_fwd{nullptr};
 
 static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
                         const float* sh_dc, const float* sh_objs, const float* colors_precomp, const float* opacities,
@@ -460,6 +461,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     static const int map_mode_f = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 3; return (v >= 0 && v <= 3) ? v : 3; }();
     ra.map_mode = map_mode_f;
     ra.sched = c->sched;
+    ra.wave_clock = g_wave_clock_fwd.load();
     if (map_mode_f == 3) hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
@@ -755,6 +757,11 @@ int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* strea
 
 int gsr_debug_wave_clock(unsigned long long* buf) {
   g_wave_clock.store(buf);
+  return GSR_OK;
+}
+
+int gsr_debug_wave_clock_fwd(unsigned long long* buf) {
+  g_wave_clock_fwd.store(buf);
   return GSR_OK;
 }
 

@@ -316,6 +316,7 @@ struct RenderArgs {
   float* out_objects;     // [16,H,W] or null
   float* final_T;         // [H*W]
   uint32_t* n_contrib;    // [H*W]
+  unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock_fwd): [ntiles * NSUB][2] start/end, 100 MHz
 };
 
 constexpr int PXL = 4;   // pixels per lane
@@ -438,6 +439,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)x;
   int y[NPX];
@@ -526,6 +528,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
 #pragma unroll

@@ -177,6 +177,8 @@ const char* gsr_last_error(void);
  * stamps the 100 MHz wall clock at which each tile's wave started and ended; pass NULL to stop.  Process-wide.
  */
 int gsr_debug_wave_clock(unsigned long long* buf);
+/* Same for the forward composite (K6): [ntiles * waves per tile][2]. */
+int gsr_debug_wave_clock_fwd(unsigned long long* buf);
 
 /* Test hooks (used by tests/ only): the scan and sort primitives of the binning stage on caller buffers.
  * gsr_test_scan: out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total), uint32.

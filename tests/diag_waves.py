@@ -1,4 +1,5 @@
-"""Diagnostic (not a test): per-tile wave start/end clocks of the backward composite (K7) on the benchmark scene."""
+"""Diagnostic (not a test): per-wave start/end clocks of the backward composite (K7; `fwd` argument: of K6) on the
+benchmark scene."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(__file__))
 import conftest  # noqa
@@ -23,17 +24,29 @@ img = out["render"]
 rg = D.export_state(img, "ranges").view(-1, 2).long().cpu()
 ln = (rg[:, 1] - rg[:, 0])
 nt = ln.numel()
-clk = torch.zeros(nt, 2, dtype=torch.int64, device=dev)
-lib.gsr_debug_wave_clock(ctypes.c_void_p(clk.data_ptr()))
-img.backward(gc)
-torch.cuda.synchronize()
-lib.gsr_debug_wave_clock(None)
+FWD = len(sys.argv) > 1 and sys.argv[1] == "fwd"
+if FWD:
+    lib.gsr_debug_wave_clock_fwd.argtypes = [ctypes.c_void_p]
+    clk = torch.zeros(2 * nt, 2, dtype=torch.int64, device=dev)
+    lib.gsr_debug_wave_clock_fwd(ctypes.c_void_p(clk.data_ptr()))
+    out2 = render(cam, model, pipe, bg)
+    torch.cuda.synchronize()
+    lib.gsr_debug_wave_clock_fwd(None)
+    ln = ln.repeat_interleave(2)
+    nt = 2 * nt
+else:
+    clk = torch.zeros(nt, 2, dtype=torch.int64, device=dev)
+    lib.gsr_debug_wave_clock(ctypes.c_void_p(clk.data_ptr()))
+    img.backward(gc)
+    torch.cuda.synchronize()
+    lib.gsr_debug_wave_clock(None)
+SLOTS = 8192 if FWD else 5120
 c = clk.cpu().double() / 100.0          # microseconds
 t0 = c[:, 0].min()
 start, end = c[:, 0] - t0, c[:, 1] - t0
 dur = end - start
 print(f"tiles {nt}  kernel span {end.max():.1f} us   wave duration: mean {dur.mean():.1f} p50 {dur.median():.1f} p99 {dur.quantile(0.99):.1f} max {dur.max():.1f} us")
-print(f"sum of wave durations / (4096 slots x span) = {dur.sum() / (4096 * end.max()):.3f}")
+print(f"sum of wave durations / ({SLOTS} slots x span) = {dur.sum() / (SLOTS * end.max()):.3f}")
 order = torch.argsort(ln, descending=True)
 print("longest lists: len, start, end, dur, us/entry")
 for t in order[:8].tolist():
