@@ -20,8 +20,8 @@ What is captured (data only -- inputs and the reference's outputs):
 Third-party modules the reference imports but this image lacks (hydra, omegaconf, plyfile,
 simple_knn, diff_gaussian_rasterization, detectors.factory's dependencies) are replaced by empty
 stand-in modules *for the import only*; none of their functionality is used by the captured functions.
-Functions that hard-code device="cuda" (utils/general_utils.py:64-110) cannot run here and are
-followed by reading only.
+Functions that hard-code device="cuda" (utils/general_utils.py:64-110, reached through
+GaussianModel.get_covariance) run with torch.zeros redirected to the CPU for the duration of the call.
 """
 import os
 import sys
@@ -124,6 +124,22 @@ def main():
     out["gm_get_features"] = gm.get_features.numpy()
     out["gm_get_objects"] = gm.get_objects.numpy()
     out["gm_get_xyz"] = gm.get_xyz.numpy()
+    # get_covariance -> utils/general_utils.py:64-110, whose three helpers allocate with a hard-coded device="cuda".
+    # For this call only, torch.zeros is given a wrapper that sends that device request to the CPU; the arithmetic
+    # executed is the reference's own.
+    _zeros = torch.zeros
+
+    def _zeros_cpu(*a, **k):
+        if str(k.get("device", "")) == "cuda":
+            k["device"] = "cpu"
+        return _zeros(*a, **k)
+    torch.zeros = _zeros_cpu
+    try:
+        for i, mod in enumerate((1.0, 1.3)):
+            out[f"gm_get_covariance_{i}"] = gm.get_covariance(mod).numpy()
+    finally:
+        torch.zeros = _zeros
+    out["gm_covariance_mods"] = np.array([1.0, 1.3])
 
     # ---- PGD step functions (attack.py:25-173) ----------------------------
     class Fake:
