@@ -564,28 +564,6 @@ __device__ __forceinline__ float wave_sum_to_hi(float v) {
   v += dpp_mov<0x143, 0xC>(v);   // row_bcast31 into rows 2,3
   return v;
 }
-// Packed reduction steps (gfx950 lane-swap instructions).  v_permlane32_swap exchanges the upper half of one
-// register with the lower half of another, v_permlane16_swap the odd 16-lane rows of one with the even rows
-// of the other; adding the two registers afterwards leaves value a (summed over the partner lanes) in one
-// half / the even rows and value b in the other: two live values leave each step in ONE register.
-// (The clang builtin returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the
-// VALU-write -> permlane-read wait states, which hipcc does not insert around asm.)
-__device__ __forceinline__ float pack_half(float a, float b) {   // lanes <32: a[l]+a[l+32]; lanes >=32: b[l-32]+b[l]
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-__device__ __forceinline__ float pack_row(float a, float b) {    // even rows: a[row]+a[row+1]; odd rows: b[row-1]+b[row]
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-// sum over the 16 lanes of each row; every lane of the row ends with the row's total
-__device__ __forceinline__ float row_sum(float v) {
-  v += dpp_mov<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141, 0xF>(v);   // row_half_mirror
-  v += dpp_mov<0x140, 0xF>(v);   // row_mirror
-  return v;
-}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -793,6 +771,10 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         float a2 = sqyy, b2 = dop;                       // values 4,5 : S q dy^2  | S G dL/dalpha
         float a3 = dr, b3 = dg;                          // values 6,7
         float a4 = db, b4 = 0.f;                         // values 8,9
+        // v_permlane32_swap exchanges the upper half of one register with the lower half of another: adding the
+        // two afterwards leaves value a (summed over lanes l, l+32) in lanes < 32 and value b in lanes >= 32.  (The
+        // clang builtin returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the
+        // VALU-write -> permlane-read wait states, which hipcc does not insert around asm.)
         asm volatile("s_nop 1\n\t"
                      "v_permlane32_swap_b32 %0, %5\n\t"
                      "v_permlane32_swap_b32 %1, %6\n\t"
