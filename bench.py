@@ -84,8 +84,8 @@ def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="nyc-1M")
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (parity-size runs)")
     ap.add_argument("--width", type=int, default=None)
