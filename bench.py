@@ -81,6 +81,52 @@ def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
                       f"{sample_W}x{sample_H} (N={out.num_rendered} pairs); not extrapolated to 1M/1080p"}
 
 
+def parity_and_cfg1(dev) -> dict:
+    """Second half of BASELINE.json's metric, measured in the same job: the HIP path against oracle-R (float64, the
+    checker) on S-hydrant-1k @128x128 (BASELINE config 1), plus oracle-R's float32 CPU time on that config (median of
+    5 after one warm-up)."""
+    import math
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.scenes import make_scene
+    from oracle import oracle_r as O
+    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=1)
+    cam = cams[0]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    gc = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(99))
+    out = render(cam, model, PipelineParams(skip_objects=True), bg)
+    out["render"].backward(gc.to(dev))
+    torch.cuda.synchronize()
+    cpu = lambda t: t.detach().cpu()
+    st = O.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), cpu(bg), 1.0,
+                    cpu(cam.world_view_transform), cpu(cam.full_proj_transform), 3, cpu(cam.camera_center), False, False)
+    ref, _, _ = make_scene("hydrant-1k", device="cpu", n_views=1)
+    ro = O.rasterize(ref.get_xyz, None, ref.get_opacity, st, shs=ref.get_features, scales=ref.get_scaling,
+                     rotations=ref.get_rotation)
+    (ro.color * gc.double()).sum().backward()
+    solid = ~ro.fragile_px
+    rgb = (cpu(out["render"]).double() - ro.color.detach()).abs().max(dim=0).values[solid].max().item()
+    rel = 0.0
+    for p_hip, p_ref in zip(model.parameters(), ref.parameters()):
+        if p_ref.grad is None or p_hip.grad is None or p_ref.grad.abs().max().item() == 0.0:
+            continue
+        rel = max(rel, ((cpu(p_hip.grad).double() - p_ref.grad).abs().max() / p_ref.grad.abs().max()).item())
+    inp = dict(means3D=ref.get_xyz.detach(), shs=ref.get_features.detach(), opacities=ref.get_opacity.detach(),
+               scales=ref.get_scaling.detach(), rotations=ref.get_rotation.detach())
+    st32 = O.Settings(st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.bg.float(), 1.0, st.viewmatrix,
+                      st.projmatrix, 3, st.campos, False, False)
+    times = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        O.forward_backward(inp, st32, gc, dtype=torch.float32)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[2]
+    return {"parity": {"scene": "S-hydrant-1k 128x128 (BASELINE config 1) vs oracle-R float64",
+                       "rgb_max_abs_err": rgb, "grad_max_rel_err": rel,
+                       "tolerance": {"rgb_abs": 1e-4, "grad_rel": 1e-3}},
+            "cfg1_cpu": {"value": 1.0 / med, "unit": "views/s", "seconds_median_of_5": med,
+                         "sample": "oracle-R float32 fwd+bwd, S-hydrant-1k 128x128"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +142,7 @@ def main():
                     help="HIP streams the views are dealt over (view i runs on stream i %% S): the small sort/scan "
                          "kernels of one view overlap the compositing kernels of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed forward-only / PGD-iteration extras")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
     args = ap.parse_args()
 
@@ -273,10 +320,43 @@ def main():
         }
         if valu is not None:
             result["roofline"]["valu"] = valu
+        if world == 1 and not args.no_extras:
+            # SURVEY.md section 8d "also report": forward-only rate and one PGD iteration (untimed extras)
+            log("extras: forward-only views, PGD iterations ...")
+            from gsplat_attack.attack import pgd_attack
+            with torch.no_grad():
+                run_fwd = min(args.steps, 100)
+                for s_ in (streams or []):
+                    s_.wait_stream(torch.cuda.current_stream(dev))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(run_fwd):
+                    if streams is None:
+                        render(cam, model, pipe, bg)
+                    else:
+                        with torch.cuda.stream(streams[i % len(streams)]):
+                            render(cam, model, pipe, bg)
+                torch.cuda.synchronize()
+                fwd_rate = run_fwd / (time.perf_counter() - t0)
+            recs = []
+            pgd_model = model.clone()
+            pgd_attack(pgd_model, cams[:8], iters=6, groups=("color", "position", "scaling", "rotation", "opacity"),
+                       log=recs.append, streams=max(args.streams, 1))
+            pgd_ms = 1e3 * sorted(r["seconds"] for r in recs[2:])[len(recs[2:]) // 2]
+            del pgd_model
+            result["extras"] = {"fwd_only_views_per_s": round(fwd_rate, 1),
+                                "pgd_iteration_ms": round(pgd_ms, 3),
+                                "pgd_iteration": "8 views x (fwd+bwd) + surrogate detector loss + step on "
+                                                 "{colour, position, scaling, rotation, opacity}, one GPU"}
         if world == 1 and not args.no_cpu_baseline:
             sp, sw, sh = (int(x) for x in args.cpu_sample.split(","))
             log(f"cpu baseline (oracle-R) on a {sp}-Gaussian {sw}x{sh} sample ...")
             result["cpu_baseline"] = cpu_baseline(sp, sw, sh)
+            log("parity vs oracle-R and CPU time on BASELINE config 1 ...")
+            extra = parity_and_cfg1(dev)
+            result["cpu_baseline"]["cfg1"] = extra["cfg1_cpu"]
+            result["grad_max_rel_err_vs_ref"] = extra["parity"]["grad_max_rel_err"]
+            result["parity"] = extra["parity"]
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
