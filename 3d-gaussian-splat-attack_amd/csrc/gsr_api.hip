@@ -21,6 +21,7 @@
 #include "gsr_kernels.hip.h"
 #include "gsr_sort.hip.h"
 #include "gsr_knn.hip.h"
+#include "gsr_pgd.hip.h"
 
 using namespace gsr;
 
@@ -688,6 +689,34 @@ void gsr_trim_pool(void) {
     else { (void)hipFree(b.p); pl.total -= b.bytes; }
   }
   pl.blocks.swap(keep);
+}
+
+int gsr_pgd_step(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,
+                 int32_t l2, void* stream) {
+  if (rows < 0 || cols < 1 || cols > PGD_MAX_COLS)
+    return set_err(GSR_ERR_INVALID, "gsr_pgd_step: rows=%lld cols=%d (1..%d columns)", (long long)rows, cols, PGD_MAX_COLS);
+  if (rows == 0) return GSR_OK;
+  if (!x || !grad || !x0) return set_err(GSR_ERR_INVALID, "gsr_pgd_step: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  const size_t n = (size_t)rows * (size_t)cols;
+  const unsigned blocks = (unsigned)((rows + 63) / 64);
+  if (!l2) {
+    hipLaunchKernelGGL((k_pgd_step<false>), dim3(blocks), dim3(64), 0, st, x, grad, x0, (size_t)rows, cols, alpha, epsilon,
+                       (const double*)nullptr, 0);
+  } else {
+    const int nb = (int)std::min<size_t>((n + 4095) / 4096, 1024);
+    void* blk = pool_alloc(dev, sizeof(double) * (size_t)nb, st);
+    if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_pgd_step: allocation failed");
+    double* partial = static_cast<double*>(blk);
+    hipLaunchKernelGGL(k_pgd_sumsq, dim3(nb), dim3(256), 0, st, grad, n, partial);
+    hipLaunchKernelGGL((k_pgd_step<true>), dim3(blocks), dim3(64), 0, st, x, grad, x0, (size_t)rows, cols, alpha, epsilon,
+                       partial, nb);
+    pool_free(dev, blk);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_pgd_step: launch failed: %s", hipGetErrorString(e));
+  return GSR_OK;
 }
 
 int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* stream) {

@@ -96,6 +96,9 @@ def _load():
     lib.gsr_profile.argtypes = [i32]
     lib.gsr_profile_read.restype = ctypes.c_int
     lib.gsr_profile_read.argtypes = [ctypes.POINTER(ctypes.c_float), i64p]
+    lib.gsr_pgd_step.restype = ctypes.c_int
+    lib.gsr_pgd_step.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_int32, vp]
     lib.gsr_test_scan.restype = ctypes.c_int
     lib.gsr_test_scan.argtypes = [vp, vp, ctypes.c_uint32, vp]
     lib.gsr_test_sort_pairs.restype = ctypes.c_int

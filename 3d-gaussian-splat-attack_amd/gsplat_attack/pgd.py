@@ -15,13 +15,41 @@ from __future__ import annotations
 import torch
 
 
+def _hip_step(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor, l2: bool) -> bool:
+    """Device tensors take the fused HIP update (libgsraster.so: gsr_pgd_step, two launches per tensor).  Returns
+    False when the tensors do not have the layout it needs (the formulation below is then used as written)."""
+    if not (x.is_cuda and grad.is_cuda and x0.is_cuda and x.dtype == grad.dtype == x0.dtype == torch.float32):
+        return False
+    if x.dim() < 1 or x.shape != grad.shape or x.shape != x0.shape or x.shape[0] == 0:
+        return False
+    rows = x.shape[0]
+    cols = x.numel() // rows
+    if cols > 48 or not (x.is_contiguous() and grad.is_contiguous() and x0.is_contiguous()):
+        return False
+    import ctypes
+    import diff_gaussian_rasterization as D
+    lib = D._load()
+    with torch.cuda.device(x.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.gsr_pgd_step(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(grad.data_ptr()), ctypes.c_void_p(x0.data_ptr()),
+                              ctypes.c_int64(rows), ctypes.c_int32(cols), ctypes.c_float(alpha), ctypes.c_float(epsilon),
+                              ctypes.c_int32(1 if l2 else 0), stream)
+    if rc != 0:
+        raise RuntimeError(lib.gsr_last_error().decode())
+    return True
+
+
 def linf_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
+    if _hip_step(x.data, grad, alpha, epsilon, x0, False):
+        return
     with torch.no_grad():
         x.add_(torch.sign(grad), alpha=-alpha)
         x.sub_(x0).clamp_(-epsilon, epsilon).add_(x0)
 
 
 def l2_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
+    if _hip_step(x.data, grad, alpha, epsilon, x0, True):
+        return
     with torch.no_grad():
         norm = torch.linalg.vector_norm(grad.reshape(-1), ord=2)
         # branch-free form of "if norm > 0 ... else zero step" (no host sync on the device path)

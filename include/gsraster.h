@@ -124,6 +124,16 @@ void gsr_ctx_free(GsrCtx* ctx);
 /* Frustum test only (view-space z > 0.2): present[P] = 1/0.  Replaces GaussianRasterizer.markVisible. */
 int gsr_mark_visible(const GsrSettings* settings, int32_t P, const float* means3D, uint8_t* present, void* stream);
 
+/*
+ * gsr_pgd_step: one projected-gradient update of a raw attribute tensor x[rows, cols] in place (reference
+ * attack.py:25-173, the ten gaussian_*_{linf,l2}_attack functions; the colour rules call it once for _features_rest
+ * [P,45] and once for _features_dc [P,3]).  l2 == 0: x += -alpha*sign(grad); x = clamp(x - x0, -eps, eps) + x0.
+ * l2 != 0: x += -alpha*grad/||grad||_2 with the norm over the whole tensor (no step when it is 0), then every ROW of
+ * x - x0 longer than eps is scaled by eps/(norm + 1e-7) (torch.renorm(p=2, dim=0, maxnorm=eps)).  cols <= 48.
+ */
+int gsr_pgd_step(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,
+                 int32_t l2, void* stream);
+
 /* Mean squared distance of every point to its 3 nearest other points (exact): replaces the reference's second native
  * import, simple_knn._C.distCUDA2 (reference scene/gaussian_model.py:17, called at :144 to seed the initial scales).
  * points [P,3] float32 device, mean_dist2 [P] float32 device.  Synchronises the stream once (scene set-up routine, not

@@ -98,3 +98,26 @@ def test_combined_scene_render_equals_render_of_the_concatenated_attributes():
         ref = render(cams[0], whole, PipelineParams(skip_objects=True), bg)["render"]
     got = render_combined(target, background, cams[:1], bg)[0]
     assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("shape", [(5000, 3), (4097, 4), (3000, 1), (2500, 15, 3), (1, 1, 3), (64, 45)])
+@pytest.mark.parametrize("kind", ["linf", "l2"])
+def test_fused_pgd_step_matches_the_tensor_formulation(shape, kind):
+    """gsr_pgd_step (HIP) against the PyTorch statement of the reference's update rules (gsplat_attack/pgd.py on CPU,
+    itself pinned to attack.py:25-173 by tests/test_golden_twins.py), including rows inside and outside the eps ball
+    and a zero gradient."""
+    from gsplat_attack import pgd
+    g = torch.Generator().manual_seed(sum(shape) + len(kind))
+    x = torch.randn(*shape, generator=g)
+    x0 = x + torch.randn(*shape, generator=g) * torch.rand(shape[0], *([1] * (len(shape) - 1)), generator=g) * 2.0
+    grad = torch.randn(*shape, generator=g) * 3.0
+    step = pgd.l2_step_ if kind == "l2" else pgd.linf_step_
+    for gr in (grad, torch.zeros_like(grad)):
+        want = x.clone()
+        step(want, gr, 0.5, 0.8, x0)                       # CPU tensors: the formulation as written
+        got = x.clone().cuda()
+        step(got, gr.cuda(), 0.5, 0.8, x0.cuda())           # device tensors: the fused kernel
+        torch.cuda.synchronize()
+        assert torch.allclose(got.cpu(), want, atol=2e-6, rtol=1e-5), (shape, kind, (got.cpu() - want).abs().max())
+        if kind == "linf":
+            assert torch.equal(got.cpu(), want)
