@@ -523,6 +523,9 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   const int P = c->P;
   if (P == 0) return GSR_OK;
   const bool obj = grad_objects != nullptr && c->sh_objs != nullptr;
+  // Only colour-side gradients wanted (SH / precomputed colours / object features): K7 and K8+K9 drop the geometry
+  // sums and the projection chain rule (the colour attack; BASELINE configs 2 and 3).
+  const bool geom = dmeans3D || dmeans2D || dopacities || dscales || drotations || dcov3D;
   const uint32_t N = c->N;
   void* part_blk = nullptr;
   void* pobj_blk = nullptr;
@@ -565,11 +568,19 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
     const dim3 gridT(render_grid(c->ntiles * (int)nsub)), blk(64);
     if (obj) {
-      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4>), gridT, blk, 0, st, ra);
-      else hipLaunchKernelGGL((k_render_bwd<true, 2>), gridT, blk, 0, st, ra);
+      if (geom) {
+        if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4, true>), gridT, blk, 0, st, ra);
+        else hipLaunchKernelGGL((k_render_bwd<true, 2, true>), gridT, blk, 0, st, ra);
+      } else {
+        if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4, false>), gridT, blk, 0, st, ra);
+        else hipLaunchKernelGGL((k_render_bwd<true, 2, false>), gridT, blk, 0, st, ra);
+      }
+    } else if (geom) {
+      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<false, 4, true>), gridT, blk, 0, st, ra);
+      else hipLaunchKernelGGL((k_render_bwd<false, 2, true>), gridT, blk, 0, st, ra);
     } else {
-      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<false, 4>), gridT, blk, 0, st, ra);
-      else hipLaunchKernelGGL((k_render_bwd<false, 2>), gridT, blk, 0, st, ra);
+      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<false, 4, false>), gridT, blk, 0, st, ra);
+      else hipLaunchKernelGGL((k_render_bwd<false, 2, false>), gridT, blk, 0, st, ra);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "render backward: launch failed: %s", hipGetErrorString(e)));
@@ -587,16 +598,20 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
+    const dim3 gridK9((unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK));
     // SH rows of 16 coefficients x 3 channels (the only layout the reference uses) go through LDS
     const bool sh_lds = c->shs != nullptr && pa.dsh != nullptr && c->K == 16;
     if (c->raw) {
       if (!pa.dsh || !pa.dsh_dc)
         return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
-      hipLaunchKernelGGL((k_preprocess_bwd<true, true>), dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, pa);
+      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      else hipLaunchKernelGGL((k_preprocess_bwd<true, true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
     } else if (sh_lds) {
-      hipLaunchKernelGGL((k_preprocess_bwd<true, false>), dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, pa);
+      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      else hipLaunchKernelGGL((k_preprocess_bwd<true, false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
     } else {
-      hipLaunchKernelGGL((k_preprocess_bwd<false, false>), dim3((P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, st, pa);
+      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<false, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      else hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));

@@ -612,15 +612,22 @@ constexpr int PART_F4 = 3;
 // OWN partial row (row = NSUB * slot + half; K8/K9 sums the NSUB rows of a pair, rows of halves the entry does not
 // reach stay stale and are skipped by their tag).  The serial walk of the longest list is the kernel's critical
 // path: halving the per-entry work of a wave shortens it, and the smaller register state lets six waves share a SIMD.
-template <bool OBJ, int NPX>
+// GEOM = false: only dL/dcolour (and dL/dobject features) is wanted -- the colour attack, BASELINE configs 2 and 3.
+// The walk then keeps T and the blend weight only (no running colour term, no dL/dalpha, no conic / mean / opacity
+// sums): three sums per entry instead of nine, two parked registers instead of five, eight entries per transposed sum.
+template <bool OBJ, int NPX, bool GEOM>
 __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   constexpr int NSUB = PXL / NPX;
+  constexpr int NREG = GEOM ? 5 : 2;              // registers parked per contributing entry
+  constexpr int RB = GEOM ? RED_B : 8;            // entries between two transposed sums (RB * 4 * NREG <= 64 lanes)
+  constexpr int RENTRY = NREG * RED_REG;
+  constexpr int TAGV = GEOM ? 9 : 3;              // the unused last value: its two lanes stamp the tag words
   __shared__ float4 s0[64];
   __shared__ float4 s1[64];
   __shared__ float2 s2[64];
   __shared__ uint32_t sslot[64];
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
-  __shared__ __attribute__((aligned(16))) float sred[RED_B * RED_ENTRY];
+  __shared__ __attribute__((aligned(16))) float sred[RB * RENTRY];
   const int lane = threadIdx.x;
   int item;
   if (a.map_mode == 3) {
@@ -638,9 +645,10 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
   const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
-  const int red_e = lane / 20, red_v = 2 * ((lane % 20) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
-  // row word this lane stores (value 9 is the unused tenth sum: its two lanes stamp the tag words 9 and 10)
-  const int red_word = red_v == 9 ? 9 + red_sub : (red_sub == 0 ? red_v : -1);
+  const int red_e = lane / (4 * NREG), red_v = 2 * ((lane % (4 * NREG)) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
+  // row word this lane stores (the unused last value's two lanes stamp the tag words 9 and 10; without the geometry
+  // sums the three colour sums still go to their usual words 6..8)
+  const int red_word = red_v == TAGV ? 9 + red_sub : (red_sub == 0 ? red_v + (GEOM ? 0 : 6) : -1);
   const float red_tag = __uint_as_float(red_sub ? a.tag_hi : a.tag_lo);
   int red_j = 0;       // lane b: batch index j of the b-th parked entry
   int red_n = 0;       // parked entries (wave uniform)
@@ -745,32 +753,37 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
             const float inv1m = __builtin_amdgcn_rcpf(1.f - ae);
             T[k] *= inv1m;
             const float w = ae * T[k];
-            float cg = fmaf(e1.z, g0[k], fmaf(e1.w, g1[k], e2.x * g2[k]));
+            dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
             if (OBJ) {
 #pragma unroll
-              for (int c = 0; c < NUM_OBJ; ++c) {
-                cg = fmaf(so[j][c], gO[k][c], cg);
-                dobj[c] = fmaf(w, gO[k][c], dobj[c]);
-              }
+              for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = fmaf(w, gO[k][c], dobj[c]);
             }
-            const float dcg = cg - Acc[k];
-            const float dLda = valid ? T[k] * dcg : 0.f;
-            Acc[k] = fmaf(ae, dcg, Acc[k]);                  // ae*cg + (1-ae)*Acc: now includes this entry
-            dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
-            dop = fmaf(G, dLda, dop);
-            const float q = oG * dLda;
-            const float qy = q * dy;
-            sq += q; sqy += qy; sqyy = fmaf(qy, dy, sqyy);
+            if (GEOM) {
+              float cg = fmaf(e1.z, g0[k], fmaf(e1.w, g1[k], e2.x * g2[k]));
+              if (OBJ) {
+#pragma unroll
+                for (int c = 0; c < NUM_OBJ; ++c) cg = fmaf(so[j][c], gO[k][c], cg);
+              }
+              const float dcg = cg - Acc[k];
+              const float dLda = valid ? T[k] * dcg : 0.f;
+              Acc[k] = fmaf(ae, dcg, Acc[k]);                  // ae*cg + (1-ae)*Acc: now includes this entry
+              dop = fmaf(G, dLda, dop);
+              const float q = oG * dLda;
+              const float qy = q * dy;
+              sq += q; sqy += qy; sqyy = fmaf(qy, dy, sqyy);
+            }
           }
         }
       }
       if (hit) {
         // nine per-lane sums -> five registers (lanes < 32: value 2n, lanes >= 32: value 2n+1), parked in LDS
+        float a3 = dr, b3 = dg;                          // values 6,7  (colour only: values 0,1)
+        float a4 = db, b4 = 0.f;                         // values 8,9  (colour only: values 2,3)
+        float* w = &sred[red_n * RENTRY + red_wofs];
+        if (GEOM) {
         float a0 = sq * dx, b0 = sqy;                    // values 0,1 : S q dx    | S q dy
         float a1 = a0 * dx, b1 = sqy * dx;               // values 2,3 : S q dx^2  | S q dx dy
         float a2 = sqyy, b2 = dop;                       // values 4,5 : S q dy^2  | S G dL/dalpha
-        float a3 = dr, b3 = dg;                          // values 6,7
-        float a4 = db, b4 = 0.f;                         // values 8,9
         // v_permlane32_swap exchanges the upper half of one register with the lower half of another: adding the
         // two afterwards leaves value a (summed over lanes l, l+32) in lanes < 32 and value b in lanes >= 32.  (The
         // clang builtin returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the
@@ -782,8 +795,14 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
                      "v_permlane32_swap_b32 %3, %8\n\t"
                      "v_permlane32_swap_b32 %4, %9"
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
-        float* w = &sred[red_n * RED_ENTRY + red_wofs];
         w[0] = a0 + b0; w[RED_REG] = a1 + b1; w[2 * RED_REG] = a2 + b2; w[3 * RED_REG] = a3 + b3; w[4 * RED_REG] = a4 + b4;
+        } else {
+          asm volatile("s_nop 1\n\t"
+                       "v_permlane32_swap_b32 %0, %2\n\t"
+                       "v_permlane32_swap_b32 %1, %3"
+                       : "+v"(a3), "+v"(a4), "+v"(b3), "+v"(b4));
+          w[0] = a3 + b3; w[RED_REG] = a4 + b4;
+        }
         red_j = lane == red_n ? j : red_j;
         ++red_n;
         if (OBJ) {
@@ -799,7 +818,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         }
       }
       }
-      if (red_n == RED_B || (j == 0 && red_n > 0)) {     // sslot[] is re-staged after j == 0: drain before that
+      if (red_n == RB || (j == 0 && red_n > 0)) {     // sslot[] is re-staged after j == 0: drain before that
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -814,7 +833,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
             float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[jm] * PART_F4);
             // words 9 and 10 carry this backward call's 64-bit tag: rows that no wave writes keep whatever the
             // workspace held and are recognised as stale by K8/K9, so the partial-row buffer is never cleared
-            row[red_word] = red_v == 9 ? red_tag : t;
+            row[red_word] = red_v == TAGV ? red_tag : t;
           }
         }
         red_n = 0;
@@ -867,7 +886,9 @@ struct PreBwdArgs {
 // RAW: inputs are the raw parameters as in k_preprocess<.,true>; the gradients written are those of the raw
 // parameters (chain rule of exp / normalize / sigmoid applied here) and a.dsh / a.dsh_dc receive the
 // _features_rest / _features_dc parts of the SH gradient.
-template <bool SH_LDS, bool RAW>
+// GEOM = false: the rows carry the three colour sums only (K7 without the geometry sums) and only the SH / colour /
+// object-feature gradients are produced.
+template <bool SH_LDS, bool RAW, bool GEOM>
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   __shared__ float4 srow[SH_LDS ? PRE_WAVES * 64 * SHROW_F4 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -899,7 +920,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
           const float4* r = &wrow[(e - c0) * PART_F4];
           const float4 p0 = r[0], p1 = r[1], p2 = r[2];
           if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-          mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+          if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
+          dr += p1.z; dg += p1.w; db += p2.x;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -915,7 +937,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
       for (uint32_t e = b0 + lane; e < b1; e += 64) {
         const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
         if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-        t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w; t[4] += p1.x; t[5] += p1.y; t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
+        if (GEOM) { t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w; t[4] += p1.x; t[5] += p1.y; }
+        t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
       }
 #pragma unroll
       for (int i = 0; i < 9; ++i) t[i] = __shfl(wave_sum_to_hi(t[i]), 63, 64);
@@ -949,7 +972,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
         for (uint32_t e = o0; e < o1; ++e) {
           const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
           if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-          mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; dr += p1.z; dg += p1.w; db += p2.x;
+          if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
+          dr += p1.z; dg += p1.w; db += p2.x;
         }
       }
       if (a.dsh_objs) {
@@ -978,8 +1002,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
       const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
       const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
       const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
-      if (a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
-      if (a.dopac) a.dopac[g] = RAW ? dop * e1.y * (1.f - e1.y) : dop;   // e1.y = sigmoid(raw opacity)
+      if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
+      if (GEOM && a.dopac) a.dopac[g] = RAW ? dop * e1.y * (1.f - e1.y) : dop;   // e1.y = sigmoid(raw opacity)
       const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
       float dp[3] = {0.f, 0.f, 0.f};
       if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
@@ -996,6 +1020,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
           sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
         }
       }
+      if (GEOM) {
       float c6[6];
       float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
       float inv_qn = 1.f;
@@ -1026,6 +1051,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
         }
         if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
         if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+      }
       }
     }
   }

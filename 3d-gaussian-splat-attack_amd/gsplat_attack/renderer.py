@@ -20,7 +20,7 @@ class PipelineParams:
     """The three switches render() reads (reference attack.py:254-256, configs/config.yaml:61-63)."""
 
     def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False,
-                 skip_objects: bool = False, fused_activations: bool = True):
+                 skip_objects: bool = False, fused_activations: bool = True, viewspace_grad: bool = True):
         self.convert_SHs_python = convert_SHs_python
         self.compute_cov3D_python = compute_cov3D_python
         self.debug = debug
@@ -30,6 +30,10 @@ class PipelineParams:
         # extension (default off = reference behaviour): do not composite the 16 object-feature channels,
         # which the attack never reads (``render_object`` is then all zeros)
         self.skip_objects = skip_objects
+        # extension (default on = reference behaviour): `viewspace_points` receives the screen-space gradient.  A
+        # colour-only attack turns it off (and freezes the geometry parameters): the backward then runs without the
+        # geometry sums and the projection chain rule (BASELINE configs 2 and 3)
+        self.viewspace_grad = viewspace_grad
 
 
 def _has_raw_layout(pc) -> bool:
@@ -45,7 +49,7 @@ def _has_raw_layout(pc) -> bool:
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     # The reference builds `zeros_like(...) + 0` and calls retain_grad() on that non-leaf (:25-29); a zero LEAF gives
     # callers the same thing (values 0, .grad filled by backward) without an add kernel and a gradient copy per view.
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=bool(getattr(pipe, "viewspace_grad", True)))
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--objects", action="store_true", help="composite the 16 object channels too")
+    ap.add_argument("--color-only", action="store_true",
+                    help="gradients on the SH coefficients only (BASELINE configs 2/3): geometry parameters frozen")
     ap.add_argument("--no-cull", action="store_true", help="keep the full 3-sigma tile rects (A/B of the footprint cull)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the views are dealt over (view i runs on stream i %% S): the small sort/scan "
@@ -170,7 +172,10 @@ def main():
     cam = cams[rank % n_views]
     H, W = cam.image_height, cam.image_width
     P = model.get_xyz.shape[0]
-    pipe = PipelineParams(skip_objects=not args.objects)
+    pipe = PipelineParams(skip_objects=not args.objects, viewspace_grad=not args.color_only)
+    if args.color_only:
+        for n_ in ("_xyz", "_scaling", "_rotation", "_opacity", "_objects_dc"):
+            getattr(model, n_).requires_grad_(False)
     bg = torch.zeros(3, device=dev)
     gc = torch.randn(3, H, W, generator=torch.Generator().manual_seed(99)).to(dev)
 
@@ -299,7 +304,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{spec.name}: {P} Gaussians (SH degree 3), {W}x{H}, one view per step per GPU, "
                                    "render() fwd + bwd to all attribute grads"
-                                   + (", 16 object channels on" if args.objects else ", object channels off"),
+                                   + (", 16 object channels on" if args.objects else ", object channels off")
+                                   + (", gradients on SH coefficients only" if args.color_only else ""),
                        "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
                        "streams": args.streams,
                        "parallelism": f"views sharded 1/GPU, dp{world}"

@@ -393,3 +393,69 @@ def test_lists_longer_than_the_schedule_bins():
         scales=scales.to(dev), rotations=rots.to(dev))
     rg = D.export_state(color, "ranges").view(-1, 2).long()
     assert int((rg[:, 1] - rg[:, 0]).max()) > 4092
+
+
+@pytest.mark.parametrize("scene,kw", [("hydrant-1k", {}), ("nyc-1M", dict(P=20000, width=320, height=180))])
+def test_colour_only_backward_equals_the_colour_part_of_the_full_backward(scene, kw):
+    """Geometry parameters frozen (requires_grad False) and no screen-space gradient wanted: K7 / K8+K9 run without the
+    geometry sums.  The SH gradients must be those of the full backward (the DC band bitwise: same sums, same order),
+    through both the fused raw-parameter path and the classic activated-tensor path."""
+    from gsplat_attack.renderer import PipelineParams, render
+    D = _hip()
+    dev = torch.device("cuda:0")
+    model, cams, _ = _scene(scene, device=dev, n_views=1, **kw)
+    cam = cams[0]
+    bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
+    gc = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5)).to(dev)
+    for fused in (True, False):
+        model.zero_grad()
+        for p in model.parameters():
+            p.requires_grad_(True)
+        out = render(cam, model, PipelineParams(skip_objects=True, fused_activations=fused), bg)
+        out["render"].backward(gc)
+        full = (model._features_dc.grad.clone(), model._features_rest.grad.clone())
+        img_full = out["render"].detach().clone()
+        model.zero_grad()
+        for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_objects_dc"):
+            getattr(model, n).requires_grad_(False)
+        out = render(cam, model, PipelineParams(skip_objects=True, fused_activations=fused, viewspace_grad=False), bg)
+        out["render"].backward(gc)
+        torch.cuda.synchronize()
+        assert torch.equal(out["render"].detach(), img_full)
+        assert model._xyz.grad is None and model._opacity.grad is None
+        assert torch.equal(model._features_dc.grad, full[0]), fused          # same sums, same order
+        # the higher SH bands go through sh_to_rgb_bwd, which the compiler contracts into FMAs differently once the
+        # position gradient it also produces is dead code: last-bit differences only
+        scale = full[1].abs().max().item()
+        assert (model._features_rest.grad - full[1]).abs().max().item() <= 1e-6 * scale, fused
+    for p in model.parameters():
+        p.requires_grad_(True)
+
+
+def test_colour_only_backward_with_precomputed_colours_and_objects():
+    """colors_precomp + object features as the only differentiable inputs (geometry tensors plain): gradients equal
+    those of the full backward."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    model, cams, _ = _scene(n_views=1)
+    cam = cams[0]
+    inp = model_inputs(model)
+    P = inp["means3D"].shape[0]
+    g = torch.Generator().manual_seed(3)
+    cols = torch.rand(P, 3, generator=g)
+    gc = torch.randn(3, cam.image_height, cam.image_width, generator=g).to(dev)
+    go = torch.randn(O.NUM_OBJECTS, cam.image_height, cam.image_width, generator=g).to(dev) * 0.3
+    st = settings_for(cam, torch.zeros(3), 3, 1.0, cls=D.GaussianRasterizationSettings, device=dev)
+    res = []
+    for geom in (True, False):
+        t = {k: inp[k].to(dev).clone().requires_grad_(geom) for k in ("means3D", "opacities", "scales", "rotations")}
+        c = cols.to(dev).clone().requires_grad_(True)
+        ob = inp["sh_objs"].to(dev).clone().requires_grad_(True)
+        color, _, objects = D.GaussianRasterizer(raster_settings=st)(
+            means3D=t["means3D"], means2D=torch.zeros(P, 3, device=dev, requires_grad=geom), opacities=t["opacities"],
+            colors_precomp=c, sh_objs=ob, scales=t["scales"], rotations=t["rotations"])
+        ((color * gc).sum() + (objects * go).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((c.grad.clone(), ob.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
