@@ -270,8 +270,8 @@ def main():
         valu = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            kern = {"render_bwd": "void gsr::k_render_bwd<false, 4>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
-                    "preprocess_bwd": "void gsr::k_preprocess_bwd<true, true>",
+            kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
+                    "preprocess_bwd": "void gsr::k_preprocess_bwd<true, true, true>",
                     "preprocess": "void gsr::k_preprocess<true, true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
