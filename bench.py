@@ -218,11 +218,12 @@ def main():
     # Timed region: only the dominant kernel stage (K7, the backward composite) is bracketed by HIP events on the
     # launch stream -- two event records per step; bracketing all seven stages costs ~10 us of queue gap each.
     DOMINANT = "render_bwd"
+    if streams is not None:
+        run_steps(2 * len(streams))          # untimed: lets every stream build its own workspace blocks
+        torch.cuda.synchronize()
     D.profile(True, stages=[DOMINANT])
     if world > 1:
         dist.barrier()
-    if streams is not None:
-        run_steps(2 * len(streams))          # untimed: lets every stream build its own workspace blocks
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps)
