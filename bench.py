@@ -155,7 +155,12 @@ def main():
     from gsplat_attack.scenes import make_scene
     import diff_gaussian_rasterization as D
 
-    rank, world, local = gdist.init_from_env("nccl")
+    # BENCH_REHEARSE_GLOO=1: rehearsal of the N > 1 code path on a box with ONE GPU (every rank on cuda:0, gloo
+    # collectives through the host) -- checks the distributed logic, measures nothing meaningful
+    rehearse = os.environ.get("BENCH_REHEARSE_GLOO", "0") == "1"
+    rank, world, local = gdist.init_from_env("gloo" if rehearse else "nccl")
+    if rehearse:
+        local = 0
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local)
