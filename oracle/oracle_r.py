@@ -408,7 +408,8 @@ def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, 
     loss = (out.color * grad_color.to(dtype)).sum()
     if grad_objects is not None:
         loss = loss + (out.objects * grad_objects.to(dtype)).sum()
-    loss.backward()
+    if loss.requires_grad:          # nothing visible: the image is the background, every gradient is zero
+        loss.backward()
     grads = {k: (v.grad if v is not None and v.grad is not None else
                  (torch.zeros_like(v) if v is not None else None)) for k, v in leaf.items()}
     grads["means2D"] = m2d.grad if m2d.grad is not None else torch.zeros_like(m2d)

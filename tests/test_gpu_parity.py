@@ -459,3 +459,34 @@ def test_colour_only_backward_with_precomputed_colours_and_objects():
         res.append((c.grad.clone(), ob.grad.clone()))
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
+def test_random_configurations(seed):
+    """Seeded random draws of everything a caller chooses: Gaussian count (1 .. 4000), image size (not a multiple of
+    the tile size, down to less than one tile), field of view, camera pose (inside / outside the cloud), background,
+    active SH degree, scale modifier, opacity and scale distributions, object features on or off."""
+    from gsplat_attack.cameras import look_at_camera
+    g = torch.Generator().manual_seed(seed)
+
+    def u(lo, hi):
+        return lo + (hi - lo) * torch.rand((), generator=g).item()
+    P = int(round(math.exp(u(0.0, math.log(4000.0)))))
+    W, H = int(u(9, 230)), int(u(9, 170))
+    xyz = torch.randn(P, 3, generator=g) * torch.tensor([u(0.1, 0.6), u(0.1, 0.6), u(0.1, 0.6)])
+    scales = torch.exp(torch.randn(P, 3, generator=g) * u(0.2, 0.9) + math.log(u(0.01, 0.12)))
+    rots = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
+    opac = torch.sigmoid(torch.randn(P, 1, generator=g) * u(0.5, 3.0) + u(-2.0, 2.0))
+    shs = torch.randn(P, 16, 3, generator=g) * u(0.05, 0.5)
+    shs[:, 0] += torch.randn(P, 3, generator=g)
+    inp = dict(means3D=xyz, shs=shs, opacities=opac, scales=scales, rotations=rots)
+    with_objs = seed % 2 == 0
+    if with_objs:
+        inp["sh_objs"] = torch.randn(P, 1, 16, generator=g) * 0.3
+    dist = u(0.3, 3.5)                                   # 0.3: the camera sits inside the cloud (near-plane culls)
+    th, ph = u(0, 2 * math.pi), u(-0.6, 0.6)
+    eye = (dist * math.cos(th) * math.cos(ph), dist * math.sin(ph), dist * math.sin(th) * math.cos(ph))
+    cam = look_at_camera(eye, (u(-0.1, 0.1), u(-0.1, 0.1), u(-0.1, 0.1)), fovx=u(0.3, 1.4), width=W, height=H)
+    bg = torch.rand(3, generator=g)
+    check(inp, cam, bg, sh_degree=int(u(0, 3.999)), scale_modifier=u(0.5, 1.8), with_gobj=with_objs, seed=seed,
+          frag_frac=3e-2, elem_frac=5e-3)
