@@ -491,9 +491,13 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       const float4 e0 = n0, e1 = n1;
       const float2 e2 = n2;
       const int jc = j;
-      todo &= todo - 1ull;
-      const bool more = todo != 0ull;
-      j = more ? __builtin_ctzll(todo) : jc;  // prefetch the next entry while this one is composited
+      // Next entry of the batch that reaches this wave (the scalar unit is shared by the CU's four SIMDs and this
+      // loop leans on it: three scalar instructions instead of the eight the compiler makes of the C expressions).
+      // After the last entry s_ff1 returns -1: the prefetch below then reads slot 63, which is never used.
+      int jraw;
+      asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
+      const bool more = jraw >= 0;
+      j = jraw & 63;                          // prefetch the next entry while this one is composited
       n0 = s0[j]; n1 = s1[j]; n2 = s2[j];
       const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) & alive;
       const uint32_t pos = base - rg.x + jc + 1;
