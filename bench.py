@@ -21,6 +21,7 @@ algorithmic bytes of SURVEY.md section 8(d) and its live HIP-event duration over
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -350,6 +351,31 @@ def main():
                             render(cam, model, pipe, bg)
                 torch.cuda.synchronize()
                 fwd_rate = run_fwd / (time.perf_counter() - t0)
+            col_rate = None
+            if not args.color_only:
+                # gradients on the SH coefficients only (BASELINE configs 2/3): geometry frozen, lighter K7 / K8+K9
+                frozen = [getattr(model, n_) for n_ in ("_xyz", "_scaling", "_rotation", "_opacity")]
+                for p_ in frozen:
+                    p_.requires_grad_(False)
+                pipe_c = PipelineParams(skip_objects=not args.objects, viewspace_grad=False)
+                n_col = min(args.steps, 150)
+
+                def col_steps(n):
+                    for i in range(n):
+                        ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
+                        with ctx_:
+                            model.zero_grad()
+                            render(cam, model, pipe_c, bg)["render"].backward(gc)
+                for s_ in (streams or []):
+                    s_.wait_stream(torch.cuda.current_stream(dev))
+                col_steps(6)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                col_steps(n_col)
+                torch.cuda.synchronize()
+                col_rate = n_col / (time.perf_counter() - t0)
+                for p_ in frozen:
+                    p_.requires_grad_(True)
             recs = []
             pgd_model = model.clone()
             pgd_attack(pgd_model, cams[:8], iters=6, groups=("color", "position", "scaling", "rotation", "opacity"),
@@ -357,6 +383,7 @@ def main():
             pgd_ms = 1e3 * sorted(r["seconds"] for r in recs[2:])[len(recs[2:]) // 2]
             del pgd_model
             result["extras"] = {"fwd_only_views_per_s": round(fwd_rate, 1),
+                                "sh_grads_only_views_per_s": None if col_rate is None else round(col_rate, 1),
                                 "pgd_iteration_ms": round(pgd_ms, 3),
                                 "pgd_iteration": "8 views x (fwd+bwd) + surrogate detector loss + step on "
                                                  "{colour, position, scaling, rotation, opacity}, one GPU"}
