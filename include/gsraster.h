@@ -98,6 +98,9 @@ int gsr_forward(const GsrSettings* settings, int32_t P, int32_t K, const float* 
  *   dmeans3D [P,3], dmeans2D [P,3] (gradient w.r.t. the screen-space means in NDC units, z = 0; this is what
  *   lands in viewspace_points.grad, reference gaussian_renderer/__init__.py:26-30), dshs [P,K,3],
  *   dsh_objs [P,16], dcolors_precomp [P,3], dopacities [P], dscales [P,3], drotations [P,4], dcov3D [P,6].
+ * When every geometry-side output (dmeans3D, dmeans2D, dopacities, dscales, drotations, dcov3D) is NULL the
+ * backward runs its colour-only kernels (no conic / mean / opacity sums, no projection chain rule); the colour-side
+ * gradients are the same numbers either way.
  * May be called more than once on a context (retain_graph).                                                  */
 int gsr_backward(GsrCtx* ctx, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
                  float* dshs, float* dsh_objs, float* dcolors_precomp, float* dopacities, float* dscales,
