@@ -54,6 +54,28 @@ class GaussianModel:
         m._objects_dc = par(objects_dc)
         return m
 
+    @classmethod
+    def create_from_pcd(cls, points, colors, sh_degree: int = 3, device="cpu", generator=None) -> "GaussianModel":
+        """Initial model from a sparse point cloud (reference scene/gaussian_model.py:130-158): DC colour = RGB2SH(rgb),
+        higher bands 0, isotropic log-scale = log sqrt(mean squared distance to the 3 nearest neighbours)
+        (``simple_knn._C.distCUDA2`` -- the HIP kernel on a device, clamped at 1e-7), identity rotations, opacity
+        logit(0.1), random object features RGB2SH(U[0,1)).  points [P,3], colors [P,3] in [0,1] (array-likes)."""
+        from simple_knn._C import distCUDA2
+        from .sh import RGB2SH
+        xyz = torch.as_tensor(points, dtype=torch.float32).to(device).contiguous()
+        rgb = torch.as_tensor(colors, dtype=torch.float32).to(device)
+        P = xyz.shape[0]
+        K = (sh_degree + 1) ** 2
+        dist2 = torch.clamp_min(distCUDA2(xyz), 1e-7)
+        scales = torch.log(torch.sqrt(dist2))[:, None].repeat(1, 3)
+        rots = torch.zeros(P, 4, device=xyz.device)
+        rots[:, 0] = 1.0
+        opac = torch.full((P, 1), 0.1, device=xyz.device)
+        opac = torch.log(opac / (1.0 - opac))                            # inverse_sigmoid, utils/general_utils.py:18-19
+        objs = RGB2SH(torch.rand(P, NUM_OBJECTS, generator=generator).to(xyz.device))[:, None, :]
+        return cls.from_tensors(xyz, RGB2SH(rgb)[:, None, :], torch.zeros(P, K - 1, 3, device=xyz.device), scales, rots,
+                                opac, objs, sh_degree=sh_degree, device=xyz.device)
+
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
                 self._opacity, self._objects_dc]

@@ -47,3 +47,27 @@ def test_one_million_points_runs_and_is_plausible():
     d2[torch.arange(200), idx] = float("inf")
     ref = torch.topk(d2, 3, dim=1, largest=False).values.mean(dim=1)
     assert torch.allclose(d[idx].double(), ref, rtol=2e-5, atol=1e-9)
+
+
+def test_model_from_colmap_points_renders():
+    """COLMAP sparse points -> create_from_pcd (distCUDA2 on the HIP path) -> render(): the data-format side of the
+    path end to end on the device."""
+    import os
+    from gsplat_attack.colmap import cameras_from_colmap, read_points3D_binary
+    from gsplat_attack.gaussian_model import GaussianModel
+    from gsplat_attack.renderer import PipelineParams, render
+    here = os.path.dirname(os.path.abspath(__file__))
+    xyz, rgb, _ = read_points3D_binary(os.path.join(here, "golden", "colmap_sample_bin", "sparse", "0", "points3D.bin"))
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    pts = torch.cat([torch.from_numpy(xyz).float(), torch.randn(2000, 3, generator=g) * 0.5])
+    cols = torch.cat([torch.from_numpy(rgb).float() / 255.0, torch.rand(2000, 3, generator=g)])
+    model = GaussianModel.create_from_pcd(pts, cols, device=dev)
+    cpu = GaussianModel.create_from_pcd(pts, cols, device="cpu")
+    assert torch.allclose(model._scaling.detach().cpu(), cpu._scaling.detach(), atol=1e-4)
+    cam = cameras_from_colmap(os.path.join(here, "golden", "colmap_sample_bin"), device=dev)[0]
+    out = render(cam, model, PipelineParams(), torch.zeros(3, device=dev))
+    out["render"].sum().backward()
+    torch.cuda.synchronize()
+    assert out["render"].shape == (3, cam.image_height, cam.image_width) and torch.isfinite(out["render"]).all()
+    assert torch.isfinite(model._xyz.grad).all()

@@ -104,3 +104,25 @@ def test_removal_and_concat_setup():
     m.concat_setup("xyz", frozen._xyz[:5].detach(), False)
     assert m._xyz.shape[0] == 12 and not m._xyz.requires_grad
     assert torch.equal(m._xyz[7:].detach(), frozen._xyz[:5].detach())
+
+
+def test_create_from_pcd_initialisation():
+    """Counterpart of scene/gaussian_model.py:130-158: shapes, DC colour, identity rotation, 0.1 opacity and the
+    3-NN log-scale (against a brute-force neighbour search)."""
+    import numpy as np
+    from gsplat_attack.gaussian_model import GaussianModel
+    from gsplat_attack.sh import SH2RGB
+    rng = np.random.default_rng(4)
+    pts = rng.normal(size=(300, 3)).astype(np.float32)
+    cols = rng.uniform(size=(300, 3)).astype(np.float32)
+    m = GaussianModel.create_from_pcd(pts, cols, generator=torch.Generator().manual_seed(1))
+    assert m._xyz.shape == (300, 3) and m._features_dc.shape == (300, 1, 3) and m._features_rest.shape == (300, 15, 3)
+    assert m._objects_dc.shape == (300, 1, 16) and m._opacity.shape == (300, 1)
+    assert torch.allclose(SH2RGB(m._features_dc[:, 0].detach()), torch.from_numpy(cols), atol=1e-6)
+    assert float(m._features_rest.abs().max()) == 0.0
+    assert torch.allclose(m.get_opacity.detach(), torch.full((300, 1), 0.1), atol=1e-6)
+    assert torch.equal(m.get_rotation.detach(), torch.tensor([[1.0, 0, 0, 0]]).expand(300, 4))
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    d2.sort(axis=1)
+    want = np.log(np.sqrt(np.maximum(d2[:, 1:4].mean(axis=1), 1e-7)))
+    assert np.allclose(m._scaling.detach().numpy(), np.repeat(want[:, None], 3, 1), atol=1e-4)
