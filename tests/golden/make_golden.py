@@ -198,6 +198,15 @@ def main():
     out["colmap_T"] = np.stack([r[3] for r in rows])
     out["colmap_fov"] = np.array([[r[4], r[5]] for r in rows])
     out["colmap_wh"] = np.array([[r[6], r[7]] for r in rows])
+    # scene/dataset_readers.py:40-66 getNerfppNorm on those cameras (its CameraInfo only needs .R and .T here)
+    from scene.dataset_readers import getNerfppNorm
+
+    class _CI:
+        def __init__(self, R, T):
+            self.R, self.T = R, T
+    norm = getNerfppNorm([_CI(r[2], r[3]) for r in rows])
+    out["colmap_nerfnorm_radius"] = np.array(norm["radius"])
+    out["colmap_nerfnorm_translate"] = np.asarray(norm["translate"])
 
     # ---- COLMAP binary model (scene/colmap_loader.py:125-154, :180-244) ---------------------------------------
     # The fixture files are written here from the text sample in COLMAP's published binary layout, WITH 2D points and
