@@ -46,81 +46,60 @@ def _has_raw_layout(pc) -> bool:
         return False
 
 
+def _settings(cam, pc, pipe, bg_color, scaling_modifier) -> GaussianRasterizationSettings:
+    """The 12 fields in call-site order (reference gaussian_renderer/__init__.py:33-49): tan(FoV/2), integer image size,
+    the camera's transposed matrices, the model's ACTIVE SH degree, prefiltered always False."""
+    half_x, half_y = 0.5 * cam.FoVx, 0.5 * cam.FoVy
+    return GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), math.tan(half_x), math.tan(half_y),
+                                         bg_color, scaling_modifier, cam.world_view_transform, cam.full_proj_transform,
+                                         pc.active_sh_degree, cam.camera_center, False, pipe.debug)
+
+
+def _result(image, screenspace_points, radii, objects) -> dict:
+    """The dict of reference gaussian_renderer/__init__.py:99-103 (the image is NOT clamped)."""
+    return dict(render=image, viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii,
+                render_object=objects)
+
+
+def _python_colours(cam, pc):
+    """convert_SHs_python branch (reference :70-78): SH evaluated with tensor ops, +0.5, clamped at 0."""
+    n = pc.get_features.shape[0]
+    coeffs = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    rays = pc.get_xyz - cam.camera_center.repeat(n, 1)
+    rays = rays / rays.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(pc.active_sh_degree, coeffs, rays) + 0.5, 0.0)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     # The reference builds `zeros_like(...) + 0` and calls retain_grad() on that non-leaf (:25-29); a zero LEAF gives
     # callers the same thing (values 0, .grad filled by backward) without an add kernel and a gradient copy per view.
     screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=bool(getattr(pipe, "viewspace_grad", True)))
+    st = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
+    no_objects = bool(getattr(pipe, "skip_objects", False))
 
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height),
-        image_width=int(viewpoint_camera.image_width),
-        tanfovx=tanfovx,
-        tanfovy=tanfovy,
-        bg=bg_color,
-        scale_modifier=scaling_modifier,
-        viewmatrix=viewpoint_camera.world_view_transform,
-        projmatrix=viewpoint_camera.full_proj_transform,
-        sh_degree=pc.active_sh_degree,
-        campos=viewpoint_camera.camera_center,
-        prefiltered=False,
-        debug=pipe.debug,
-    )
-    if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.convert_SHs_python
-            and not pipe.compute_cov3D_python and _has_raw_layout(pc)):
-        rendered_image, radii, rendered_objects = rasterize_gaussians_raw(
-            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
-            None if getattr(pipe, "skip_objects", False) else pc._objects_dc, pc._opacity, pc._scaling, pc._rotation,
-            raster_settings)
-        return {"render": rendered_image,
-                "viewspace_points": screenspace_points,
-                "visibility_filter": radii > 0,
-                "radii": radii,
-                "render_object": rendered_objects}
+    fused = (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.convert_SHs_python
+             and not pipe.compute_cov3D_python and _has_raw_layout(pc))
+    if fused:
+        image, radii, objects = rasterize_gaussians_raw(
+            pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, None if no_objects else pc._objects_dc,
+            pc._opacity, pc._scaling, pc._rotation, st)
+        return _result(image, screenspace_points, radii, objects)
 
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
-    means3D = pc.get_xyz
-    means2D = screenspace_points
-    opacity = pc.get_opacity
-
-    scales = rotations = cov3D_precomp = None
+    # classic surface: activated tensors through the keyword call of reference :86-95
+    kw = dict(means3D=pc.get_xyz, means2D=screenspace_points, opacities=pc.get_opacity, shs=None, colors_precomp=None,
+              scales=None, rotations=None, cov3D_precomp=None,
+              # the reference leaves `sh_objs` unbound on its two Python-colour branches (SURVEY.md section 3.1 quirk 5);
+              # here the object features are always passed, which is what its only working branch does
+              sh_objs=None if no_objects else pc.get_objects)
     if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+        kw["cov3D_precomp"] = pc.get_covariance(scaling_modifier)
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
-
-    # The reference leaves `sh_objs` unbound on the two Python-colour branches;
-    # here the object features are always passed, which is what its only working branch does.
-    shs = colors_precomp = None
-    sh_objs = None if getattr(pipe, "skip_objects", False) else pc.get_objects
-    if override_color is None:
-        if pipe.convert_SHs_python:
-            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
-            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
-            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
-        else:
-            shs = pc.get_features
+        kw["scales"], kw["rotations"] = pc.get_scaling, pc.get_rotation
+    if override_color is not None:
+        kw["colors_precomp"] = override_color
+    elif pipe.convert_SHs_python:
+        kw["colors_precomp"] = _python_colours(viewpoint_camera, pc)
     else:
-        colors_precomp = override_color
-
-    rendered_image, radii, rendered_objects = rasterizer(
-        means3D=means3D,
-        means2D=means2D,
-        shs=shs,
-        sh_objs=sh_objs,
-        colors_precomp=colors_precomp,
-        opacities=opacity,
-        scales=scales,
-        rotations=rotations,
-        cov3D_precomp=cov3D_precomp)
-
-    return {"render": rendered_image,
-            "viewspace_points": screenspace_points,
-            "visibility_filter": radii > 0,
-            "radii": radii,
-            "render_object": rendered_objects}
+        kw["shs"] = pc.get_features
+    image, radii, objects = GaussianRasterizer(raster_settings=st)(**kw)
+    return _result(image, screenspace_points, radii, objects)
