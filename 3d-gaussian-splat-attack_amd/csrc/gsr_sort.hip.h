@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* tm
   return wbase + incl - v;
 }
 
-// ---- exclusive scan over n u32 (three launches; the middle one is a single block) ----------------
+// ---- exclusive scan over n u32 (two launches: block sums, then carry + local scan) ------------------
 // The prefix sums are 32-bit (they number at most 2^31 pairs); next to them the exact 64-bit total is accumulated so
 // that the host can tell a wrapped scan from a valid one.
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* tmp64) {
@@ -74,45 +74,41 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial(const uint32_t* _
   if (threadIdx.x == 0) { sums[blockIdx.x] = total; if (sums64) sums64[blockIdx.x] = t64; }
 }
 
-// in-place exclusive scan of sums[nb] by one block; total -> *total_out (may be null); exact total -> *total64_out
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_sums(uint32_t* __restrict__ sums, uint32_t nb,
-                                                            uint32_t* __restrict__ total_out,
-                                                            const unsigned long long* __restrict__ sums64,
-                                                            unsigned long long* __restrict__ total64_out) {
+// Second and last launch of the scan: block b forms its own carry from the raw block sums of k_scan_partial (at most
+// a few thousand words, L2 resident) instead of waiting for a single-block scan of them; the last block also writes
+// the totals.  Two dependent launches per scan instead of three.
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply_carry(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                                   const uint32_t* __restrict__ sums, uint32_t nb,
+                                                                   uint32_t* __restrict__ total_out,
+                                                                   const unsigned long long* __restrict__ sums64,
+                                                                   unsigned long long* __restrict__ total64_out) {
   __shared__ uint32_t tmp[4];
   __shared__ unsigned long long tmp64[4];
-  uint32_t carry = 0;
-  unsigned long long acc64 = 0;
-  for (uint32_t base = 0; base < nb; base += SCAN_THREADS) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = (i < nb) ? sums[i] : 0u;
-    if (sums64 && i < nb) acc64 += sums64[i];
-    uint32_t total;
-    const uint32_t ex = block_excl_scan_256(v, tmp, total);
-    if (i < nb) sums[i] = carry + ex;
-    carry += total;
-  }
-  const unsigned long long t64 = block_sum_u64(acc64, tmp64);
-  if (threadIdx.x == 0) {
-    if (total_out) *total_out = carry;
-    if (total64_out) *total64_out = t64;
-  }
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint32_t* in, uint32_t* out,
-                                                             uint32_t n, const uint32_t* __restrict__ sums) {
-  __shared__ uint32_t tmp[4];
-  const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+  const uint32_t b = blockIdx.x;
+  uint32_t part = 0;
+  for (uint32_t i = threadIdx.x; i < b; i += SCAN_THREADS) part += sums[i];
+  uint32_t carry;
+  block_excl_scan_256(part, tmp, carry);                 // carry = sum of the block sums in front of this block
+  const uint32_t base = b * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
   uint32_t v[SCAN_ITEMS];
   uint32_t s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
   uint32_t total;
-  uint32_t run = block_excl_scan_256(s, tmp, total) + sums[blockIdx.x];
+  uint32_t run = block_excl_scan_256(s, tmp, total) + carry;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
     if (base + i < n) out[base + i] = run;
     run += v[i];
+  }
+  if (b == nb - 1) {
+    if (total_out && threadIdx.x == 0) *total_out = carry + total;
+    if (total64_out) {
+      unsigned long long a = 0;
+      for (uint32_t i = threadIdx.x; i < nb; i += SCAN_THREADS) a += sums64[i];
+      const unsigned long long t64 = block_sum_u64(a, tmp64);
+      if (threadIdx.x == 0) *total64_out = t64;
+    }
   }
 }
 
@@ -128,9 +124,8 @@ inline void scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, ui
   }
   const uint32_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
   hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, sums, total64_out ? sums64 : nullptr);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nb, total_out,
-                     total64_out ? (const unsigned long long*)sums64 : nullptr, total64_out);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, sums);
+  hipLaunchKernelGGL(k_scan_apply_carry, dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, (const uint32_t*)sums, nb,
+                     total_out, total64_out ? (const unsigned long long*)sums64 : nullptr, total64_out);
 }
 
 // ---- stable LSD radix sort pass over (key,val) pairs ------------------------------------------------
