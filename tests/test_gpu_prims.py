@@ -17,7 +17,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 100_000, 1_234_567])
+@pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 100_000, 1_234_567, 20_000_001])
 def test_exclusive_scan(n):
     lib, D = _lib()
     g = torch.Generator().manual_seed(n)
