@@ -96,35 +96,37 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             if p.requires_grad:
                 p.requires_grad_(False)
                 frozen.append(p)
-    history = []
-    ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" else None
-    for it in range(iters):
-        t0 = time.perf_counter()
-        model.zero_grad()
-        losses = []
-        for cam in mine:                                   # one forward+backward per view: peak memory = one view per stream
-            with (ring.next() if ring is not None else contextlib.nullcontext()):
-                img = render(cam, model, pipe, bg)["render"]
-                loss = loss_fn(img[None])
-                loss.backward()
-                losses.append(loss.detach())
-        if ring is not None:
-            ring.join()
-        total = torch.stack(losses).sum() if losses else torch.zeros((), device=dev)
-        if world > 1:
-            if frozen:
-                gdist.allreduce_attribute_grads(model, names=("_features_dc", "_features_rest"))   # 192 MB instead of 236
-            else:
-                gdist.allreduce_attribute_grads(model)
-            torch.distributed.all_reduce(total)
-        _step(model, originals, groups, norm, alpha, epsilon)
-        history.append(float(total))
-        if log is not None:
-            if dev.type == "cuda":
-                torch.cuda.synchronize()
-            log({"iter": it, "loss": history[-1], "seconds": time.perf_counter() - t0, "views": len(cameras)})
-    for p in frozen:
-        p.requires_grad_(True)
+    try:
+        history = []
+        ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" else None
+        for it in range(iters):
+            t0 = time.perf_counter()
+            model.zero_grad()
+            losses = []
+            for cam in mine:                                   # one forward+backward per view: peak memory = one view per stream
+                with (ring.next() if ring is not None else contextlib.nullcontext()):
+                    img = render(cam, model, pipe, bg)["render"]
+                    loss = loss_fn(img[None])
+                    loss.backward()
+                    losses.append(loss.detach())
+            if ring is not None:
+                ring.join()
+            total = torch.stack(losses).sum() if losses else torch.zeros((), device=dev)
+            if world > 1:
+                if frozen:
+                    gdist.allreduce_attribute_grads(model, names=("_features_dc", "_features_rest"))   # 192 MB instead of 236
+                else:
+                    gdist.allreduce_attribute_grads(model)
+                torch.distributed.all_reduce(total)
+            _step(model, originals, groups, norm, alpha, epsilon)
+            history.append(float(total))
+            if log is not None:
+                if dev.type == "cuda":
+                    torch.cuda.synchronize()
+                log({"iter": it, "loss": history[-1], "seconds": time.perf_counter() - t0, "views": len(cameras)})
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
     return history
 
 
