@@ -388,7 +388,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     uint32_t* pinned = pinned_word(dev);
     hipEvent_t n_ready = count_event(dev);
     if (!pinned || !n_ready) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host word / event allocation failed"));
-    F_TRY("read pair count", hipMemcpyAsync(pinned, c->offg + P, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // one 8-byte copy: the exact 64-bit total (N is its low word once it is known to be below 2^31)
     F_TRY("read pair count", hipMemcpyAsync(pinned + 2, c->total64, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     F_TRY("read pair count", hipEventRecord(n_ready, st));
     uint32_t* skey;
@@ -408,10 +408,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       scan_exclusive_u32(cnt, c->off, (uint32_t)P, psums, c->off + P, st);
       F_LAUNCH("pack/scan");
       F_TRY("read pair count", hipEventSynchronize(n_ready));
-      N = *pinned;
       unsigned long long exact = 0;
       memcpy(&exact, pinned + 2, sizeof(exact));
-      if (exact != (unsigned long long)N || exact >= MAX_PAIRS)   // NSUB * N must stay below 2^32
+      N = (uint32_t)exact;
+      if (exact >= MAX_PAIRS)   // NSUB * N must stay below 2^32
         return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: %llu (tile, Gaussian) pairs exceed the supported %llu "
                             "(splats cover too many tiles: check scales / scale_modifier)", exact, MAX_PAIRS));
     }
