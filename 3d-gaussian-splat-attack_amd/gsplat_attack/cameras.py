@@ -71,8 +71,10 @@ class Camera:
     def _refresh_view(self):
         # scene/cameras.py:60-69: view + full projection are refreshed, camera_center is NOT
         #  -- kept, so synthesised cameras shade identically.
+        # .contiguous(): the reference keeps the transposed VIEW; a dense copy has the same values and spares the
+        # rasteriser binding a 16-element copy kernel per view
         self.world_view_transform = torch.tensor(world_to_view(self.R, self.T, self.trans, self.scale)) \
-            .transpose(0, 1).to(self.device)
+            .transpose(0, 1).contiguous().to(self.device)
         self.full_proj_transform = (self.world_view_transform.unsqueeze(0)
                                     .bmm(self.projection_matrix.unsqueeze(0))).squeeze(0)
 
