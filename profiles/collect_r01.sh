@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/r01
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- $BENCH > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- $BENCH > /dev/null 2> $OUT/write.err
@@ -37,7 +37,7 @@ for k in sorted(set(fetch) | set(write)):
               "hbm_bytes_raw": (f_kb + w_kb) * 1024, "hbm_bytes_fetch_x2": (2 * f_kb + w_kb) * 1024,
               # wave-level instruction counts per launch; SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles
               **{c: sq[c].get(k, 0.0) for c in sq}}
-json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline", "per_kernel": res}, open(f"{out}/pmc_traffic.json", "w"), indent=1)
+json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras", "per_kernel": res}, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_fetch_x2"] / 1e6 for k, v in res.items()}, indent=1))
 PY
 cp $OUT/stats/s_kernel_stats.csv $R/gpurun_out/r01_kernel_stats.csv
