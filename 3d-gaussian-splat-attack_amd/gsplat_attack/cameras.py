@@ -66,7 +66,7 @@ class Camera:
         self.projection_matrix = projection_matrix(self.znear, self.zfar, self.FoVx, self.FoVy) \
             .transpose(0, 1).to(self.device)
         self._refresh_view()
-        self.camera_center = self.world_view_transform.inverse()[3, :3]
+        self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()   # dense: no per-view copy in the binding
 
     def _refresh_view(self):
         # scene/cameras.py:60-69: view + full projection are refreshed, camera_center is NOT
