@@ -13,6 +13,7 @@ There is NO fallback: without the compiled library or without a HIP device every
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 from typing import NamedTuple, Optional
 
@@ -142,6 +143,31 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
 
 
+_SMALL = {}      # id(tensor) -> (weakref to it, its _version, dense float32 device copy)
+
+
+def _small_dense(t: torch.Tensor, device) -> torch.Tensor:
+    """Dense float32 device form of a tiny settings tensor.  The reference's Camera keeps world_view_transform as a
+    transposed VIEW and camera_center as a row of a column-major inverse (scene/cameras.py:54-57): both would cost a copy
+    kernel on every render call.  The copy is made once per tensor object and version (weak reference: a dead or
+    modified tensor is never served from here)."""
+    if t.device == device and t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    hit = _SMALL.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    d = _f32c(t.detach(), device)
+    if d is t or d.data_ptr() == t.data_ptr():
+        return d
+    if len(_SMALL) > 512:
+        _SMALL.clear()
+    try:
+        _SMALL[id(t)] = (weakref.ref(t), t._version, d)
+    except TypeError:
+        pass
+    return d
+
+
 class _SettingsPack:
     """C settings + the device tensors it points into (kept alive as long as the pack lives)."""
 
@@ -150,9 +176,9 @@ class _SettingsPack:
         self.bg = _f32c(rs.bg.detach().flatten(), device)
         if self.bg.numel() < 3:
             raise ValueError("bg must hold at least 3 values")
-        self.vm = _f32c(rs.viewmatrix.detach(), device)
-        self.pm = _f32c(rs.projmatrix.detach(), device)
-        self.cam = _f32c(rs.campos.detach().flatten(), device)
+        self.vm = _small_dense(rs.viewmatrix, device)
+        self.pm = _small_dense(rs.projmatrix, device)
+        self.cam = _small_dense(rs.campos, device).flatten()
         if self.vm.numel() != 16 or self.pm.numel() != 16 or self.cam.numel() < 3:
             raise ValueError("viewmatrix / projmatrix must be 4x4 and campos must hold 3 values")
         self.c = _CSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),

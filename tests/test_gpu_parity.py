@@ -490,3 +490,33 @@ def test_random_configurations(seed):
     bg = torch.rand(3, generator=g)
     check(inp, cam, bg, sh_degree=int(u(0, 3.999)), scale_modifier=u(0.5, 1.8), with_gobj=with_objs, seed=seed,
           frag_frac=3e-2, elem_frac=5e-3)
+
+
+def test_non_contiguous_camera_tensors_are_cached_and_invalidated():
+    """The reference's Camera hands over a transposed view matrix and a strided camera centre; the binding's dense copies
+    are reused while the tensors are unchanged and refreshed when they are modified in place or replaced."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    model, cams, _ = _scene(n_views=2)
+    inp = {k: v.to(dev) for k, v in model_inputs(model, with_objs=False).items()}
+    P = inp["means3D"].shape[0]
+
+    def draw(vm, pm, cp):
+        st = D.GaussianRasterizationSettings(cams[0].image_height, cams[0].image_width, math.tan(cams[0].FoVx * 0.5),
+                                             math.tan(cams[0].FoVy * 0.5), torch.zeros(3, device=dev), 1.0, vm, pm, 3, cp,
+                                             False, False)
+        return D.GaussianRasterizer(raster_settings=st)(means3D=inp["means3D"], means2D=torch.zeros(P, 3, device=dev),
+                                                        opacities=inp["opacities"], shs=inp["shs"], scales=inp["scales"],
+                                                        rotations=inp["rotations"])[0]
+    dense = [draw(c.world_view_transform.to(dev), c.full_proj_transform.to(dev), c.camera_center.to(dev)) for c in cams]
+    vm = cams[0].world_view_transform.to(dev).t().contiguous().t()          # transposed view, like the reference's
+    pm = cams[0].full_proj_transform.to(dev).t().contiguous().t()
+    big = torch.zeros(4, 4, device=dev)
+    big[:3, 3] = cams[0].camera_center.to(dev)
+    cp = big[:3, 3]                                                          # stride 4, like inverse()[3, :3]
+    assert not vm.is_contiguous() and not cp.is_contiguous()
+    assert torch.equal(draw(vm, pm, cp), dense[0])
+    assert torch.equal(draw(vm, pm, cp), dense[0])                           # served from the cache
+    vm.copy_(cams[1].world_view_transform.to(dev)); pm.copy_(cams[1].full_proj_transform.to(dev))
+    big[:3, 3] = cams[1].camera_center.to(dev)                               # in place: versions change
+    assert torch.equal(draw(vm, pm, cp), dense[1])
