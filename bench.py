@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--objects", action="store_true", help="composite the 16 object channels too")
     ap.add_argument("--color-only", action="store_true",
                     help="gradients on the SH coefficients only (BASELINE configs 2/3): geometry parameters frozen")
+    ap.add_argument("--classic", action="store_true",
+                    help="activated tensors through GaussianRasterizer (what the reference's own render() does) instead of "
+                         "the fused raw-parameter path")
     ap.add_argument("--no-cull", action="store_true", help="keep the full 3-sigma tile rects (A/B of the footprint cull)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the views are dealt over (view i runs on stream i %% S): the small sort/scan "
@@ -178,7 +181,8 @@ def main():
     cam = cams[rank % n_views]
     H, W = cam.image_height, cam.image_width
     P = model.get_xyz.shape[0]
-    pipe = PipelineParams(skip_objects=not args.objects, viewspace_grad=not args.color_only)
+    pipe = PipelineParams(skip_objects=not args.objects, viewspace_grad=not args.color_only,
+                          fused_activations=not args.classic)
     if args.color_only:
         for n_ in ("_xyz", "_scaling", "_rotation", "_opacity", "_objects_dc"):
             getattr(model, n_).requires_grad_(False)
@@ -312,7 +316,8 @@ def main():
             "config": {"workload": f"{spec.name}: {P} Gaussians (SH degree 3), {W}x{H}, one view per step per GPU, "
                                    "render() fwd + bwd to all attribute grads"
                                    + (", 16 object channels on" if args.objects else ", object channels off")
-                                   + (", gradients on SH coefficients only" if args.color_only else ""),
+                                   + (", gradients on SH coefficients only" if args.color_only else "")
+                                   + (", classic activated-tensor surface" if args.classic else ""),
                        "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
                        "streams": args.streams,
                        "parallelism": f"views sharded 1/GPU, dp{world}"
