@@ -94,3 +94,28 @@ def test_simple_knn_shim_imports_and_measures():
     d = distCUDA2(pts)
     assert d.shape == (5,)
     assert abs(d[0].item() - (1 + 4 + 9) / 3) < 1e-5
+
+
+def test_patch_reference_rebinds_render_everywhere():
+    """gsplat_attack.patch_reference swaps the reference's render for the fused one in the defining module and in
+    modules that imported the name (stand-in modules: the reference is not importable at test time)."""
+    import sys
+    import types
+    import gsplat_attack
+    from gsplat_attack.renderer import render as fused
+    gr = types.ModuleType("gaussian_renderer_standin")
+
+    def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+        raise AssertionError("the original must not be called any more")
+    gr.render = render
+    user = types.ModuleType("attack_standin")
+    user.render = render                       # `from gaussian_renderer import render`
+    other = types.ModuleType("unrelated_standin")
+    other.render = lambda: None
+    sys.modules.update({gr.__name__: gr, user.__name__: user, other.__name__: other})
+    try:
+        assert gsplat_attack.patch_reference(gr.__name__) == 2
+        assert gr.render is fused and user.render is fused and other.render is not fused
+    finally:
+        for m in (gr, user, other):
+            sys.modules.pop(m.__name__, None)
