@@ -77,7 +77,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     st = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     no_objects = bool(getattr(pipe, "skip_objects", False))
 
-    fused = (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.convert_SHs_python
+    fused = (getattr(pipe, "fused_activations", True) and override_color is None and not pipe.convert_SHs_python
              and not pipe.compute_cov3D_python and _has_raw_layout(pc))
     if fused:
         image, radii, objects = rasterize_gaussians_raw(

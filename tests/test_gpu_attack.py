@@ -121,3 +121,26 @@ def test_fused_pgd_step_matches_the_tensor_formulation(shape, kind):
         assert torch.allclose(got.cpu(), want, atol=2e-6, rtol=1e-5), (shape, kind, (got.cpu() - want).abs().max())
         if kind == "linf":
             assert torch.equal(got.cpu(), want)
+
+
+def test_render_with_a_reference_style_pipe_object_takes_the_fused_path():
+    """A pipe object with only the reference's three switches (attack.py:254-256) -- what render() sees after
+    gsplat_attack.patch_reference() -- still gets the fused raw-parameter path: the image equals the classic surface's
+    and gradients land on the raw parameters."""
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.scenes import make_scene
+
+    class GroupParams:                       # the reference's bare attribute bag
+        convert_SHs_python = False
+        compute_cov3D_python = False
+        debug = False
+    dev = torch.device("cuda:0")
+    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=1)
+    bg = torch.zeros(4, device=dev)          # the reference passes four zeros for black (attack.py:396)
+    out = render(cams[0], model, GroupParams(), bg)
+    assert type(out["render"].grad_fn).__name__ == "_RasterizeGaussiansRawBackward"
+    ref = render(cams[0], model, PipelineParams(fused_activations=False), bg)
+    assert (out["render"] - ref["render"]).abs().max().item() < 2e-6
+    assert (out["render_object"] - ref["render_object"]).abs().max().item() < 2e-6
+    out["render"].sum().backward()
+    assert model._scaling.grad is not None and out["viewspace_points"].grad is not None
