@@ -520,3 +520,23 @@ def test_non_contiguous_camera_tensors_are_cached_and_invalidated():
     vm.copy_(cams[1].world_view_transform.to(dev)); pm.copy_(cams[1].full_proj_transform.to(dev))
     big[:3, 3] = cams[1].camera_center.to(dev)                               # in place: versions change
     assert torch.equal(draw(vm, pm, cp), dense[1])
+
+
+def test_debug_setting_dumps_the_inputs_of_a_failed_forward(tmp_path, monkeypatch):
+    """debug=True (reference pipe.debug, configs/config.yaml:63): a forward that fails on the device side leaves a
+    torch.save'd snapshot of its inputs next to the process, like the extension's snapshot_fw.dump."""
+    D = _hip()
+    from gsplat_attack.cameras import look_at_camera
+    monkeypatch.chdir(tmp_path)
+    dev = torch.device("cuda:0")
+    cam = look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), fovx=0.9, width=3840, height=2160, device=dev)
+    st = settings_for(cam, torch.zeros(3), cls=D.GaussianRasterizationSettings, device=dev)._replace(debug=True)
+    P = 100_000
+    means = (torch.randn(P, 3, generator=torch.Generator().manual_seed(0)) * 0.05).to(dev)
+    with pytest.raises(RuntimeError, match="snapshot_fw.dump"):
+        D.GaussianRasterizer(raster_settings=st)(
+            means3D=means, means2D=torch.zeros(P, 3, device=dev), opacities=torch.full((P, 1), 0.5, device=dev),
+            shs=torch.zeros(P, 16, 3, device=dev), scales=torch.full((P, 3), 50.0, device=dev),
+            rotations=torch.tensor([[1.0, 0, 0, 0]], device=dev).repeat(P, 1))
+    snap = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert torch.equal(snap["means3D"].cpu(), means.cpu()) and snap["settings"]["image_width"] == 3840
