@@ -366,7 +366,12 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                      ctypes.byref(handle),
                                      ctypes.byref(nren), stream)
         if rc != 0:
-            raise Exception(_err(lib)) if rc == 1 else RuntimeError(_err(lib))
+            msg = _err(lib)
+            if raster_settings.debug:
+                torch.save({"xyz": x, "features_dc": dc, "features_rest": rest, "objects_dc": obj, "opacity": op,
+                            "scaling": sc, "rotation": ro, "settings": raster_settings._asdict()}, "snapshot_fw.dump")
+                msg += " (raw parameters saved to snapshot_fw.dump)"
+            raise Exception(msg) if rc == 1 else RuntimeError(msg)
         ctx.holder = _CtxHolder(lib, handle)
         ctx.pack = pack
         ctx.num_rendered = nren.value
