@@ -69,7 +69,7 @@ struct Pool {
 };
 
 constexpr int MAX_DEV = 32;
-constexpr size_t POOL_SOFT_CAP = size_t(48) << 30;   // of 288 GB: beyond this, free blocks of other streams are re-used
+constexpr size_t POOL_SOFT_CAP = size_t(24) << 30;   // of 288 GB: beyond this, free blocks of other streams are re-used
 Pool g_pool[MAX_DEV];
 
 int cur_dev() {
@@ -108,12 +108,26 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
   const size_t want = bytes + bytes / 8;
   if (hipMalloc(&p, want) != hipSuccess) {
     (void)hipGetLastError();
-    if (other < 0) return nullptr;
-    Block& b = pl.blocks[other];                         // out of memory: fall back to the other stream's block
-    (void)hipStreamSynchronize(b.stream);
-    b.used = true;
-    b.stream = st;
-    return b.p;
+    if (other >= 0) {                                    // out of memory: take the other stream's block
+      Block& b = pl.blocks[other];
+      (void)hipStreamSynchronize(b.stream);
+      b.used = true;
+      b.stream = st;
+      return b.p;
+    }
+    // give the device back every idle block of this pool (none of them fits), then try once more
+    std::vector<Block> keep;
+    for (Block& b : pl.blocks) {
+      if (b.used) { keep.push_back(b); continue; }
+      (void)hipStreamSynchronize(b.stream);
+      (void)hipFree(b.p);
+      pl.total -= b.bytes;
+    }
+    pl.blocks.swap(keep);
+    if (hipMalloc(&p, want) != hipSuccess && hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
   }
   pl.blocks.push_back(Block{p, want, st, true});
   pl.total += want;
@@ -241,6 +255,11 @@ static ViewArgs view_args(const GsrSettings& s) {
 
 constexpr unsigned long long MAX_PAIRS = 1ull << 31;   // 32-bit pair numbering with head-room
 
+// per-call launch overrides carried in GsrSettings.flags (include/gsraster.h)
+static int flag_fwd_npx(uint32_t f) { const int v = (f >> 4) & 7u; return v == 1 ? 1 : v == 2 ? 2 : v == 3 ? 4 : 0; }
+static int flag_bwd_npx(uint32_t f) { const int v = (f >> 8) & 3u; return v == 1 ? 2 : v == 2 ? 4 : 0; }
+static int flag_tile_map(uint32_t f) { const int v = (f >> 12) & 7u; return (v >= 1 && v <= 4) ? v - 1 : 3; }
+
 static int ceil_log2(uint32_t v) {
   int b = 0;
   while ((1u << b) < v) ++b;
@@ -344,8 +363,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   unsigned long long* psums64 = ss.take<unsigned long long>(Pp / SCAN_CHUNK + 2);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* tbl_blk = nullptr;
   auto fail = [&](int code) {
     pool_free(dev, scratch_blk);
+    pool_free(dev, tbl_blk);
     for (void* b : pairs_blk) if (b && b != c->rank_blk) pool_free(dev, b);
     gsr_ctx_free(c);
     return code;
@@ -427,7 +448,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)N, st);
       if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", N));
     }
-    void* tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS), st);
+    tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS), st);
     if (!tbl_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: sort table allocation failed"));
     uint32_t* tileA = static_cast<uint32_t*>(pairs_blk[0]); uint32_t* rankA = static_cast<uint32_t*>(pairs_blk[1]);
     uint32_t* tileB = static_cast<uint32_t*>(pairs_blk[2]); uint32_t* rankB = static_cast<uint32_t*>(pairs_blk[3]);
@@ -451,6 +472,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     c->pair_rank = res ? rankB : rankA;
     c->rank_blk = res ? pairs_blk[3] : pairs_blk[1];
     pool_free(dev, tbl_blk);
+    tbl_blk = nullptr;
     for (void* b : pairs_blk) if (b != c->rank_blk) pool_free(dev, b);
     for (void*& b : pairs_blk) b = nullptr;
   }
@@ -459,7 +481,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     RenderArgs ra;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
-    static const int map_mode_f = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 3; return (v >= 0 && v <= 3) ? v : 3; }();
+    const int map_mode_f = flag_tile_map(s->flags);
     ra.map_mode = map_mode_f;
     ra.sched = c->sched;
     ra.wave_clock = g_wave_clock_fwd.load();
@@ -467,9 +489,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
     // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
-    // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FWD_NPX=1|2|4 overrides.
-    static const int fwd_npx_env = [] { const char* e = getenv("GSR_FWD_NPX"); int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
-    const int fwd_npx = fwd_npx_env ? fwd_npx_env : (ntiles < 4096 ? 1 : 2);
+    // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
+    const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : 2);
     const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
     if (out_objects && sh_objs) {
       if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
@@ -534,9 +555,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   // K7 runs one wave per 16x(4*npx) part of a tile; each writes its own partial row per list entry
   // (4 pixels per lane: one wave per tile; 2: two).  A tile's list is walked serially, so an image with fewer tiles
   // than the chip has wave slots (4 waves x 1024 SIMDs at K7's register count) runs faster split finer, even
-  // though K8/K9 then sums twice the rows; GSR_BWD_NPX=2|4 overrides.
-  static const int bwd_npx_env = [] { const char* e = getenv("GSR_BWD_NPX"); int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 0; }();
-  const int bwd_npx = bwd_npx_env ? bwd_npx_env : (c->ntiles < 4096 ? 2 : 4);
+  // though K8/K9 then sums twice the rows; GSR_FLAG_BWD_SPLIT(n) overrides.
+  const int bwd_npx = flag_bwd_npx(c->st.flags) ? flag_bwd_npx(c->st.flags) : (c->ntiles < 4096 ? 2 : 4);
   const uint32_t nsub = (uint32_t)(PXL / bwd_npx);
   if (N > 0) {
     part_blk = pool_alloc(dev, sizeof(float4) * PART_F4 * (size_t)N * nsub, st);
@@ -560,8 +580,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.tag_lo = tag_lo; ra.tag_hi = tag_hi;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = c->sh_objs; ra.bg = c->st.bg; ra.W = c->st.image_width; ra.H = c->st.image_height;
-    static const int map_mode_b = [] { const char* e = getenv("GSR_MAP_MODE"); int v = e ? atoi(e) : 3; return (v >= 0 && v <= 3) ? v : 3; }();
-    ra.map_mode = map_mode_b;
+    ra.map_mode = flag_tile_map(c->st.flags);
     ra.sched = c->sched;
     ra.wave_clock = g_wave_clock.load();
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const fl
                                                  const float* __restrict__ x0, size_t rows, int cols, float alpha,
                                                  float eps, const double* __restrict__ partial, int nb) {
   __shared__ float sd[64 * PGD_MAX_COLS];     // the wave's deltas x_new - x0
+  __shared__ float sf[64];                    // per-row clip factors
   const int lane = threadIdx.x;
   const size_t r0 = (size_t)blockIdx.x * 64;
   const int nr = (int)min((size_t)64, rows - r0);
@@ -72,11 +73,16 @@ __global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const fl
     const float nrm = sqrtf(ss);
     if (nrm > eps) f = eps / (nrm + 1e-7f);
   }
-  // row r's factor sits in lane r: fetch it per element
+  // Row r's factor is parked in LDS and read per element.  (A cross-lane read of lane r's register inside the loop
+  // below would return 0 for rows whose owner lane has already left the loop in the last, partial iteration:
+  // ds_bpermute yields 0 for an inactive source lane.)
+  sf[lane] = f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int i = lane; i < n; i += 64) {
     const int r = i / cols;
-    const float fr = __shfl(f, r, 64);
-    x[base + i] = fmaf(sd[i], fr, x0[base + i]);
+    x[base + i] = fmaf(sd[i], sf[r], x0[base + i]);
   }
 }
 

@@ -25,7 +25,23 @@ _LIB_NAME = "libgsraster.so"
 _lib = None
 
 FLAG_NO_CULL = 1          # GSR_FLAG_NO_CULL (include/gsraster.h)
-_FLAGS = 0
+FLAG_NO_SEGMENTS = 1 << 16
+_FLAGS = int(os.environ.get("GSR_FLAGS", "0"), 0)
+
+
+def flag_fwd_split(npx: int) -> int:
+    """GSR_FLAG_FWD_SPLIT: pixels per lane (1|2|4) of the forward compositor, 0 = library's choice."""
+    return {0: 0, 1: 1, 2: 2, 4: 3}[npx] << 4
+
+
+def flag_bwd_split(npx: int) -> int:
+    """GSR_FLAG_BWD_SPLIT: pixels per lane (2|4) of the backward compositor, 0 = library's choice."""
+    return {0: 0, 2: 1, 4: 2}[npx] << 8
+
+
+def flag_tile_map(mode: int) -> int:
+    """GSR_FLAG_TILE_MAP: block -> tile map 0..3 (3 = longest list first, the default)."""
+    return ((mode & 3) + 1) << 12
 
 
 def set_flags(flags: int) -> None:
@@ -143,7 +159,7 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
 
 
-_SMALL = {}      # id(tensor) -> (weakref to it, its _version, dense float32 device copy)
+_SMALL = {}      # (id(tensor), device) -> (weakref to it, its _version, dense float32 device copy, copy event, stream)
 
 
 def _small_dense(t: torch.Tensor, device) -> torch.Tensor:
@@ -153,8 +169,12 @@ def _small_dense(t: torch.Tensor, device) -> torch.Tensor:
     modified tensor is never served from here)."""
     if t.device == device and t.dtype == torch.float32 and t.is_contiguous():
         return t
-    hit = _SMALL.get(id(t))
+    key = (id(t), str(device))
+    hit = _SMALL.get(key)
+    cur = torch.cuda.current_stream(device) if device.type == "cuda" else None
     if hit is not None and hit[0]() is t and hit[1] == t._version:
+        if cur is not None and hit[4] != cur.cuda_stream:
+            cur.wait_event(hit[3])          # the copy was enqueued on another stream: order this stream behind it
         return hit[2]
     d = _f32c(t.detach(), device)
     if d is t or d.data_ptr() == t.data_ptr():
@@ -162,7 +182,11 @@ def _small_dense(t: torch.Tensor, device) -> torch.Tensor:
     if len(_SMALL) > 512:
         _SMALL.clear()
     try:
-        _SMALL[id(t)] = (weakref.ref(t), t._version, d)
+        ev = None
+        if cur is not None:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+        _SMALL[key] = (weakref.ref(t), t._version, d, ev, cur.cuda_stream if cur is not None else 0)
     except TypeError:
         pass
     return d
@@ -205,6 +229,19 @@ class _CtxHolder:
             except Exception:
                 pass
             self.handle = None
+
+
+def _versions(tensors):
+    return tuple(None if t is None else t._version for t in tensors)
+
+
+def _check_versions(tensors, versions):
+    """The kept buffers are aliases of the caller's tensors (no copy when they are already dense float32): the library
+    re-reads them in backward, so an in-place modification in between would silently change the gradients."""
+    for t, v in zip(tensors, versions):
+        if t is not None and t._version != v:
+            raise RuntimeError("one of the tensors given to the rasteriser's forward was modified in place before its "
+                               f"backward ran (version {t._version}, expected {v}); clone it or step after backward()")
 
 
 def _empty_like_or_none(t):
@@ -278,8 +315,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape,
                       None if scales is None else scales.shape, None if rotations is None else rotations.shape,
                       None if cov3Ds_precomp is None else cov3Ds_precomp.shape)
-        # the library reads these again in backward: keep the exact (contiguous fp32) buffers alive
+        # the library reads these again in backward: keep the exact (contiguous fp32) buffers alive, and remember
+        # their versions -- an in-place edit between forward and backward must raise, as a saved tensor would
         ctx.kept = (m3, shc, shoc, colc, opc, scc, roc, covc)
+        ctx.versions = _versions(ctx.kept)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         return color, radii, objects
@@ -287,6 +326,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_objects):
         lib = ctx.holder.lib
+        _check_versions(ctx.kept, ctx.versions)
         m3, shc, shoc, colc, opc, scc, roc, covc = ctx.kept
         device = m3.device
         P = int(m3.shape[0])
@@ -378,6 +418,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.shapes = (xyz.shape, means2D.shape, features_dc.shape, features_rest.shape,
                       None if objects_dc is None else objects_dc.shape, opacity.shape, scaling.shape, rotation.shape)
         ctx.kept = (x, dc, rest, obj, op, sc, ro)
+        ctx.versions = _versions(ctx.kept)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         return color, radii, objects
@@ -385,6 +426,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_objects):
         lib = ctx.holder.lib
+        _check_versions(ctx.kept, ctx.versions)
         x, dc, rest, obj, op, sc, ro = ctx.kept
         device = x.device
         P = int(x.shape[0])

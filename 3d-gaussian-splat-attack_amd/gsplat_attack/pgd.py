@@ -15,17 +15,27 @@ from __future__ import annotations
 import torch
 
 
-def _hip_step(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor, l2: bool) -> bool:
+def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Tensor, l2: bool) -> bool:
     """Device tensors take the fused HIP update (libgsraster.so: gsr_pgd_step, two launches per tensor).  Returns
-    False when the tensors do not have the layout it needs (the formulation below is then used as written)."""
-    if not (x.is_cuda and grad.is_cuda and x0.is_cuda and x.dtype == grad.dtype == x0.dtype == torch.float32):
+    False for host tensors (the formulation below is then used as written: that is the CPU statement the golden
+    fixtures pin).  A device tensor the kernel cannot take raises instead of silently running tensor ops."""
+    if not x.is_cuda:
         return False
-    if x.dim() < 1 or x.shape != grad.shape or x.shape != x0.shape or x.shape[0] == 0:
-        return False
+    if grad is None:
+        # no gradient reached this tensor (a rank without views, a frozen group): zero step, projection only
+        grad = torch.zeros_like(x)
+    if not (grad.is_cuda and x0.is_cuda) or x.shape != grad.shape or x.shape != x0.shape:
+        raise ValueError(f"pgd step: x {tuple(x.shape)} on {x.device}, grad {tuple(grad.shape)} on {grad.device}, "
+                         f"x0 {tuple(x0.shape)} on {x0.device} must agree")
+    if x.dim() < 1 or x.shape[0] == 0:
+        return True
     rows = x.shape[0]
     cols = x.numel() // rows
-    if cols > 48 or not (x.is_contiguous() and grad.is_contiguous() and x0.is_contiguous()):
-        return False
+    if x.dtype != torch.float32 or not x.is_contiguous() or cols > 48:
+        raise NotImplementedError("gsr_pgd_step updates contiguous float32 [rows, <=48] tensors in place "
+                                  f"(got {x.dtype}, contiguous={x.is_contiguous()}, {cols} columns)")
+    grad = grad.to(torch.float32).contiguous()
+    x0 = x0.to(torch.float32).contiguous()
     import ctypes
     import diff_gaussian_rasterization as D
     lib = D._load()
@@ -36,20 +46,27 @@ def _hip_step(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float,
                               ctypes.c_int32(1 if l2 else 0), stream)
     if rc != 0:
         raise RuntimeError(lib.gsr_last_error().decode())
+    # the kernel wrote through the raw pointer: tell autograd (a rasteriser forward that saved this tensor and has not
+    # run its backward yet must see the change, diff_gaussian_rasterization checks the versions)
+    torch.autograd.graph.increment_version(x)
     return True
 
 
 def linf_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
-    if _hip_step(x.data, grad, alpha, epsilon, x0, False):
+    if _hip_step(x.detach(), grad, alpha, epsilon, x0, False):
         return
+    if grad is None:
+        grad = torch.zeros_like(x)
     with torch.no_grad():
         x.add_(torch.sign(grad), alpha=-alpha)
         x.sub_(x0).clamp_(-epsilon, epsilon).add_(x0)
 
 
 def l2_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
-    if _hip_step(x.data, grad, alpha, epsilon, x0, True):
+    if _hip_step(x.detach(), grad, alpha, epsilon, x0, True):
         return
+    if grad is None:
+        grad = torch.zeros_like(x)
     with torch.no_grad():
         norm = torch.linalg.vector_norm(grad.reshape(-1), ord=2)
         # branch-free form of "if norm > 0 ... else zero step" (no host sync on the device path)

@@ -45,6 +45,18 @@ enum {
  * alpha >= 1/255 on any pixel of the tile are dropped before the sort: outputs are identical, only
  * num_rendered-internal work shrinks.  The flag exists for A/B tests of exactly that claim. */
 #define GSR_FLAG_NO_CULL 1u
+/* Per-call overrides of launch heuristics -- results do not depend on them (bitwise for the tile map; the tile split
+ * only changes which wave owns which strip, and how many partial rows a pair has); they exist so that tests can drive
+ * every kernel instantiation on small inputs.  0 in a field = the library's own choice from the tile count.
+ *   GSR_FLAG_FWD_SPLIT(n)  n = 1|2|4 pixels per lane in the forward compositor (4|2|1 waves per 16x16 tile)
+ *   GSR_FLAG_BWD_SPLIT(n)  n = 2|4   pixels per lane in the backward compositor
+ *   GSR_FLAG_TILE_MAP(m)   m = 0..3  block -> tile map: 0 image order, 1 one band per XCD, 2 32-tile bands round
+ *                                    robin, 3 longest list first (default)
+ *   GSR_FLAG_SEG(n)        n = 1     never split a long tile list over several waves (see gsr_backward) */
+#define GSR_FLAG_FWD_SPLIT(n) ((uint32_t)((n) == 1 ? 1u : (n) == 2 ? 2u : (n) == 4 ? 3u : 0u) << 4)
+#define GSR_FLAG_BWD_SPLIT(n) ((uint32_t)((n) == 2 ? 1u : (n) == 4 ? 2u : 0u) << 8)
+#define GSR_FLAG_TILE_MAP(m) ((uint32_t)(((m) & 3u) + 1u) << 12)
+#define GSR_FLAG_NO_SEGMENTS (1u << 16)
 
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the

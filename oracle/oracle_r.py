@@ -148,6 +148,9 @@ class Geom(NamedTuple):
     rect_min: torch.Tensor   # [P,2] int  tile rect [min,max)
     rect_max: torch.Tensor   # [P,2] int
     fragile: torch.Tensor    # [P] bool   an integer decision sits within rounding of its edge
+    ghost_min: torch.Tensor  # [P,2] int  tile rect a float32 implementation might use instead (= rect unless fragile)
+    ghost_max: torch.Tensor  # [P,2] int
+    maybe: torch.Tensor      # [P] bool   culled here, but a float32 implementation might keep it (fragile cull)
 
 
 def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
@@ -230,28 +233,55 @@ def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=
         fragile = fragile | _near_int(q, tol * q.abs().clamp_min(1.0))
     fragile = fragile | ((tz - 0.2).abs() < tol)
 
+    # The rect a float32 implementation might legitimately arrive at for a fragile Gaussian: one tile more on every
+    # side.  rasterize() walks these extra (tile, Gaussian) pairs as GHOSTS -- they never contribute, they only mark
+    # the pixels where they would have -- so that the fragile-pixel flags are per pixel, not per tile.
+    fr_i = fragile.to(torch.int64)
+    gminx = torch.clamp(rminx - fr_i, 0, gx)
+    gminy = torch.clamp(rminy - fr_i, 0, gy)
+    gmaxx = torch.clamp(rmaxx + fr_i, 0, gx)
+    gmaxy = torch.clamp(rmaxy + fr_i, 0, gy)
+    maybe = fragile & ~valid & (tz > 0.1) & det_ok & ((gmaxx - gminx) * (gmaxy - gminy) > 0)
+
     return Geom(valid, radii, xy, tz, conic,
-                torch.stack([rminx, rminy], dim=1), torch.stack([rmaxx, rmaxy], dim=1), fragile)
+                torch.stack([rminx, rminy], dim=1), torch.stack([rmaxx, rmaxy], dim=1), fragile,
+                torch.stack([gminx, gminy], dim=1), torch.stack([gmaxx, gmaxy], dim=1), maybe)
 
 
 # --------------------------------------------------------------------------
 # binning (K2-K5) and compositing (K6)
 # --------------------------------------------------------------------------
 
-def build_tile_lists(g: Geom, H: int, W: int):
+def _tiles_in_windows(tx, ty, windows):
+    keep = torch.zeros_like(tx, dtype=torch.bool)
+    for (x0, y0, x1, y1) in windows:
+        keep |= (tx >= x0) & (tx < x1) & (ty >= y0) & (ty < y1)
+    return keep
+
+
+def build_tile_lists(g: Geom, H: int, W: int, tile_windows=None, ghosts: bool = False):
     """(tile id, Gaussian id) pairs sorted by (tile, depth) with ties in Gaussian-index
     order, i.e. a stable sort of row-major-emitted pairs on key (tile<<32 | depth bits).
-    Returns (sorted gaussian ids [N], ranges [T,2])."""
+    Returns (sorted gaussian ids [N], ranges [T,2], ghost flags [N]).
+
+    tile_windows: list of (tx0, ty0, tx1, ty1) half-open tile rectangles -- only pairs of those tiles are
+    kept (the lists of the kept tiles are complete).  ghosts: also emit the pairs of the widened rects of fragile
+    Gaussians (Geom.ghost_min/max, Geom.maybe), flagged so that the compositor skips them."""
     gx = (W + TILE - 1) // TILE
     gy = (H + TILE - 1) // TILE
     T = gx * gy
-    ids = torch.nonzero(g.valid).flatten()
+    sel = (g.valid | g.maybe) if ghosts else g.valid
+    ids = torch.nonzero(sel).flatten()
     if ids.numel() == 0:
-        return torch.zeros(0, dtype=torch.int64), torch.zeros(T, 2, dtype=torch.int64)
+        return (torch.zeros(0, dtype=torch.int64), torch.zeros(T, 2, dtype=torch.int64),
+                torch.zeros(0, dtype=torch.bool))
     depth = g.depth.detach()[ids].to(torch.float32)        # the key holds float32 depth bits
     order = torch.argsort(depth, stable=True)
     ids = ids[order]
-    rmin, rmax = g.rect_min[ids], g.rect_max[ids]
+    if ghosts:
+        rmin, rmax = g.ghost_min[ids], g.ghost_max[ids]
+    else:
+        rmin, rmax = g.rect_min[ids], g.rect_max[ids]
     wx = rmax[:, 0] - rmin[:, 0]
     cnt = wx * (rmax[:, 1] - rmin[:, 1])
     owner = torch.repeat_interleave(torch.arange(ids.numel()), cnt)
@@ -259,14 +289,23 @@ def build_tile_lists(g: Geom, H: int, W: int):
     local = torch.arange(int(cnt.sum())) - start[owner]
     ty = rmin[owner, 1] + local // wx[owner]
     tx = rmin[owner, 0] + local % wx[owner]
+    gid = ids[owner]
+    if ghosts:
+        real_min, real_max = g.rect_min[gid], g.rect_max[gid]
+        ghost = ~g.valid[gid] | (tx < real_min[:, 0]) | (tx >= real_max[:, 0]) | (ty < real_min[:, 1]) | (ty >= real_max[:, 1])
+    else:
+        ghost = torch.zeros(gid.numel(), dtype=torch.bool)
+    if tile_windows is not None:
+        keep = _tiles_in_windows(tx, ty, tile_windows)
+        tx, ty, gid, ghost = tx[keep], ty[keep], gid[keep], ghost[keep]
     tile = ty * gx + tx
     o2 = torch.argsort(tile, stable=True)                  # stable => depth order kept inside each tile
     tile_s = tile[o2]
-    gid_s = ids[owner[o2]]
+    gid_s = gid[o2]
     counts = torch.bincount(tile_s, minlength=T)
     ends = torch.cumsum(counts, 0)
     ranges = torch.stack([ends - counts, ends], dim=1)
-    return gid_s, ranges
+    return gid_s, ranges, ghost[o2]
 
 
 class RenderOut(NamedTuple):
@@ -278,13 +317,19 @@ class RenderOut(NamedTuple):
     fragile_px: torch.Tensor   # [H,W] bool  a threshold test sat within rounding of its edge
     num_rendered: int
     fragile_gauss: torch.Tensor
+    window_px: Optional[torch.Tensor] = None   # [H,W] bool: pixels that were composited (None = all of them)
 
 
 def rasterize(means3D, means2D, opacities, st: Settings, shs=None, sh_objs=None, colors_precomp=None,
               scales=None, rotations=None, cov3D_precomp=None, dtype=torch.float64,
-              frag_tol: Optional[float] = None) -> RenderOut:
+              frag_tol: Optional[float] = None, tile_windows=None) -> RenderOut:
     """Full forward (differentiable).  Argument names follow the rasteriser call site
-    gaussian_renderer/__init__.py:86-95."""
+    gaussian_renderer/__init__.py:86-95.
+
+    tile_windows: optional list of half-open tile rectangles (tx0, ty0, tx1, ty1).  Only those tiles are
+    composited (everything per Gaussian still runs over all P); the other pixels of the outputs are zero and
+    ``window_px`` marks the composited ones.  Lets full-size scenes (1M Gaussians @1080p, 2M @4K) be checked on the
+    tiles a test picks, with dL/dC zero elsewhere."""
     if (shs is None) == (colors_precomp is None):
         raise Exception('Please provide excatly one of either SHs or precomputed colors!')
     if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -308,78 +353,107 @@ def rasterize(means3D, means2D, opacities, st: Settings, shs=None, sh_objs=None,
     opac = opacities.view(P)
     objs = sh_objs.reshape(P, NUM_OBJECTS) if sh_objs is not None else None
 
-    gid, ranges = build_tile_lists(g, H, W)
     gx = (W + TILE - 1) // TILE
     gy = (H + TILE - 1) // TILE
+    if tile_windows is not None:
+        tile_windows = [(max(0, x0), max(0, y0), min(gx, x1), min(gy, y1)) for (x0, y0, x1, y1) in tile_windows]
+    gid, ranges, ghost_all = build_tile_lists(g, H, W, tile_windows, ghosts=True)
+    num_rendered = int((~ghost_all).sum())
     # relative half-width of the "a float32 implementation may legitimately flip this test" band
     tol = frag_tol if frag_tol is not None else 2e-5
 
-    color_rows, obj_rows, T_rows, n_rows, f_rows = [], [], [], [], []
+    if tile_windows is None:
+        todo = [(tx, ty) for ty in range(gy) for tx in range(gx)]
+    else:
+        seen = set()
+        for (x0, y0, x1, y1) in tile_windows:
+            for ty in range(y0, y1):
+                for tx in range(x0, x1):
+                    seen.add((tx, ty))
+        todo = sorted(seen, key=lambda q: (q[1], q[0]))
+
+    c_t, o_t, T_t, n_t, f_t = [], [], [], [], []
     yy, xx = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
-    for ty in range(gy):
-        c_t, o_t, T_t, n_t, f_t = [], [], [], [], []
-        for tx in range(gx):
-            s, e = int(ranges[ty * gx + tx, 0]), int(ranges[ty * gx + tx, 1])
-            ids = gid[s:e]
-            L = ids.numel()
-            pxs = (tx * TILE + xx).reshape(-1, 1).to(dtype)       # [256,1]
-            pys = (ty * TILE + yy).reshape(-1, 1).to(dtype)
-            if L == 0:
-                c_t.append(bg[:, None].expand(3, TILE * TILE).reshape(3, TILE, TILE))
-                o_t.append(torch.zeros(NUM_OBJECTS, TILE, TILE, dtype=dtype))
-                T_t.append(torch.ones(TILE, TILE, dtype=dtype))
-                n_t.append(torch.zeros(TILE, TILE, dtype=torch.int64))
-                f_t.append(torch.zeros(TILE, TILE, dtype=torch.bool))
-                continue
-            dx = g.xy[ids, 0][None, :] - pxs                       # [256,L]
-            dy = g.xy[ids, 1][None, :] - pys
-            A, B, C = g.conic[ids, 0][None], g.conic[ids, 1][None], g.conic[ids, 2][None]
-            power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
-            Gv = torch.exp(torch.clamp_max(power, 0.0))
-            a_raw = opac[ids][None, :] * Gv
-            alpha = a_raw - torch.relu(a_raw - 0.99).detach()      # min(0.99, .) with transparent backward
-            valid = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)
-            a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
-            one_m = 1.0 - a_eff
-            T_incl = torch.cumprod(one_m, dim=1)
-            T_excl = torch.cat([torch.ones(TILE * TILE, 1, dtype=dtype), T_incl[:, :-1]], dim=1)
-            stop = valid & (T_incl.detach() < 1e-4)
-            alive = torch.cumsum(stop.to(torch.int64), dim=1) == 0  # entries strictly before the stopping one
-            wgt = torch.where(alive & valid, a_eff * T_excl, torch.zeros_like(a_eff))   # [256,L]
-            col = wgt @ rgb[ids]                                    # [256,3]
-            # final T = T before the stopping entry, or the full product
-            contrib = alive & valid
-            T_alive = torch.where(alive, one_m, torch.ones_like(one_m))
-            T_fin = torch.prod(T_alive, dim=1)
-            pos = torch.arange(1, L + 1)[None, :].expand_as(contrib)
-            n_c = torch.where(contrib, pos, torch.zeros_like(pos)).max(dim=1).values
-            col = col + T_fin[:, None] * bg[None, :]
-            if objs is not None:
-                ob = wgt @ objs[ids]
-            else:
-                ob = torch.zeros(TILE * TILE, NUM_OBJECTS, dtype=dtype)
-            with torch.no_grad():
-                reach = alive | stop                               # entries the loop actually evaluated
-                fr = (reach & (power <= 0) & ((alpha * 255.0 - 1.0).abs() < tol)).any(dim=1)   # alpha ~ 1/255
-                fr |= (reach & valid & ((T_incl * 1e4 - 1.0).abs() < 10 * tol)).any(dim=1)      # T' ~ 1e-4
-                fr |= (reach & (power.abs() < 1e-6) & ((dx != 0) | (dy != 0))).any(dim=1)       # power ~ 0
-                fr |= g.fragile[ids].any()
-            c_t.append(col.t().reshape(3, TILE, TILE))
-            o_t.append(ob.t().reshape(NUM_OBJECTS, TILE, TILE))
-            T_t.append(T_fin.reshape(TILE, TILE))
-            n_t.append(n_c.reshape(TILE, TILE))
-            f_t.append(fr.reshape(TILE, TILE))
-        color_rows.append(torch.cat(c_t, dim=2))
-        obj_rows.append(torch.cat(o_t, dim=2))
-        T_rows.append(torch.cat(T_t, dim=1))
-        n_rows.append(torch.cat(n_t, dim=1))
-        f_rows.append(torch.cat(f_t, dim=1))
-    color = torch.cat(color_rows, dim=1)[:, :H, :W]
-    objects = torch.cat(obj_rows, dim=1)[:, :H, :W]
-    final_T = torch.cat(T_rows, dim=0)[:H, :W]
-    n_contrib = torch.cat(n_rows, dim=0)[:H, :W]
-    fragile_px = torch.cat(f_rows, dim=0)[:H, :W]
-    return RenderOut(color, g.radii, objects, final_T, n_contrib, fragile_px, int(gid.numel()), g.fragile)
+    for (tx, ty) in todo:
+        s, e = int(ranges[ty * gx + tx, 0]), int(ranges[ty * gx + tx, 1])
+        ids = gid[s:e]
+        ghost = ghost_all[s:e]
+        L = ids.numel()
+        pxs = (tx * TILE + xx).reshape(-1, 1).to(dtype)       # [256,1]
+        pys = (ty * TILE + yy).reshape(-1, 1).to(dtype)
+        if L == 0:
+            c_t.append(bg[:, None].expand(3, TILE * TILE).reshape(3, TILE, TILE))
+            o_t.append(torch.zeros(NUM_OBJECTS, TILE, TILE, dtype=dtype))
+            T_t.append(torch.ones(TILE, TILE, dtype=dtype))
+            n_t.append(torch.zeros(TILE, TILE, dtype=torch.int64))
+            f_t.append(torch.zeros(TILE, TILE, dtype=torch.bool))
+            continue
+        real = ~ghost
+        dx = g.xy[ids, 0][None, :] - pxs                       # [256,L]
+        dy = g.xy[ids, 1][None, :] - pys
+        A, B, C = g.conic[ids, 0][None], g.conic[ids, 1][None], g.conic[ids, 2][None]
+        power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
+        Gv = torch.exp(torch.clamp_max(power, 0.0))
+        a_raw = opac[ids][None, :] * Gv
+        alpha = a_raw - torch.relu(a_raw - 0.99).detach()      # min(0.99, .) with transparent backward
+        would = (power <= 0) & (alpha.detach() >= 1.0 / 255.0)  # passes the reference's two per-pixel tests
+        valid = would & real[None, :]
+        a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
+        one_m = 1.0 - a_eff
+        T_incl = torch.cumprod(one_m, dim=1)
+        T_excl = torch.cat([torch.ones(TILE * TILE, 1, dtype=dtype), T_incl[:, :-1]], dim=1)
+        stop = valid & (T_incl.detach() < 1e-4)
+        alive = torch.cumsum(stop.to(torch.int64), dim=1) == 0  # entries strictly before the stopping one
+        wgt = torch.where(alive & valid, a_eff * T_excl, torch.zeros_like(a_eff))   # [256,L]
+        col = wgt @ rgb[ids]                                    # [256,3]
+        # final T = T before the stopping entry, or the full product
+        contrib = alive & valid
+        T_alive = torch.where(alive, one_m, torch.ones_like(one_m))
+        T_fin = torch.prod(T_alive, dim=1)
+        pos = torch.cumsum(real.to(torch.int64), 0)[None, :].expand_as(contrib)   # list position without the ghosts
+        n_c = torch.where(contrib, pos, torch.zeros_like(pos)).max(dim=1).values
+        col = col + T_fin[:, None] * bg[None, :]
+        if objs is not None:
+            ob = wgt @ objs[ids]
+        else:
+            ob = torch.zeros(TILE * TILE, NUM_OBJECTS, dtype=dtype)
+        with torch.no_grad():
+            reach = alive | stop                               # entries the loop actually evaluated
+            fr = (reach & real[None] & (power <= 0) & ((alpha * 255.0 - 1.0).abs() < tol)).any(dim=1)   # alpha ~ 1/255
+            fr |= (reach & valid & ((T_incl * 1e4 - 1.0).abs() < 10 * tol)).any(dim=1)      # T' ~ 1e-4
+            fr |= (reach & real[None] & (power.abs() < 1e-6) & ((dx != 0) | (dy != 0))).any(dim=1)   # power ~ 0
+            # Gaussians whose integer decisions (radius, tile rect, near-plane cull) are fragile: a float32
+            # implementation may drop them from this tile (real entries) or add them to it (ghost entries).  Only the
+            # pixels where such an entry passes -- or all but passes -- the alpha test can differ.
+            loose = (power <= 0) & (alpha >= (1.0 - 1e-3) / 255.0)
+            flip = (g.fragile[ids] & real)[None] | ghost[None]
+            fr |= (reach & flip & loose).any(dim=1)
+        c_t.append(col.t().reshape(3, TILE, TILE))
+        o_t.append(ob.t().reshape(NUM_OBJECTS, TILE, TILE))
+        T_t.append(T_fin.reshape(TILE, TILE))
+        n_t.append(n_c.reshape(TILE, TILE))
+        f_t.append(fr.reshape(TILE, TILE))
+
+    # assemble: one differentiable scatter of the composited tiles into the (tile-padded) image
+    tys = torch.tensor([q[1] for q in todo], dtype=torch.int64)
+    txs = torch.tensor([q[0] for q in todo], dtype=torch.int64)
+
+    def assemble(tiles, ch, dt, fill=0):
+        buf = torch.full((gy, gx) + ((ch,) if ch else ()) + (TILE, TILE), fill, dtype=dt)
+        if len(tiles):
+            buf = buf.index_put((tys, txs), torch.stack(tiles))
+        if ch:
+            return buf.permute(2, 0, 3, 1, 4).reshape(ch, gy * TILE, gx * TILE)[:, :H, :W]
+        return buf.permute(0, 2, 1, 3).reshape(gy * TILE, gx * TILE)[:H, :W]
+    color = assemble(c_t, 3, dtype)
+    objects = assemble(o_t, NUM_OBJECTS, dtype)
+    final_T = assemble(T_t, 0, dtype)
+    n_contrib = assemble(n_t, 0, torch.int64)
+    fragile_px = assemble(f_t, 0, torch.bool, False)
+    window_px = None
+    if tile_windows is not None:
+        window_px = assemble([torch.ones(TILE, TILE, dtype=torch.bool)] * len(todo), 0, torch.bool, False)
+    return RenderOut(color, g.radii, objects, final_T, n_contrib, fragile_px, num_rendered, g.fragile, window_px)
 
 
 def mark_visible(means3D, st: Settings) -> torch.Tensor:
@@ -393,7 +467,8 @@ def mark_visible(means3D, st: Settings) -> torch.Tensor:
 # convenience: forward + backward for a fixed dL/dC (what tests and bench use)
 # --------------------------------------------------------------------------
 
-def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, dtype=torch.float64):
+def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, dtype=torch.float64,
+                     tile_windows=None):
     """inputs: dict of float tensors (means3D, shs, opacities, scales, rotations[, sh_objs, ...]).
     Returns (RenderOut, grads dict incl. 'means2D')."""
     leaf = {}
@@ -404,7 +479,7 @@ def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, 
     out = rasterize(leaf["means3D"], m2d, leaf["opacities"], st, shs=leaf.get("shs"),
                     sh_objs=leaf.get("sh_objs"), colors_precomp=leaf.get("colors_precomp"),
                     scales=leaf.get("scales"), rotations=leaf.get("rotations"),
-                    cov3D_precomp=leaf.get("cov3D_precomp"), dtype=dtype)
+                    cov3D_precomp=leaf.get("cov3D_precomp"), dtype=dtype, tile_windows=tile_windows)
     loss = (out.color * grad_color.to(dtype)).sum()
     if grad_objects is not None:
         loss = loss + (out.objects * grad_objects.to(dtype)).sum()

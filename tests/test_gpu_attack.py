@@ -100,7 +100,8 @@ def test_combined_scene_render_equals_render_of_the_concatenated_attributes():
     assert torch.equal(ref, got)
 
 
-@pytest.mark.parametrize("shape", [(5000, 3), (4097, 4), (3000, 1), (2500, 15, 3), (1, 1, 3), (64, 45)])
+@pytest.mark.parametrize("shape", [(5000, 3), (4097, 4), (3000, 1), (2500, 15, 3), (1, 1, 3), (64, 45),
+                                   (5022, 3), (4106, 15, 3), (94, 4), (30, 3), (10, 45)])
 @pytest.mark.parametrize("kind", ["linf", "l2"])
 def test_fused_pgd_step_matches_the_tensor_formulation(shape, kind):
     """gsr_pgd_step (HIP) against the PyTorch statement of the reference's update rules (gsplat_attack/pgd.py on CPU,

@@ -14,7 +14,7 @@ def _brute(pts):
 @pytest.mark.parametrize("kind", ["uniform", "city", "flat", "duplicates", "outliers", "tiny"])
 def test_matches_brute_force(kind):
     from simple_knn._C import distCUDA2
-    g = torch.Generator().manual_seed(hash(kind) % 1000)
+    g = torch.Generator().manual_seed(sum(map(ord, kind)))   # str hashes change per process
     if kind == "uniform":
         pts = torch.rand(6000, 3, generator=g) * 10
     elif kind == "city":
