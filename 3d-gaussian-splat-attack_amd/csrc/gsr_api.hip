@@ -234,6 +234,12 @@ struct GsrCtx {
   // kept workspace
   void* keep_blk = nullptr;
   void* rank_blk = nullptr;
+  void* seg_blk = nullptr;        // boundary records of split tiles (null: no tile is split)
+  float4* bnd = nullptr;
+  uint32_t* segoff = nullptr;
+  uint2* rec_item = nullptr;
+  uint32_t* nrec = nullptr;
+  uint32_t seg_shift = 0, rec_cap = 0;
   size_t keep_bytes = 0;
   float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;   // splat records in depth order
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // the same in storage order
@@ -274,6 +280,7 @@ void gsr_ctx_free(GsrCtx* c) {
   if (!c) return;
   pool_free(c->dev, c->keep_blk);
   pool_free(c->dev, c->rank_blk);
+  pool_free(c->dev, c->seg_blk);
   delete c;
 }
 
@@ -485,7 +492,28 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     ra.map_mode = map_mode_f;
     ra.sched = c->sched;
     ra.wave_clock = g_wave_clock_fwd.load();
-    if (map_mode_f == 3) hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched);
+    // Long tile lists are split into segments for the backward (gsr_kernels.hip.h, "Segments"): the forward stores the
+    // per-pixel (T, C) at the segment boundaries.  Not with object channels (their 16 running sums are not stored), not
+    // for a forward-only call, not under GSR_FLAG_NO_SEGMENTS.
+    static const int seg_shift_env = [] { const char* e = getenv("GSR_SEG_SHIFT"); int v = e ? atoi(e) : 8; return (v >= 6 && v <= 16) ? v : 8; }();
+    ra.bnd = nullptr; ra.segoff = nullptr; ra.seg_shift = 0;
+    if (N > 0 && ctx_out && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
+      const uint32_t per = N >> seg_shift_env;
+      c->seg_shift = (uint32_t)seg_shift_env;
+      c->rec_cap = per + std::min<uint32_t>((uint32_t)ntiles, per) + 1u;   // sum over split tiles of ceil(len / seg)
+      SlabPlan gp;
+      gp.add<float4>((size_t)c->rec_cap * PXL * 64); gp.add<uint2>(c->rec_cap); gp.add<uint32_t>(ntiles); gp.add<uint32_t>(4);
+      c->seg_blk = pool_alloc(dev, gp.bytes + 256, st);
+      if (!c->seg_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: segment boundary buffer (N=%u) allocation failed", N));
+      Slab gs{static_cast<char*>(c->seg_blk), gp.bytes + 256, 0};
+      c->bnd = gs.take<float4>((size_t)c->rec_cap * PXL * 64); c->rec_item = gs.take<uint2>(c->rec_cap);
+      c->segoff = gs.take<uint32_t>(ntiles); c->nrec = gs.take<uint32_t>(4);
+      F_TRY("segments", hipMemsetAsync(c->rec_item, 0, sizeof(uint2) * c->rec_cap, st));
+      ra.bnd = c->bnd; ra.segoff = c->segoff; ra.seg_shift = c->seg_shift;
+    }
+    if (map_mode_f == 3 || c->bnd)
+      hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift, c->segoff,
+                         c->rec_item, c->rec_cap, c->nrec);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
     // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
@@ -585,7 +613,11 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.wave_clock = g_wave_clock.load();
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
-    const dim3 gridT(render_grid(c->ntiles * (int)nsub)), blk(64);
+    // split tiles: one extra work item per boundary record, in front of the per-tile items
+    const bool segs = c->bnd != nullptr && !obj;
+    ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->nrec;
+    ra.seg_shift = c->seg_shift; ra.extra_blocks = segs ? c->rec_cap * nsub : 0u;
+    const dim3 gridT(ra.extra_blocks + (unsigned)render_grid(c->ntiles * (int)nsub)), blk(64);
     if (obj) {
       if (geom) {
         if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4, true>), gridT, blk, 0, st, ra);

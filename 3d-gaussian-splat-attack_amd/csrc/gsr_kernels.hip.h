@@ -316,8 +316,28 @@ struct RenderArgs {
   float* out_objects;     // [16,H,W] or null
   float* final_T;         // [H*W]
   uint32_t* n_contrib;    // [H*W]
+  // segment boundaries of long tile lists (see "Segments" below); bnd == nullptr: none are kept
+  float4* bnd;            // [records][256] (T, C_r, C_g, C_b) per pixel, pixel = strip * 64 + lane
+  const uint32_t* segoff; // [ntiles] first boundary record of the tile, SEG_NONE for tiles that are not split
+  uint32_t seg_shift;     // log2 of the segment length
   unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock_fwd): [ntiles * NSUB][2] start/end, 100 MHz
 };
+
+// ------------------------------------------------------------------------------------------------
+// Segments.  Front-to-back compositing is associative in (T, C): the state after list position b, (T_b, C_b), is all
+// that the entries behind b need from the entries in front of it.  The forward walk of a tile whose list is longer
+// than one segment (2^seg_shift entries) stores that state per pixel at every segment boundary, plus its final (T, C);
+// the backward then walks every SEGMENT as an independent work item on its own wave: a pixel whose last contributor
+// lies behind the segment starts from T_b and from the colour it shows behind b,
+//     Acc_b = ((C_final - C_b) . g + T_final (bg . g)) / T_b,
+// instead of from (T_final, bg . g) -- the same two recursions the unsplit walk carries (T /= 1 - alpha,
+// Acc = alpha c.g + (1 - alpha) Acc), cut at b.  The serial walk of the ~1000-entry lists, which used to set the run
+// time of the backward composite long after the average SIMD had run dry, becomes 2^seg_shift entries at most.
+// A tile's records: one per interior boundary j = 1 .. nseg-1 (record segoff + j - 1), then the final state
+// (record segoff + nseg - 1).  rec_item[r] = {tile, j} names the extra backward work item of record r (j = 0: final
+// record, no item).  Tiles that are not split (segoff = SEG_NONE) run exactly the code they ran before.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t SEG_NONE = 0xFFFFFFFFu;
 
 constexpr int PXL = 4;   // pixels per lane
 constexpr float LOG2E = 1.4426950408889634f;
@@ -326,8 +346,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 // is handed the contiguous band [x*ceil(n/8), ...): neighbouring tiles share one L2.  mode 0: identity (items are
 // dealt round-robin over the XCDs: no L2 sharing, but image regions of different cost spread over all XCDs).
 // mode 2: bands of 32 consecutive items are dealt round-robin: local sharing inside a band, global spread.
-__device__ __forceinline__ int item_of_block(int nitems, int mode) {
-  const int b = (int)blockIdx.x;
+__device__ __forceinline__ int item_of_block(int b, int nitems, int mode) {
   if (mode == 0) return b;
   if (mode == 1) {
     const int tpx = (nitems + 7) >> 3;
@@ -337,7 +356,6 @@ __device__ __forceinline__ int item_of_block(int nitems, int mode) {
   const int x = b & 7, s = b >> 3;
   return ((s >> 5) * 8 + x) * 32 + (s & 31);
 }
-__device__ __forceinline__ int tile_of_block(int ntiles) { return item_of_block(ntiles, 1); }
 
 // ------------------------------------------------------------------------------------------------
 // Tile schedule (map mode 3, the default).  A tile's list is walked serially by its wave(s), so the longest list
@@ -349,8 +367,12 @@ __device__ __forceinline__ int tile_of_block(int ntiles) { return item_of_block(
 // ------------------------------------------------------------------------------------------------
 constexpr int SCHED_BINS = 1024;
 constexpr uint32_t SCHED_TILE_MASK = (1u << 28) - 1u;
+// seg_shift = 0: no tile is split.  rec_cap: capacity of the boundary-record buffer (a tile whose records would not
+// fit stays unsplit); nrec_out receives the number of records in use.
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2* __restrict__ ranges,
-                                                        uint32_t* __restrict__ sched) {
+                                                        uint32_t* __restrict__ sched, uint32_t seg_shift,
+                                                        uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
+                                                        uint32_t rec_cap, uint32_t* __restrict__ nrec_out) {
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
@@ -390,6 +412,46 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
     const uint32_t prio = (uint32_t)(((uint64_t)len * 4u) / longest);      // 0..3
     sched[p] = (uint32_t)i | (prio << 28);
   }
+  // ---- boundary records of the split tiles: exclusive scan of nseg over the tiles, in tile order ------------------
+  if (segoff == nullptr) return;
+  __syncthreads();
+  const uint32_t seg_len = 1u << seg_shift;
+  const int chunk = (ntiles + 1023) / 1024;
+  const int i0 = min(t * chunk, ntiles), i1 = min(i0 + chunk, ntiles);
+  uint32_t mine = 0;
+  if (seg_shift != 0u) {
+    for (int i = i0; i < i1; ++i) {
+      const uint2 r = ranges[i];
+      const uint32_t len = r.y - r.x;
+      if (len > seg_len) mine += (len + seg_len - 1u) >> seg_shift;
+    }
+  }
+  uint32_t inc2 = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc2, d, 64);
+    if (lane >= d) inc2 += o;
+  }
+  if (lane == 63) wsum[wave] = inc2;
+  __syncthreads();
+  uint32_t run = inc2 - mine;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+  for (int i = i0; i < i1; ++i) {
+    const uint2 r = ranges[i];
+    const uint32_t len = r.y - r.x;
+    uint32_t off = SEG_NONE;
+    if (seg_shift != 0u && len > seg_len) {
+      const uint32_t nseg = (len + seg_len - 1u) >> seg_shift;
+      if (run + nseg <= rec_cap) {
+        off = run;
+        for (uint32_t j = 1; j < nseg; ++j) rec_item[run + j - 1u] = make_uint2((uint32_t)i, j);
+        rec_item[run + nseg - 1u] = make_uint2((uint32_t)i, 0u);
+      }
+      run += nseg;                                  // counted either way: the scan above did
+    }
+    segoff[i] = off;
+  }
+  if (t == 1023) *nrec_out = min(run, rec_cap);
 }
 __device__ __forceinline__ void set_wave_priority(uint32_t prio) {
   if (prio == 3u) __builtin_amdgcn_s_setprio(3);
@@ -433,12 +495,15 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     item = (int)(sc & SCHED_TILE_MASK) * NSUB + (int)(blockIdx.x % NSUB);
     set_wave_priority(sc >> 28);
   } else {
-    item = item_of_block(a.ntiles * NSUB, a.map_mode);
+    item = item_of_block((int)blockIdx.x, a.ntiles * NSUB, a.map_mode);
     if (item >= a.ntiles * NSUB) return;
   }
   const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
+  // a split tile (see "Segments"): this wave stores (T, C) of its pixels at every segment boundary it walks past
+  const uint32_t rec0 = (!OBJ && a.bnd != nullptr) ? a.segoff[tile] : SEG_NONE;
+  const uint32_t seg_mask = (1u << a.seg_shift) - 1u;
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)x;
@@ -483,7 +548,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (todo == 0ull) continue;
+    if (todo != 0ull) {
     int j = __builtin_ctzll(todo);
     float4 n0 = s0[j], n1 = s1[j];
     float2 n2 = s2[j];
@@ -530,7 +595,22 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       }
       if (!more) break;
     }
+    }
     __builtin_amdgcn_wave_barrier();
+    if (!OBJ && rec0 != SEG_NONE) {
+      const uint32_t pos_end = base - rg.x + 64u;       // list positions 1 .. pos_end are behind us
+      if ((pos_end & seg_mask) == 0u && pos_end < rg.y - rg.x) {
+        float4* rec = a.bnd + ((size_t)(rec0 + (pos_end >> a.seg_shift) - 1u) * PXL + sub * NPX) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) rec[k * 64] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
+      }
+    }
+  }
+  if (!OBJ && rec0 != SEG_NONE) {                       // final state of a split tile: record rec0 + nseg - 1
+    const uint32_t nseg = (rg.y - rg.x + seg_mask) >> a.seg_shift;
+    float4* rec = a.bnd + ((size_t)(rec0 + nseg - 1u) * PXL + sub * NPX) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) rec[k * 64] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
   }
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
@@ -606,6 +686,12 @@ struct RenderBwdArgs {
   const float* grad_objects;  // [16,H,W] or null
   float4* part;               // [N][3]
   float4* part_obj;           // [N][4] or null
+  // split tiles (see "Segments"): the first extra_blocks workgroups are the extra work items, one per boundary record
+  const float4* bnd;          // null: no tile is split
+  const uint32_t* segoff;
+  const uint2* rec_item;
+  const uint32_t* nrec;
+  uint32_t seg_shift, extra_blocks;
   uint32_t tag_lo, tag_hi;    // stamped into every row written by this call
   unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock): [ntiles][2] start/end of each tile's wave, 100 MHz
 };
@@ -634,19 +720,41 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float sred[RB * RENTRY];
   const int lane = threadIdx.x;
   int item;
-  if (a.map_mode == 3) {
-    if ((int)blockIdx.x >= a.ntiles * NSUB) return;
-    const uint32_t sc = a.sched[blockIdx.x / NSUB];
-    item = (int)(sc & SCHED_TILE_MASK) * NSUB + (int)(blockIdx.x % NSUB);
-    set_wave_priority(sc >> 28);
+  uint32_t seg = 0;                                   // segment of the tile's list this wave walks
+  if (blockIdx.x < a.extra_blocks) {
+    // extra work item of a split tile: segment j >= 1.  They come first in the grid: each is a full segment long.
+    const uint32_t r = blockIdx.x / NSUB;
+    if (r >= *a.nrec) return;
+    const uint2 it = a.rec_item[r];
+    if (it.y == 0u) return;                           // the tile's final-state record: no work item
+    item = (int)it.x * NSUB + (int)(blockIdx.x % NSUB);
+    seg = it.y;
+    set_wave_priority(3u);
   } else {
-    item = item_of_block(a.ntiles * NSUB, a.map_mode);
-    if (item >= a.ntiles * NSUB) return;
+    const int b = (int)(blockIdx.x - a.extra_blocks);
+    if (a.map_mode == 3) {
+      if (b >= a.ntiles * NSUB) return;
+      const uint32_t sc = a.sched[b / NSUB];
+      item = (int)(sc & SCHED_TILE_MASK) * NSUB + (b % NSUB);
+      set_wave_priority(sc >> 28);
+    } else {
+      item = item_of_block(b, a.ntiles * NSUB, a.map_mode);
+      if (item >= a.ntiles * NSUB) return;
+    }
   }
   const int tile = item / NSUB, sub = item - tile * NSUB;
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
-  if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
+  // list positions (a_pos, b_pos] are this wave's; an unsplit tile: the whole list
+  const uint32_t rec0 = (!OBJ && a.bnd != nullptr) ? a.segoff[tile] : SEG_NONE;
+  uint32_t a_pos = 0, b_pos = rg.y - rg.x, nseg = 1;
+  if (!OBJ && rec0 != SEG_NONE) {
+    nseg = (rg.y - rg.x + (1u << a.seg_shift) - 1u) >> a.seg_shift;
+    a_pos = seg << a.seg_shift;
+    b_pos = min(a_pos + (1u << a.seg_shift), rg.y - rg.x);
+  }
+  const bool clocked = a.wave_clock != nullptr && seg == 0u;
+  if (clocked && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
   const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
   const int red_e = lane / (4 * NREG), red_v = 2 * ((lane % (4 * NREG)) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
@@ -682,6 +790,22 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
 #pragma unroll
         for (int c = 0; c < NUM_OBJ; ++c) gO[k][c] = a.grad_objects[c * HW + pix];
       }
+      if (!OBJ && rec0 != SEG_NONE) {
+        if (ncon[k] > b_pos) {
+          // the pixel's last contributor lies behind this segment: start from the forward's state at b_pos
+          const size_t px = (size_t)(sub * NPX + k) * 64 + lane;
+          const float4 B = a.bnd[(size_t)(rec0 + seg) * (PXL * 64) + px];
+          if (GEOM) {
+            const float4 F = a.bnd[(size_t)(rec0 + nseg - 1u) * (PXL * 64) + px];
+            const float behind = fmaf(F.y - B.y, g0[k], fmaf(F.z - B.z, g1[k], (F.w - B.w) * g2[k]));
+            Acc[k] = fmaf(T[k], Acc[k], behind) / B.x;          // T[k] = T_final, Acc[k] = bg . g here
+          }
+          T[k] = B.x;
+          ncon[k] = b_pos;
+        } else if (ncon[k] <= a_pos) {
+          ncon[k] = 0;                                           // finished in front of this segment
+        }
+      }
     } else {
       T[k] = 1.f; ncon[k] = 0; g0[k] = g1[k] = g2[k] = 0.f;
       if (OBJ) {
@@ -692,8 +816,8 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     smax[k] = __builtin_amdgcn_readfirstlane(wave_max_u32(ncon[k]));   // last list position this strip uses
     maxc = max(maxc, smax[k]);
   }
-  for (int hi = (int)maxc; hi > 0; hi -= 64) {
-    const int lo = max(hi - 64, 0);
+  for (int hi = (int)maxc; hi > (int)a_pos; hi -= 64) {
+    const int lo = max(hi - 64, (int)a_pos);
     const int cnt = hi - lo;
     if (lane < cnt) {
       const uint32_t pv = a.pair_rank[rg.x + lo + lane];
@@ -848,7 +972,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
+  if (clocked && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -151,10 +151,14 @@ class Geom(NamedTuple):
     ghost_min: torch.Tensor  # [P,2] int  tile rect a float32 implementation might use instead (= rect unless fragile)
     ghost_max: torch.Tensor  # [P,2] int
     maybe: torch.Tensor      # [P] bool   culled here, but a float32 implementation might keep it (fragile cull)
+    e_conic: torch.Tensor    # [P,3]      error bars (see preprocess) of the conic,
+    e_xy: torch.Tensor       # [P,2]      the pixel centre
+    e_depth: torch.Tensor    # [P]        and the view depth
 
 
-def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
-    """K1 of SURVEY.md section 8(a) row a4, steps (1)-(8) and (10)."""
+def _project(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
+    """The arithmetic of K1 in the dtype of its inputs.
+    -> dict(tz, in_front, det_ok, conic [P,3], rr (un-rounded radius 3 sqrt(lambda)), px, py)."""
     dt = means3D.dtype
     H, W = int(st.image_height), int(st.image_width)
     V = st.viewmatrix.to(dt)
@@ -203,10 +207,46 @@ def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=
     disc = torch.clamp_min(mid * mid - det, 0.1)
     lam = mid + torch.sqrt(disc)
     rr = 3.0 * torch.sqrt(lam.detach())
-    radius = torch.ceil(rr)
     px = ((ndc[:, 0] + 1.0) * W - 1.0) * 0.5
     py = ((ndc[:, 1] + 1.0) * H - 1.0) * 0.5
+    return dict(tz=tz, in_front=in_front, det_ok=det_ok, conic=conic, rr=rr, px=px, py=py)
+
+
+ERR_SAFETY = 8.0   # error bar = ERR_SAFETY * |float32 run - float64 run| + a few ulps
+
+
+def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
+    """K1 of SURVEY.md section 8(a) row a4, steps (1)-(8) and (10), plus error bars.
+
+    The implementation under test computes in float32.  To know where ITS threshold decisions may legitimately differ
+    from this restatement's, the same arithmetic is run a second time in the other precision (float32 when the
+    caller asked for float64 and vice versa, no gradients): ERR_SAFETY times the difference between the two runs, plus
+    a few float32 ulps, is the per-Gaussian error bar of the radius, the pixel centre, the conic and the depth.
+    `fragile` marks Gaussians whose integer decisions (ceil of the radius, tile rect, near-plane cull) sit inside their
+    bar; rasterize() uses the bars of conic / centre / depth for the per-pixel tests."""
+    dt = means3D.dtype
+    H, W = int(st.image_height), int(st.image_width)
+    q = _project(means3D, scales, rotations, cov3D_precomp, st, means2D)
+    other = torch.float32 if dt == torch.float64 else torch.float64
+    with torch.no_grad():
+        def cv(t):
+            return None if t is None else t.detach().to(other)
+        q2 = _project(cv(means3D), cv(scales), cv(rotations), cv(cov3D_precomp), st, cv(means2D))
+    tz, in_front, det_ok, conic, rr = q["tz"], q["in_front"], q["det_ok"], q["conic"], q["rr"]
+    px, py = q["px"], q["py"]
     xy = torch.stack([px, py], dim=1)
+    radius = torch.ceil(rr)
+    f32eps = 1.2e-7
+
+    def bar(x, x2, floor):
+        d = (x.detach().double() - x2.double()).abs()
+        d = torch.nan_to_num(d, nan=0.0, posinf=0.0, neginf=0.0)
+        return ERR_SAFETY * d + floor
+    e_rr = bar(rr, q2["rr"], 8 * f32eps * rr.detach().double().abs())
+    e_px = bar(px, q2["px"], 4 * f32eps * max(W, 1))
+    e_py = bar(py, q2["py"], 4 * f32eps * max(H, 1))
+    e_z = bar(tz, q2["tz"], 4 * f32eps * tz.detach().double().abs())
+    e_con = bar(conic, q2["conic"], 8 * f32eps * conic.detach().double().abs())
 
     gx = (W + TILE - 1) // TILE
     gy = (H + TILE - 1) // TILE
@@ -223,15 +263,16 @@ def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=
     valid = in_front & det_ok & (area > 0)
     radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
 
-    # fragile integer decisions (used by tests to excuse +-1 radius / rect flips in float32)
+    # fragile integer decisions: the decision variable sits inside its error bar of the edge
     def _near_int(v, tol):
+        v = torch.nan_to_num(v.double(), nan=0.0, posinf=0.0, neginf=0.0)
         return (v - torch.round(v)).abs() < tol
-    tol = 2e-4 if dt == torch.float32 else 1e-9
-    fragile = _near_int(rr, tol * rr.clamp_min(1.0))
-    for q in ((pxd - radius) / TILE, (pyd - radius) / TILE,
-              (pxd + radius + (TILE - 1)) / TILE, (pyd + radius + (TILE - 1)) / TILE):
-        fragile = fragile | _near_int(q, tol * q.abs().clamp_min(1.0))
-    fragile = fragile | ((tz - 0.2).abs() < tol)
+    fragile = _near_int(rr.detach(), e_rr)
+    for qv, e in (((pxd - radius) / TILE, e_px), ((pyd - radius) / TILE, e_py),
+                  ((pxd + radius + (TILE - 1)) / TILE, e_px), ((pyd + radius + (TILE - 1)) / TILE, e_py)):
+        fragile = fragile | _near_int(qv, e / TILE + 1e-7)
+    fragile = fragile | ((tz.detach().double() - 0.2).abs() < e_z)
+    fragile = fragile & (tz.detach() > 0.1)
 
     # The rect a float32 implementation might legitimately arrive at for a fragile Gaussian: one tile more on every
     # side.  rasterize() walks these extra (tile, Gaussian) pairs as GHOSTS -- they never contribute, they only mark
@@ -245,7 +286,8 @@ def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=
 
     return Geom(valid, radii, xy, tz, conic,
                 torch.stack([rminx, rminy], dim=1), torch.stack([rmaxx, rmaxy], dim=1), fragile,
-                torch.stack([gminx, gminy], dim=1), torch.stack([gmaxx, gmaxy], dim=1), maybe)
+                torch.stack([gminx, gminy], dim=1), torch.stack([gmaxx, gmaxy], dim=1), maybe,
+                e_con.to(dt), torch.stack([e_px, e_py], dim=1).to(dt), e_z.to(dt))
 
 
 # --------------------------------------------------------------------------
@@ -419,15 +461,38 @@ def rasterize(means3D, means2D, opacities, st: Settings, shs=None, sh_objs=None,
             ob = torch.zeros(TILE * TILE, NUM_OBJECTS, dtype=dtype)
         with torch.no_grad():
             reach = alive | stop                               # entries the loop actually evaluated
-            fr = (reach & real[None] & (power <= 0) & ((alpha * 255.0 - 1.0).abs() < tol)).any(dim=1)   # alpha ~ 1/255
-            fr |= (reach & valid & ((T_incl * 1e4 - 1.0).abs() < 10 * tol)).any(dim=1)      # T' ~ 1e-4
-            fr |= (reach & real[None] & (power.abs() < 1e-6) & ((dx != 0) | (dy != 0))).any(dim=1)   # power ~ 0
+            # error bar of `power` at every (pixel, entry): first-order propagation of the conic / centre bars of
+            # preprocess(), plus the rounding of the float32 evaluation of the quadratic form itself
+            eA, eB, eC = g.e_conic[ids, 0][None], g.e_conic[ids, 1][None], g.e_conic[ids, 2][None]
+            ex, ey = g.e_xy[ids, 0][None], g.e_xy[ids, 1][None]
+            adx, ady = dx.abs(), dy.abs()
+            e_pow = (0.5 * eA * dx * dx + 0.5 * eC * dy * dy + eB * adx * ady
+                     + (A * dx + B * dy).abs() * ex + (C * dy + B * dx).abs() * ey
+                     + 6e-7 * (0.5 * A.abs() * dx * dx + 0.5 * C.abs() * dy * dy + B.abs() * adx * ady))
+            e_al = e_pow + tol                                 # relative bar of alpha = o exp(power): d ln(alpha) = d power
+            near_floor = (alpha * 255.0 - 1.0).abs() < e_al    # alpha ~ 1/255
+            fr = (reach & real[None] & (power <= e_pow) & near_floor).any(dim=1)
+            fr |= (reach & real[None] & (power.abs() < e_pow) & would & ((dx != 0) | (dy != 0))).any(dim=1)   # power ~ 0
+            # T' = prod (1 - alpha): relative bar = sum over the contributing entries of alpha/(1-alpha) * bar(alpha)
+            e_T = torch.cumsum(torch.where(valid, a_eff / one_m * e_al, torch.zeros_like(e_al)), dim=1) + tol
+            fr |= (reach & valid & ((T_incl * 1e4 - 1.0).abs() < e_T)).any(dim=1)           # T' ~ 1e-4
             # Gaussians whose integer decisions (radius, tile rect, near-plane cull) are fragile: a float32
             # implementation may drop them from this tile (real entries) or add them to it (ghost entries).  Only the
             # pixels where such an entry passes -- or all but passes -- the alpha test can differ.
-            loose = (power <= 0) & (alpha >= (1.0 - 1e-3) / 255.0)
+            loose = (power <= e_pow) & (alpha * 255.0 >= 1.0 - e_al)
             flip = (g.fragile[ids] & real)[None] | ghost[None]
             fr |= (reach & flip & loose).any(dim=1)
+            # depth near-ties: list neighbours (up to two apart) whose float32 depth keys may sort the other way round;
+            # only pixels that both of them reach can differ
+            if L > 1:
+                z = g.depth.detach()[ids].double()
+                ez = g.e_depth[ids].double()
+                for sft in (1, 2):
+                    if L > sft:
+                        tie = (z[sft:] - z[:-sft]) <= (ez[sft:] + ez[:-sft])
+                        if bool(tie.any()):
+                            both = loose[:, sft:] & loose[:, :-sft] & reach[:, :-sft] & tie[None, :]
+                            fr |= both.any(dim=1)
         c_t.append(col.t().reshape(3, TILE, TILE))
         o_t.append(ob.t().reshape(NUM_OBJECTS, TILE, TILE))
         T_t.append(T_fin.reshape(TILE, TILE))
@@ -467,10 +532,23 @@ def mark_visible(means3D, st: Settings) -> torch.Tensor:
 # convenience: forward + backward for a fixed dL/dC (what tests and bench use)
 # --------------------------------------------------------------------------
 
+def solid_grads(out: RenderOut, grad_color, grad_objects=None):
+    """dL/dC (and dL/dobjects) with the fragile pixels -- and, for a windowed render, the pixels outside the windows --
+    zeroed.  A parity test feeds THESE to both sides: a pixel where a float32 threshold test may legitimately flip then
+    owns no gradient, so the gradient comparison needs no outlier allowance."""
+    keep = ~out.fragile_px
+    if out.window_px is not None:
+        keep = keep & out.window_px
+    gc = grad_color * keep.to(grad_color.dtype)
+    go = None if grad_objects is None else grad_objects * keep.to(grad_objects.dtype)
+    return gc, go
+
+
 def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, dtype=torch.float64,
-                     tile_windows=None):
+                     tile_windows=None, drop_fragile: bool = False):
     """inputs: dict of float tensors (means3D, shs, opacities, scales, rotations[, sh_objs, ...]).
-    Returns (RenderOut, grads dict incl. 'means2D')."""
+    Returns (RenderOut, grads dict incl. 'means2D').  drop_fragile: the loss ignores the fragile pixels
+    (solid_grads(); the caller gets the effective dL/dC by calling solid_grads on the returned RenderOut)."""
     leaf = {}
     for k, v in inputs.items():
         leaf[k] = None if v is None else v.detach().to(dtype).clone().requires_grad_(True)
@@ -480,6 +558,8 @@ def forward_backward(inputs: dict, st: Settings, grad_color, grad_objects=None, 
                     sh_objs=leaf.get("sh_objs"), colors_precomp=leaf.get("colors_precomp"),
                     scales=leaf.get("scales"), rotations=leaf.get("rotations"),
                     cov3D_precomp=leaf.get("cov3D_precomp"), dtype=dtype, tile_windows=tile_windows)
+    if drop_fragile:
+        grad_color, grad_objects = solid_grads(out, grad_color, grad_objects)
     loss = (out.color * grad_color.to(dtype)).sum()
     if grad_objects is not None:
         loss = loss + (out.objects * grad_objects.to(dtype)).sum()
