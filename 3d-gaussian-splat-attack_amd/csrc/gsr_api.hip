@@ -243,6 +243,8 @@ struct GsrCtx {
   size_t keep_bytes = 0;
   float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;   // splat records in depth order
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // the same in storage order
+  float* D = nullptr;             // [P,9] d rgb / d view direction (lane-group kernels, SH input, backward expected)
+  bool lanegroup = false;         // K1 ran as k_pre_fwd: K8+K9 runs as k_pre_bwd
   uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
   uint32_t* sched = nullptr;      // [ntiles] tiles longest-list-first + priority class
@@ -340,6 +342,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   kp.add<float4>(3 * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<unsigned long long>(2); kp.add<uint32_t>(ntiles);
+  // the SH layouts the reference uses (and precomputed colours) take the lane-group kernels
+  c->lanegroup = raw || (shs && K == 16) || colors_precomp != nullptr;
+  const bool want_D = c->lanegroup && shs != nullptr && ctx_out != nullptr;
+  if (want_D) kp.add<float>(9 * Pp);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
@@ -361,6 +367,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   c->total64 = ks.take<unsigned long long>(2);
   c->sched = ks.take<uint32_t>(ntiles);
+  if (want_D) c->D = ks.take<float>(9 * Pp);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
@@ -397,13 +404,14 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   if (P > 0) {
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
-      if (raw)
-        hipLaunchKernelGGL((k_preprocess<true, true>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
-                           cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
-      else if (shs && K == 16)
-        hipLaunchKernelGGL((k_preprocess<true, false>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
-                           cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
-      else
+      if (c->lanegroup) {
+        PreArgs pa;
+        pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
+        pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
+        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkeyA; pa.tcnt = tcnt;
+        if (raw) hipLaunchKernelGGL((k_pre_fwd<true>), gridPre, blkPre, 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_fwd<false>), gridPre, blkPre, 0, st, pa);
+      } else
         hipLaunchKernelGGL((k_preprocess<false, false>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
                            cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
       // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
@@ -644,7 +652,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
     pa.tag_lo = tag_lo; pa.tag_hi = tag_hi; pa.nsub = nsub;
     pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
-    pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc;
+    pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc; pa.D = c->D;
     pa.dmeans3D = dmeans3D; pa.dmeans2D = dmeans2D; pa.dsh = c->shs ? dshs : nullptr; pa.dsh_objs = dsh_objs;
     pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
@@ -652,14 +660,19 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     const dim3 gridK9((unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK));
     // SH rows of 16 coefficients x 3 channels (the only layout the reference uses) go through LDS
     const bool sh_lds = c->shs != nullptr && pa.dsh != nullptr && c->K == 16;
-    if (c->raw) {
-      if (!pa.dsh || !pa.dsh_dc)
-        return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
-      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-      else hipLaunchKernelGGL((k_preprocess_bwd<true, true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-    } else if (sh_lds) {
-      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-      else hipLaunchKernelGGL((k_preprocess_bwd<true, false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+    (void)sh_lds;
+    if (c->raw && ((pa.dsh == nullptr) != (pa.dsh_dc == nullptr)))
+      return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
+    if (c->lanegroup && c->shs && geom && !c->D)
+      return done(set_err(GSR_ERR_STATE, "gsr_backward: the forward of this context was run without its backward state"));
+    if (c->lanegroup) {
+      if (c->raw) {
+        if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      } else {
+        if (geom) hipLaunchKernelGGL((k_pre_bwd<false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_bwd<false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      }
     } else {
       if (geom) hipLaunchKernelGGL((k_preprocess_bwd<false, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
       else hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);

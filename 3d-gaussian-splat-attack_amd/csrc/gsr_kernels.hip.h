@@ -999,6 +999,7 @@ struct PreBwdArgs {
   const float* cov3d;
   const float* sh;        // RAW: _features_rest
   const float* sh_dc;     // RAW: _features_dc
+  const float* D;         // [P,9] d rgb / d view direction left by k_pre_fwd (lane-group kernels only)
   float* dmeans3D;
   float* dmeans2D;
   float* dsh;             // RAW: gradient of _features_rest
@@ -1216,6 +1217,404 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
         const int row = e / 45;
         rest[e] = wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)];
       }
+    }
+  }
+}
+
+
+// ================================================================================================
+// K1 and K8+K9 in LANE-GROUP form (the SH layouts the reference uses: K = 16 coefficients, or the raw dc | rest pair).
+//
+// The per-Gaussian geometry is one thread per Gaussian, but everything that touches a 192-byte SH row is done by a
+// GROUP OF FOUR LANES per Gaussian: lane q of the group owns coefficients 4q .. 4q+3 (12 consecutive floats), so a wave
+// moves SH data with 16-byte loads / stores of consecutive addresses (16 Gaussians x 4 lanes per instruction) and the
+// rows never pass through LDS.  What an owner lane hands to its group is a 13-word slot, so a wave needs 3.3 KB of LDS
+// instead of 13 KB and the kernels are no longer limited to three waves per SIMD; K1 reads the SH rows of the
+// SURVIVORS only (compacted by a ballot), and leaves d(rgb)/d(view direction) (9 floats) behind so that the backward
+// gets the view-direction term of dL/dmean without reading the coefficients again.
+// ================================================================================================
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };   // 16-byte access at 4-byte alignment
+struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
+
+constexpr int SLOT_W = 13;     // words per hand-over slot (odd: 16 groups reading 16 slots hit 16 different banks)
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_mov<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  return v;
+}
+
+// the 12 floats of lane q: coefficients 4q .. 4q+3, three channels each
+template <bool RAW>
+__device__ __forceinline__ void load_sh12(const float* __restrict__ sh, const float* __restrict__ sh_dc, uint32_t g, int q,
+                                          float v[12]) {
+  if (RAW) {
+    const float* rest = sh + (size_t)g * 45 + 12 * q;                       // coefficients 4q+1 .. : 9 floats
+    const float* head = q == 0 ? sh_dc + (size_t)g * 3 : rest - 3;          // coefficient 4q
+    const F3u h = *reinterpret_cast<const F3u*>(head);
+    const F4u r0 = *reinterpret_cast<const F4u*>(rest);
+    const F4u r1 = *reinterpret_cast<const F4u*>(rest + 4);
+    const float r2 = rest[8];
+    v[0] = h.x; v[1] = h.y; v[2] = h.z;
+    v[3] = r0.x; v[4] = r0.y; v[5] = r0.z; v[6] = r0.w; v[7] = r1.x; v[8] = r1.y; v[9] = r1.z; v[10] = r1.w; v[11] = r2;
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(sh + (size_t)g * 48 + 12 * q);
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+    v[0] = r0.x; v[1] = r0.y; v[2] = r0.z; v[3] = r0.w; v[4] = r1.x; v[5] = r1.y; v[6] = r1.z; v[7] = r1.w;
+    v[8] = r2.x; v[9] = r2.y; v[10] = r2.z; v[11] = r2.w;
+  }
+}
+
+template <bool RAW>
+__device__ __forceinline__ void store_sh12(float* __restrict__ dsh, float* __restrict__ dsh_dc, uint32_t g, int q,
+                                           const float v[12]) {
+  if (RAW) {
+    float* rest = dsh + (size_t)g * 45 + 12 * q;
+    float* head = q == 0 ? dsh_dc + (size_t)g * 3 : rest - 3;
+    *reinterpret_cast<F3u*>(head) = F3u{v[0], v[1], v[2]};
+    *reinterpret_cast<F4u*>(rest) = F4u{v[3], v[4], v[5], v[6]};
+    *reinterpret_cast<F4u*>(rest + 4) = F4u{v[7], v[8], v[9], v[10]};
+    rest[8] = v[11];
+  } else {
+    float4* dst = reinterpret_cast<float4*>(dsh + (size_t)g * 48 + 12 * q);
+    dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+    dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    dst[2] = make_float4(v[8], v[9], v[10], v[11]);
+  }
+}
+
+__device__ __forceinline__ float pick4(int q, float a, float b, float c, float d) {
+  return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
+}
+
+struct PreArgs {
+  int P;
+  ViewArgs va;
+  const float* means;
+  const float* scales;
+  const float* rots;
+  const float* cov3d;
+  const float* opac;
+  const float* sh;        // [P,16,3], or RAW: _features_rest [P,15,3]
+  const float* sh_dc;     // RAW: _features_dc [P,1,3]
+  const float* colors;    // precomputed colours [P,3] (then no SH)
+  int32_t* radii;
+  float4* G0;
+  float4* G1;
+  float4* G2;
+  float* D;               // [P,9] d rgb_c / d dir_axis (before the clamp), or null: not wanted (no backward follows)
+  uint32_t* dkey;
+  uint32_t* tcnt;
+};
+
+template <bool RAW>
+__global__ void __launch_bounds__(PRE_BLOCK) k_pre_fwd(PreArgs a) {
+  __shared__ float slots[PRE_WAVES * 64 * SLOT_W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ws = &slots[wave * 64 * SLOT_W];
+  const int g = blockIdx.x * PRE_BLOCK + wave * 64 + lane;
+  View v;
+  load_view(v, a.va);
+  // ---- phase A: one thread per Gaussian -- projection, culls, per-Gaussian scalars ---------------------------------
+  bool ok = false;
+  Splat s;
+  float aux0 = 0.f, aux1 = 0.f, aux2 = 0.f, op = 0.f;
+  if (g < a.P) {
+    const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+    float c6[6];
+    if (a.cov3d) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
+    } else {
+      float sc[3] = {a.scales[3 * g], a.scales[3 * g + 1], a.scales[3 * g + 2]};
+      const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+      float q[4] = {q4.x, q4.y, q4.z, q4.w};
+      if (RAW) {
+        sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+        float inv_n;
+        act_normalize4(q, q, inv_n);
+      }
+      cov3d_from_scale_rot(sc, a.va.mod, q, c6);
+    }
+    ok = project_splat(v, p, c6, s);
+    if (ok) {
+      op = RAW ? act_sigmoid(a.opac[g]) : a.opac[g];
+      if (a.colors) {
+        aux0 = a.colors[3 * g]; aux1 = a.colors[3 * g + 1]; aux2 = a.colors[3 * g + 2];
+      } else {
+        const float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        aux0 = dx * inv; aux1 = dy * inv; aux2 = dz * inv;
+      }
+    }
+    a.radii[g] = ok ? s.radius : 0;
+    a.dkey[g] = ok ? __float_as_uint(s.depth) : 0xFFFFFFFFu;
+    a.tcnt[g] = ok ? (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy)) : 0u;
+  }
+  const uint64_t live = __ballot(ok);
+  const int nlive = __popcll(live);
+  if (ok) {
+    float* sl = ws + SLOT_W * __popcll(live & ((1ull << lane) - 1ull));
+    sl[0] = s.px; sl[1] = s.py; sl[2] = s.A; sl[3] = s.B; sl[4] = s.C; sl[5] = op; sl[6] = s.depth;
+    sl[7] = __uint_as_float((uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12));
+    sl[8] = __uint_as_float((uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12));
+    sl[9] = aux0; sl[10] = aux1; sl[11] = aux2;
+    sl[12] = __uint_as_float((uint32_t)g);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- phase B: four lanes per SURVIVOR -- SH -> colour, d colour / d direction, the 48-byte record ----------------
+  const int q = lane & 3, grp = lane >> 2;
+  const int deg = a.va.deg;
+  for (int r0 = 0; r0 < nlive; r0 += 16) {
+    const int si = r0 + grp;
+    if (si < nlive) {
+      const float* sl = ws + SLOT_W * si;
+      const uint32_t gg = __float_as_uint(sl[12]);
+      float rgb0, rgb1, rgb2;
+      uint32_t cl = 0;
+      if (a.colors) {
+        rgb0 = sl[9]; rgb1 = sl[10]; rgb2 = sl[11];
+      } else {
+        const float x = sl[9], y = sl[10], z = sl[11];
+        float sv[12];
+        load_sh12<RAW>(a.sh, a.sh_dc, gg, q, sv);
+        float b[16], gx[16], gy[16], gz[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) b[k] = 0.f;
+        sh_basis(deg, x, y, z, b);
+        float bs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[j] = pick4(q, b[j], b[4 + j], b[8 + j], b[12 + j]);
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c0 = fmaf(bs[j], sv[3 * j], c0); c1 = fmaf(bs[j], sv[3 * j + 1], c1); c2 = fmaf(bs[j], sv[3 * j + 2], c2); }
+        c0 = quad_sum(c0) + 0.5f; c1 = quad_sum(c1) + 0.5f; c2 = quad_sum(c2) + 0.5f;
+        cl = (c0 < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u);
+        rgb0 = fmaxf(c0, 0.f); rgb1 = fmaxf(c1, 0.f); rgb2 = fmaxf(c2, 0.f);
+        if (a.D) {
+          sh_basis_grad(deg, x, y, z, gx, gy, gz);
+          float d[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // d[3c + axis]
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float ex = pick4(q, gx[j], gx[4 + j], gx[8 + j], gx[12 + j]);
+            const float ey = pick4(q, gy[j], gy[4 + j], gy[8 + j], gy[12 + j]);
+            const float ez = pick4(q, gz[j], gz[4 + j], gz[8 + j], gz[12 + j]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              d[3 * c] = fmaf(ex, sv[3 * j + c], d[3 * c]);
+              d[3 * c + 1] = fmaf(ey, sv[3 * j + c], d[3 * c + 1]);
+              d[3 * c + 2] = fmaf(ez, sv[3 * j + c], d[3 * c + 2]);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 9; ++i) d[i] = quad_sum(d[i]);
+          if (q < 3) {
+            const float dx_ = pick4(q, d[0], d[3], d[6], 0.f), dy_ = pick4(q, d[1], d[4], d[7], 0.f),
+                        dz_ = pick4(q, d[2], d[5], d[8], 0.f);
+            *reinterpret_cast<F3u*>(a.D + (size_t)gg * 9 + 3 * q) = F3u{dx_, dy_, dz_};
+          }
+        }
+      }
+      // lanes 0..2 of the group store one float4 of the record each: 48 contiguous bytes per Gaussian
+      const uint32_t rx = __float_as_uint(sl[7]) | (cl << 24);
+      if (q == 0) a.G0[REC * gg] = make_float4(sl[0], sl[1], sl[2], sl[3]);
+      else if (q == 1) a.G1[REC * gg] = make_float4(sl[4], sl[5], rgb0, rgb1);
+      else if (q == 2) a.G2[REC * gg] = make_float4(rgb2, sl[6], __uint_as_float(rx), sl[8]);
+    }
+  }
+}
+
+
+// K8+K9, lane-group form: per-Gaussian reduction of the partial rows and the projection chain rule by one thread per
+// Gaussian (rows staged through LDS in coalesced chunks, as before); dL/dSH written by four lanes per Gaussian straight
+// from (basis(dir), dL/drgb) -- 16-byte stores of consecutive addresses, zeros for culled Gaussians included -- and the
+// view-direction term of dL/dmean from the nine d rgb / d dir values K1 left behind: the SH coefficients are not read.
+constexpr int ROW_CHUNK = 128;     // partial rows staged per round (6 KB per wave)
+constexpr int HAND_W = 7;          // hand-over: unit direction (3) + clamped dL/drgb (3), odd stride
+
+template <bool RAW, bool GEOM>
+__global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
+  __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
+  __shared__ float shand[PRE_WAVES * 64 * HAND_W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw0 = blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
+  const int g = gw0 + lane;
+  float4* wrow = &srow[wave * ROW_CHUNK * PART_F4];
+  float* hand = &shand[wave * 64 * HAND_W];
+  const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
+  if (nw <= 0) return;
+  uint32_t o0 = 0, o1 = 0;
+  if (g < a.P) { o0 = a.offg[g] * a.nsub; o1 = a.offg[g + 1] * a.nsub; }
+  // ---- sum this Gaussian's partial rows (the wave's rows are one contiguous span) ------------------------------------
+  float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+  {
+    const uint32_t S = a.offg[gw0] * a.nsub, E = a.offg[gw0 + nw] * a.nsub;
+    const bool big = (o1 - o0) > (uint32_t)ROW_CHUNK;
+    for (uint32_t c0 = S; c0 < E; c0 += (uint32_t)ROW_CHUNK) {
+      const uint32_t rows = min((uint32_t)ROW_CHUNK, E - c0);
+      const float4* src = a.part + (size_t)c0 * PART_F4;
+      for (uint32_t i = lane; i < rows * PART_F4; i += 64) wrow[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (!big) {
+        const uint32_t lo = max(o0, c0), hi = min(o1, c0 + rows);
+        for (uint32_t e = lo; e < hi; ++e) {
+          const float4* r = &wrow[(e - c0) * PART_F4];
+          const float4 p0 = r[0], p1 = r[1], p2 = r[2];
+          if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
+          if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
+          dr += p1.z; dg += p1.w; db += p2.x;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint64_t bm = __ballot(big);
+    while (bm) {                                         // a Gaussian with more rows than a chunk: the whole wave sums it
+      const int L = __ffsll((unsigned long long)bm) - 1;
+      bm &= bm - 1;
+      const uint32_t b0 = __shfl(o0, L, 64), b1 = __shfl(o1, L, 64);
+      float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (uint32_t e = b0 + lane; e < b1; e += 64) {
+        const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+        if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
+        if (GEOM) { t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w; t[4] += p1.x; t[5] += p1.y; }
+        t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) t[i] = __shfl(wave_sum_to_hi(t[i]), 63, 64);
+      if (lane == L) { mx = t[0]; my = t[1]; mxx = t[2]; mxy = t[3]; myy = t[4]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
+    }
+  }
+  // ---- phase A: chain rule per Gaussian ------------------------------------------------------------------------------
+  float hdir[3] = {0.f, 0.f, 0.f}, hrgb[3] = {0.f, 0.f, 0.f};
+  if (g < a.P) {
+    if (o1 == o0) {   // culled: zero gradients (dL/dSH: phase B writes the zeros)
+      if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
+      if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
+      if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
+      if (a.dcolors) { a.dcolors[3 * g] = 0.f; a.dcolors[3 * g + 1] = 0.f; a.dcolors[3 * g + 2] = 0.f; }
+      if (a.dopac) a.dopac[g] = 0.f;
+      if (a.dscales) { a.dscales[3 * g] = 0.f; a.dscales[3 * g + 1] = 0.f; a.dscales[3 * g + 2] = 0.f; }
+      if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
+      if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
+    } else {
+      if (a.dsh_objs) {
+        float acc[NUM_OBJ];
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
+        if (a.part_obj) {
+          for (uint32_t e = o0; e < o1; ++e) {
+            const float4 tg = a.part[(size_t)e * PART_F4 + 2];
+            if (__float_as_uint(tg.y) != a.tag_lo || __float_as_uint(tg.z) != a.tag_hi) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 v4 = a.part_obj[(size_t)e * 4 + q];
+              acc[4 * q] += v4.x; acc[4 * q + 1] += v4.y; acc[4 * q + 2] += v4.z; acc[4 * q + 3] += v4.w;
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
+      }
+      View v;
+      load_view(v, a.va);
+      const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
+      const float A = e0.z, B = e0.w, C = e1.x;
+      // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
+      const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
+      const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
+      const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
+      if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
+      if (GEOM && a.dopac) a.dopac[g] = RAW ? dop * e1.y * (1.f - e1.y) : dop;   // e1.y = sigmoid(raw opacity)
+      const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+      float dp[3] = {0.f, 0.f, 0.f};
+      if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
+      if (a.sh) {
+        const uint32_t cl = __float_as_uint(e2.z) >> 24;
+        hrgb[0] = (cl & 1u) ? 0.f : dr; hrgb[1] = (cl & 2u) ? 0.f : dg; hrgb[2] = (cl & 4u) ? 0.f : db;
+        const float vx = p[0] - v.cam[0], vy = p[1] - v.cam[1], vz = p[2] - v.cam[2];
+        const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+        hdir[0] = vx * inv; hdir[1] = vy * inv; hdir[2] = vz * inv;
+        if (GEOM) {
+          // view-direction path of dL/dmean: dL/dd = D^T dL/drgb, then d = v/|v|: dL/dv = (dL/dd - d (d . dL/dd)) / |v|
+          const float* Dg = a.D + (size_t)g * 9;
+          const float ddx = Dg[0] * hrgb[0] + Dg[3] * hrgb[1] + Dg[6] * hrgb[2];
+          const float ddy = Dg[1] * hrgb[0] + Dg[4] * hrgb[1] + Dg[7] * hrgb[2];
+          const float ddz = Dg[2] * hrgb[0] + Dg[5] * hrgb[1] + Dg[8] * hrgb[2];
+          const float dot = hdir[0] * ddx + hdir[1] * ddy + hdir[2] * ddz;
+          dp[0] += (ddx - hdir[0] * dot) * inv;
+          dp[1] += (ddy - hdir[1] * dot) * inv;
+          dp[2] += (ddz - hdir[2] * dot) * inv;
+        }
+      }
+      if (GEOM) {
+        float c6[6];
+        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+        float inv_qn = 1.f;
+        if (a.cov3d) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
+        } else {
+          sc[0] = a.scales[3 * g]; sc[1] = a.scales[3 * g + 1]; sc[2] = a.scales[3 * g + 2];
+          const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+          q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+          if (RAW) {
+            sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
+            act_normalize4(q, q, inv_qn);
+          }
+          cov3d_from_scale_rot(sc, a.va.mod, q, c6);
+        }
+        float dc6[6];
+        project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+        if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
+        if (a.cov3d) {
+          if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
+        } else if (a.dscales || a.drots) {
+          float ds[3], dq[4];
+          cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
+          if (RAW) {
+            ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2];     // d exp(x) = exp(x)
+            act_normalize4_bwd(q, inv_qn, dq, dq);
+          }
+          if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
+          if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+        }
+      }
+    }
+  }
+  if (a.dsh == nullptr) return;
+  // ---- phase B: four lanes per Gaussian write dL/dSH = basis(dir) x dL/drgb, 48 floats per Gaussian, coalesced -------
+  {
+    float* h = hand + HAND_W * lane;
+    h[0] = hdir[0]; h[1] = hdir[1]; h[2] = hdir[2]; h[3] = hrgb[0]; h[4] = hrgb[1]; h[5] = hrgb[2];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int q = lane & 3, grp = lane >> 2;
+  const int deg = a.va.deg;
+#pragma unroll 1
+  for (int r0 = 0; r0 < nw; r0 += 16) {
+    const int si = r0 + grp;
+    if (si < nw) {
+      const float* h = hand + HAND_W * si;
+      const float x = h[0], y = h[1], z = h[2], g0 = h[3], g1 = h[4], g2 = h[5];
+      float b[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) b[k] = 0.f;
+      sh_basis(deg, x, y, z, b);
+      float out[12];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bj = pick4(q, b[j], b[4 + j], b[8 + j], b[12 + j]);
+        out[3 * j] = bj * g0; out[3 * j + 1] = bj * g1; out[3 * j + 2] = bj * g2;
+      }
+      store_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, out);
     }
   }
 }

@@ -291,12 +291,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
+        # no input wants a gradient (torch.no_grad(), or plain tensors): a forward-only call -- the library then keeps
+        # no backward state (segment boundaries, d colour / d direction)
+        keep = any(ctx.needs_input_grad)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             rc = lib.gsr_forward(ctypes.byref(pack.c), P, K, _ptr(m3), _ptr(shc), _ptr(shoc), _ptr(colc), _ptr(opc),
                                  _ptr(scc), _ptr(roc), _ptr(covc), _ptr(color), _ptr(objects) if shoc is not None else None,
                                  _ptr(radii),
-                                 ctypes.byref(handle), ctypes.byref(nren), stream)
+                                 ctypes.byref(handle) if keep else None, ctypes.byref(nren), stream)
         if rc != 0:
             msg = _err(lib)
             if raster_settings.debug:
@@ -307,7 +310,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if rc == 1:
                 raise Exception(msg)
             raise RuntimeError(msg)
-        ctx.holder = _CtxHolder(lib, handle)
+        ctx.holder = _CtxHolder(lib, handle) if keep else None
         ctx.pack = pack
         ctx.num_rendered = nren.value
         ctx.shapes = (means3D.shape, means2D.shape if means2D is not None else None,
@@ -399,11 +402,12 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
+        keep = any(ctx.needs_input_grad)           # forward-only call: no backward state is kept (see above)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
                                      _ptr(ro), _ptr(color), _ptr(objects) if obj is not None else None, _ptr(radii),
-                                     ctypes.byref(handle),
+                                     ctypes.byref(handle) if keep else None,
                                      ctypes.byref(nren), stream)
         if rc != 0:
             msg = _err(lib)
@@ -412,7 +416,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                             "scaling": sc, "rotation": ro, "settings": raster_settings._asdict()}, "snapshot_fw.dump")
                 msg += " (raw parameters saved to snapshot_fw.dump)"
             raise Exception(msg) if rc == 1 else RuntimeError(msg)
-        ctx.holder = _CtxHolder(lib, handle)
+        ctx.holder = _CtxHolder(lib, handle) if keep else None
         ctx.pack = pack
         ctx.num_rendered = nren.value
         ctx.shapes = (xyz.shape, means2D.shape, features_dc.shape, features_rest.shape,

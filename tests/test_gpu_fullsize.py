@@ -69,6 +69,12 @@ def test_nyc_background_enters_through_final_transmittance(nyc):
     assert torch.allclose(b - a, Tf[None] * bgv[:, None, None], atol=2e-6)
 
 
+def model_radii(model, cam, dev):
+    from gsplat_attack.renderer import PipelineParams, render
+    with torch.no_grad():
+        return render(cam, model, PipelineParams(skip_objects=True), torch.zeros(3, device=dev))["radii"]
+
+
 def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
     D, dev, model, cam, gc = nyc
     from gsplat_attack.renderer import PipelineParams, render
@@ -94,7 +100,7 @@ def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
     order = D.export_state(img, "order").long()
     recs = D.export_state(img, "G").view(-1, 12)
     depth_by_rank = recs[order, 9]
-    vis = recs[order, 10].view(torch.int32) != 0
+    vis = (model_radii(model, cam, dev) > 0)[order]          # records of culled Gaussians are not written
     d = depth_by_rank[vis]
     assert bool((d[1:] >= d[:-1]).all())
 
@@ -102,16 +108,33 @@ def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
 def test_nyc_cull_and_fused_paths_agree_at_full_size(nyc):
     D, dev, model, cam, gc = nyc
     bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
-    out0, g0 = _fwd_bwd(model, cam, bg, gc, fused=True)
-    img0 = out0["render"].detach().clone()
+    # Unsplit lists: dropping the pairs the footprint test rejects changes NOTHING, bit for bit.
     try:
-        D.set_flags(D.FLAG_NO_CULL)
+        D.set_flags(D.FLAG_NO_SEGMENTS)
+        out0, g0 = _fwd_bwd(model, cam, bg, gc, fused=True)
+        img0 = out0["render"].detach().clone()
+        D.set_flags(D.FLAG_NO_SEGMENTS | D.FLAG_NO_CULL)
         out1, g1 = _fwd_bwd(model, cam, bg, gc, fused=True)
     finally:
         D.set_flags(0)
     assert torch.equal(img0, out1["render"])
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+    # Default (long lists walked as segments by the backward): the forward is the same bits; the backward starts each
+    # segment from the forward's stored (T, C) instead of dividing T back through the whole list -- same numbers
+    # within float32 rounding, and the segment boundaries move with the culled pairs.
+    outs, gs = _fwd_bwd(model, cam, bg, gc, fused=True)
+    assert torch.equal(img0, outs["render"])
+    try:
+        D.set_flags(D.FLAG_NO_CULL)
+        outn, gn = _fwd_bwd(model, cam, bg, gc, fused=True)
+    finally:
+        D.set_flags(0)
+    assert torch.equal(img0, outn["render"])
+    for k in g0:
+        scale = g0[k].abs().max().clamp_min(1e-30)
+        assert ((gs[k] - g0[k]).abs().max() / scale).item() <= 2e-5, k
+        assert ((gn[k] - g0[k]).abs().max() / scale).item() <= 2e-5, k
     # Fused vs PyTorch activations differ by an ulp in scale / rotation / opacity, which flips a threshold test
     # (alpha >= 1/255, T < 1e-4) on a handful of the 2M pixels: all but 1e-4 of the pixels must agree to 2e-6, the
     # rest are bounded by one skipped/added contribution.
@@ -120,7 +143,7 @@ def test_nyc_cull_and_fused_paths_agree_at_full_size(nyc):
     assert (diff > 2e-6).float().mean().item() <= 1e-4
     assert diff.max().item() <= 1e-2
     for k in g0:
-        rel = ((g0[k] - g2[k]).abs().max() / g0[k].abs().max().clamp_min(1e-30)).item()
+        rel = ((gs[k] - g2[k]).abs().max() / gs[k].abs().max().clamp_min(1e-30)).item()
         assert rel <= 2e-3, (k, rel)
 
 

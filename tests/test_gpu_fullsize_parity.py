@@ -55,14 +55,20 @@ def window_mask(wins, H, W):
     return m
 
 
-def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None):
-    """oracle-R float64 on the CPU twin of the scene, autograd down to the RAW parameters through the getters."""
+def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, keys=None):
+    """oracle-R float64 on the CPU twin of the scene, autograd down to the RAW parameters through the getters.
+    keys = (depth keys, radii) exported from the HIP forward: the oracle composites in the order of those float32 keys
+    once they are within a few ulps of its own float64 depth (oracle_r.check_depth_keys)."""
     from gsplat_attack.scenes import make_scene
     ref, rcams, _ = make_scene(key, device="cpu", n_views=cam_i + 1, **(scale_kw or {}))
     st = settings_for(rcams[cam_i], bg)
+    depth_key = None
+    if keys is not None:
+        depth_key = keys[0]
+        O.check_depth_keys(depth_key, ref.get_xyz, st, keys[1])
     ro = O.rasterize(ref.get_xyz, None, ref.get_opacity, st, shs=ref.get_features,
                      sh_objs=ref.get_objects if objects else None, scales=ref.get_scaling, rotations=ref.get_rotation,
-                     tile_windows=wins)
+                     tile_windows=wins, depth_key=depth_key)
     # the loss ignores the pixels oracle-R flags as fragile (a float32 threshold test may flip there)
     gc, go = O.solid_grads(ro, gc, go)
     loss = (ro.color * gc.double()).sum()
@@ -101,7 +107,7 @@ def hip_raw(model, cam, bg, gc, flags=0, fused=True, objects=False, go=None, col
     return out, grads
 
 
-def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=1e-2, objects=False):
+def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=5e-2, objects=False):
     color = out["render"].detach().cpu().double()
     err = (color - ro.color.detach()).abs().max(dim=0).values
     solid = m & ~ro.fragile_px
@@ -137,10 +143,14 @@ def _windows_for(D, model, cam, bg):
     from gsplat_attack.renderer import PipelineParams, render
     H, W = cam.image_height, cam.image_width
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    img = render(cam, model, PipelineParams(skip_objects=True), bg)["render"]
+    out = render(cam, model, PipelineParams(skip_objects=True), bg)
+    img = out["render"]
     ranges = D.export_state(img, "ranges").view(-1, 2).long()
     wins, longest = pick_windows(ranges, gx, gy)
-    return wins, longest, gx, gy
+    radii = out["radii"].cpu()
+    depth = D.export_state(img, "G").view(-1, 12)[:, 9].cpu()
+    depth = torch.where(radii > 0, depth, torch.zeros_like(depth))       # records of culled Gaussians are not written
+    return wins, longest, gx, gy, (depth, radii)
 
 
 def test_cfg3_nyc_1m_1080p_all_gradients_vs_windowed_oracle():
@@ -150,11 +160,11 @@ def test_cfg3_nyc_1m_1080p_all_gradients_vs_windowed_oracle():
     dev, model, cams = _scene_on_gpu("nyc-1M", 3)
     cam = cams[2]
     bg = torch.tensor([0.1, 0.2, 0.3])
-    wins, longest, gx, gy = _windows_for(D, model, cam, bg.to(dev))
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
     assert gx * gy >= 4096 and longest > 256, (gx * gy, longest)
     m = window_mask(wins, 1080, 1920)
     gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(99)) * m
-    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 2, bg, gc, wins)
+    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 2, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev))
     rep = compare(out, grads, ro, rgrads, m)
     print("cfg3 windows", wins, "longest list", longest, rep)
@@ -171,10 +181,10 @@ def test_cfg3_classic_activated_surface_vs_windowed_oracle():
     dev, model, cams = _scene_on_gpu("nyc-1M", 1)
     cam = cams[0]
     bg = torch.zeros(3)
-    wins, longest, gx, gy = _windows_for(D, model, cam, bg.to(dev))
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
     m = window_mask(wins, 1080, 1920)
     gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(7)) * m
-    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 0, bg, gc, wins)
+    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 0, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), fused=False)
     compare(out, grads, ro, rgrads, m)
 
@@ -186,11 +196,11 @@ def test_cfg2_hydrant_full_800px_sh_gradients_vs_windowed_oracle():
     dev, model, cams = _scene_on_gpu("hydrant-full", 1)
     cam = cams[0]
     bg = torch.tensor([0.0, 0.0, 0.0])
-    wins, longest, gx, gy = _windows_for(D, model, cam, bg.to(dev))
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
     assert gx * gy < 4096
     m = window_mask(wins, 800, 800)
     gc = torch.randn(3, 800, 800, generator=torch.Generator().manual_seed(2)) * m
-    ro, rgrads, gc, _ = oracle_raw("hydrant-full", 0, bg, gc, wins)
+    ro, rgrads, gc, _ = oracle_raw("hydrant-full", 0, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), color_only=True)
     assert set(grads) == {"f_dc", "f_rest"}
     compare(out, grads, ro, rgrads, m, names=("f_dc", "f_rest"))
@@ -205,12 +215,12 @@ def test_cfg5_airport_4k_full_backward_vs_windowed_oracle():
     dev, model, cams = _scene_on_gpu("airport-4K", 1)
     cam = cams[0]
     bg = torch.tensor([0.2, 0.1, 0.0])
-    wins, longest, gx, gy = _windows_for(D, model, cam, bg.to(dev))
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
     m = window_mask(wins, 2160, 3840)
     g = torch.Generator().manual_seed(5)
     gc = torch.randn(3, 2160, 3840, generator=g) * m
     go = torch.randn(16, 2160, 3840, generator=g) * 0.2 * m
-    ro, rgrads, gc, go = oracle_raw("airport-4K", 0, bg, gc, wins, objects=True, go=go)
+    ro, rgrads, gc, go = oracle_raw("airport-4K", 0, bg, gc, wins, keys=keys, objects=True, go=go)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), objects=True, go=go.to(dev))
     rep = compare(out, grads, ro, rgrads, m, names=RAW + ("objects_dc",), objects=True)
     print("cfg5 windows", wins, "longest list", longest, rep)
@@ -229,10 +239,10 @@ def test_cfg3_pgd20_colour_attack_at_full_size():
     dev, model, cams = _scene_on_gpu("nyc-1M", 1)
     cam = cams[0]
     bg = torch.zeros(3)
-    wins, longest, gx, gy = _windows_for(D, model, cam, bg.to(dev))
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
     m = window_mask(wins, 1080, 1920)
     gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(11)) * m
-    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 0, bg, gc, wins)
+    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 0, bg, gc, wins, keys=keys)
     gcd = gc.to(dev)
     orig = {n: getattr(model, n).detach().clone() for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc",
                                                            "_features_rest")}
@@ -274,7 +284,9 @@ def test_every_tile_split_and_tile_map_against_the_oracle(fwd, bwd):
     inp = model_inputs(model, with_objs=False)
     bg = torch.tensor([0.3, 0.2, 0.1])
     gc = torch.randn(3, 180, 320, generator=torch.Generator().manual_seed(1))
-    ref, rg = O.forward_backward(inp, settings_for(cam, bg), gc, drop_fragile=True)
+    from test_gpu_parity import hip_depth_keys
+    ref, rg = O.forward_backward(inp, settings_for(cam, bg), gc, drop_fragile=True,
+                                 depth_key=hip_depth_keys(inp, cam, bg))
     gc, _ = O.solid_grads(ref, gc)
     base = None
     for mode in (0, 1, 2, 3):

@@ -53,6 +53,27 @@ def run_hip(inp, cam, bg, grad_color, grad_objects=None, sh_degree=3, scale_modi
     return color.detach().cpu(), radii.cpu(), objects.detach().cpu(), grads
 
 
+def hip_depth_keys(inp, cam, bg, sh_degree=3, scale_modifier=1.0):
+    """The float32 view depths the HIP path sorts on (exported from a forward), for oracle_r.rasterize(depth_key=...):
+    near-ties in depth may legitimately sort either way in float32; the oracle composites in the order these keys
+    define, after check_depth_keys has held them to a few ulps of the float64 depth."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    t = {k: (None if v is None else v.detach().to(dev).float()) for k, v in inp.items()}
+    P = t["means3D"].shape[0]
+    st = settings_for(cam, bg, sh_degree, scale_modifier, cls=D.GaussianRasterizationSettings, device=dev)
+    color, radii, _ = D.GaussianRasterizer(raster_settings=st)(
+        means3D=t["means3D"].requires_grad_(True), means2D=torch.zeros(P, 3, device=dev), opacities=t["opacities"],
+        shs=t.get("shs"), sh_objs=t.get("sh_objs"), colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
+        rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
+    if P == 0:
+        return torch.zeros(0)
+    keys = D.export_state(color, "G").view(-1, 12)[:, 9].cpu()
+    keys = torch.where(radii.cpu() > 0, keys, torch.zeros_like(keys))
+    O.check_depth_keys(keys, inp["means3D"], settings_for(cam, bg, sh_degree, scale_modifier), radii.cpu())
+    return keys
+
+
 def check(inp, cam, bg, sh_degree=3, scale_modifier=1.0, with_gobj=False, seed=99, frag_frac=5e-3, elem_frac=1e-3):
     H, W = cam.image_height, cam.image_width
     g = torch.Generator().manual_seed(seed)
@@ -61,7 +82,8 @@ def check(inp, cam, bg, sh_degree=3, scale_modifier=1.0, with_gobj=False, seed=9
     st = settings_for(cam, bg, sh_degree, scale_modifier)
     # dL/dC is zeroed on the pixels oracle-R flags as fragile (a float32 threshold test may flip there): both sides
     # differentiate the same loss over the solid pixels
-    ref, rg = O.forward_backward(inp, st, gc, go, dtype=torch.float64, drop_fragile=True)
+    keys = hip_depth_keys(inp, cam, bg, sh_degree, scale_modifier)
+    ref, rg = O.forward_backward(inp, st, gc, go, dtype=torch.float64, drop_fragile=True, depth_key=keys)
     gc, go = O.solid_grads(ref, gc, go)
     color, radii, objects, grads = run_hip(inp, cam, bg, gc, go, sh_degree, scale_modifier)
 
