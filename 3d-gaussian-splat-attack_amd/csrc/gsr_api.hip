@@ -294,11 +294,18 @@ void gsr_ctx_free(GsrCtx* c) {
 static std::atomic<unsigned long long*> g_wave_clock{nullptr};
 static std::atomic<unsigned long long*> g_wave_clock_fwd{nullptr};
 
+// second attribute segment of gsr_forward_raw2 (raw parameters of Pb more Gaussians, numbered after the first P - Pb)
+struct SegB {
+  int32_t Pb = 0;
+  const float *xyz = nullptr, *features_dc = nullptr, *features_rest = nullptr, *objects_dc = nullptr,
+              *opacity = nullptr, *scaling = nullptr, *rotation = nullptr;
+};
+
 static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
                         const float* sh_dc, const float* sh_objs, const float* colors_precomp, const float* opacities,
                         const float* scales, const float* rotations, const float* cov3D_precomp, float* out_color,
                         float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream,
-                        bool raw) {
+                        bool raw, const SegB* segb = nullptr) {
   if (ctx_out) *ctx_out = nullptr;
   if (!s || !out_color) return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / out_color");
   if (P < 0 || s->image_height <= 0 || s->image_width <= 0)
@@ -409,6 +416,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
         pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
         pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkeyA; pa.tcnt = tcnt;
+        pa.Pa = segb ? P - segb->Pb : P;
+        pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
+        pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
+        pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
         if (raw) hipLaunchKernelGGL((k_pre_fwd<true>), gridPre, blkPre, 0, st, pa);
         else hipLaunchKernelGGL((k_pre_fwd<false>), gridPre, blkPre, 0, st, pa);
       } else
@@ -496,6 +507,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     RenderArgs ra;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
+    ra.sh_objs_b = segb ? segb->objects_dc : nullptr; ra.Pa = segb ? P - segb->Pb : P;
     const int map_mode_f = flag_tile_map(s->flags);
     ra.map_mode = map_mode_f;
     ra.sched = c->sched;
@@ -556,6 +568,32 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
                 int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream) {
   return forward_impl(s, P, K, means3D, shs, nullptr, sh_objs, colors_precomp, opacities, scales, rotations,
                       cov3D_precomp, out_color, out_objects, radii, ctx_out, num_rendered, stream, false);
+}
+
+int gsr_forward_raw2(const GsrSettings* s, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                     const float* features_rest_a, const float* objects_dc_a, const float* opacity_logit_a,
+                     const float* log_scaling_a, const float* rotation_raw_a, int32_t Pb, const float* xyz_b,
+                     const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
+                     const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
+                     float* out_color, float* out_objects, int32_t* radii, int64_t* num_rendered, void* stream) {
+  if (Pa < 0 || Pb < 0 || (long long)Pa + Pb > 0x7FFFFFFFll) return set_err(GSR_ERR_INVALID, "gsr_forward_raw2: bad sizes Pa=%d Pb=%d", Pa, Pb);
+  if (Pb == 0)
+    return forward_impl(s, Pa, 16, xyz_a, features_rest_a, features_dc_a, objects_dc_a, nullptr, opacity_logit_a,
+                        log_scaling_a, rotation_raw_a, nullptr, out_color, out_objects, radii, nullptr, num_rendered, stream, true);
+  if (Pa == 0)
+    return forward_impl(s, Pb, 16, xyz_b, features_rest_b, features_dc_b, objects_dc_b, nullptr, opacity_logit_b,
+                        log_scaling_b, rotation_raw_b, nullptr, out_color, out_objects, radii, nullptr, num_rendered, stream, true);
+  if (!xyz_a || !features_dc_a || !features_rest_a || !opacity_logit_a || !log_scaling_a || !rotation_raw_a || !xyz_b ||
+      !features_dc_b || !features_rest_b || !opacity_logit_b || !log_scaling_b || !rotation_raw_b)
+    return set_err(GSR_ERR_INVALID, "gsr_forward_raw2: null parameter tensor");
+  if (out_objects && ((objects_dc_a == nullptr) != (objects_dc_b == nullptr)))
+    return set_err(GSR_ERR_INVALID, "gsr_forward_raw2: object features must be given for both segments or for neither");
+  SegB b;
+  b.Pb = Pb; b.xyz = xyz_b; b.features_dc = features_dc_b; b.features_rest = features_rest_b; b.objects_dc = objects_dc_b;
+  b.opacity = opacity_logit_b; b.scaling = log_scaling_b; b.rotation = rotation_raw_b;
+  return forward_impl(s, Pa + Pb, 16, xyz_a, features_rest_a, features_dc_a, objects_dc_a, nullptr, opacity_logit_a,
+                      log_scaling_a, rotation_raw_a, nullptr, out_color, out_objects, radii, nullptr, num_rendered, stream,
+                      true, &b);
 }
 
 int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const float* features_dc,

@@ -309,6 +309,8 @@ struct RenderArgs {
   const float4* R1;
   const float4* R2;
   const float* sh_objs;   // [P,16] or null
+  const float* sh_objs_b; // second segment's object features (Gaussians g >= Pa), see PreArgs
+  int Pa;
   const float* bg;
   int W, H, gridx, ntiles, map_mode;
   const uint32_t* sched;      // map mode 3: tiles longest-list-first + priority class (k_tile_schedule)
@@ -537,7 +539,9 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       if (OBJ) {
-        const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
+        const uint32_t og = __float_as_uint(c.y);
+        const float4* src = reinterpret_cast<const float4*>(og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ
+                                                                                  : a.sh_objs + (size_t)og * NUM_OBJ);
         float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
@@ -1298,6 +1302,15 @@ struct PreArgs {
   const float* sh;        // [P,16,3], or RAW: _features_rest [P,15,3]
   const float* sh_dc;     // RAW: _features_dc [P,1,3]
   const float* colors;    // precomputed colours [P,3] (then no SH)
+  // second attribute segment (gsr_forward_raw2: attacked target + frozen background rendered as ONE scene without
+  // concatenating their tensors): Gaussians g >= Pa read element g - Pa of these
+  int Pa;                 // == P when there is one segment
+  const float* means_b;
+  const float* scales_b;
+  const float* rots_b;
+  const float* opac_b;
+  const float* sh_b;
+  const float* sh_dc_b;
   int32_t* radii;
   float4* G0;
   float4* G1;
@@ -1320,14 +1333,18 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_fwd(PreArgs a) {
   Splat s;
   float aux0 = 0.f, aux1 = 0.f, aux2 = 0.f, op = 0.f;
   if (g < a.P) {
-    const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+    const bool second = g >= a.Pa;                       // which attribute segment this Gaussian lives in
+    const int gl = second ? g - a.Pa : g;
+    const float* means = second ? a.means_b : a.means;
+    const float p[3] = {means[3 * gl], means[3 * gl + 1], means[3 * gl + 2]};
     float c6[6];
     if (a.cov3d) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
     } else {
-      float sc[3] = {a.scales[3 * g], a.scales[3 * g + 1], a.scales[3 * g + 2]};
-      const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+      const float* scales = second ? a.scales_b : a.scales;
+      float sc[3] = {scales[3 * gl], scales[3 * gl + 1], scales[3 * gl + 2]};
+      const float4 q4 = reinterpret_cast<const float4*>(second ? a.rots_b : a.rots)[gl];
       float q[4] = {q4.x, q4.y, q4.z, q4.w};
       if (RAW) {
         sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
@@ -1338,7 +1355,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_fwd(PreArgs a) {
     }
     ok = project_splat(v, p, c6, s);
     if (ok) {
-      op = RAW ? act_sigmoid(a.opac[g]) : a.opac[g];
+      const float oraw = second ? a.opac_b[gl] : a.opac[gl];
+      op = RAW ? act_sigmoid(oraw) : oraw;
       if (a.colors) {
         aux0 = a.colors[3 * g]; aux1 = a.colors[3 * g + 1]; aux2 = a.colors[3 * g + 2];
       } else {
@@ -1379,7 +1397,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_fwd(PreArgs a) {
       } else {
         const float x = sl[9], y = sl[10], z = sl[11];
         float sv[12];
-        load_sh12<RAW>(a.sh, a.sh_dc, gg, q, sv);
+        if (gg >= (uint32_t)a.Pa) load_sh12<RAW>(a.sh_b, a.sh_dc_b, gg - (uint32_t)a.Pa, q, sv);
+        else load_sh12<RAW>(a.sh, a.sh_dc, gg, q, sv);
         float b[16], gx[16], gy[16], gz[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) b[k] = 0.f;

@@ -97,6 +97,8 @@ def _load():
     lib.gsr_forward_raw.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [vp, vp, vp, ctypes.POINTER(vp), i64p, vp]
     lib.gsr_backward_raw.restype = ctypes.c_int
     lib.gsr_backward_raw.argtypes = [vp] * 12
+    lib.gsr_forward_raw2.restype = ctypes.c_int
+    lib.gsr_forward_raw2.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [i32] + [vp] * 7 + [vp, vp, vp, i64p, vp]
     lib.gsr_ctx_free.restype = None
     lib.gsr_ctx_free.argtypes = [vp]
     lib.gsr_mark_visible.restype = ctypes.c_int
@@ -485,6 +487,46 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc
                                         raster_settings)
 
 
+@torch.no_grad()
+def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool = True):
+    """Forward-only render of two reference-style parameter sets as ONE scene -- `params_a` followed by `params_b`,
+    each (xyz, features_dc, features_rest, objects_dc or None, opacity, scaling, rotation), RAW tensors -- without
+    concatenating them (gsr_forward_raw2; reference attack.py:513-530 deep-copies the model and concatenates all seven
+    tensors for this).  -> (color[3,H,W], radii[Pa+Pb], objects[16,H,W]); bitwise equal to rasterize_gaussians_raw on
+    the concatenated tensors.  Not differentiable (the reference never calls backward on this render)."""
+    lib = _load()
+    xa = params_a[0]
+    if not xa.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device; there is no CPU path")
+    device = xa.device
+
+    def prep(t):
+        return None if t is None or t.numel() == 0 else _f32c(t.detach(), device)
+    a = [prep(t) for t in params_a]
+    b = [prep(t) for t in params_b]
+    Pa, Pb = int(params_a[0].shape[0]), int(params_b[0].shape[0])
+    for P, (x, dc, rest, obj, op, sc, ro) in ((Pa, a), (Pb, b)):
+        if P and (tuple(dc.shape) != (P, 1, 3) or tuple(rest.shape) != (P, 15, 3)):
+            raise ValueError("fused path needs _features_dc [P,1,3] and _features_rest [P,15,3] (SH degree 3 storage)")
+    with_obj = objects and (Pa == 0 or a[3] is not None) and (Pb == 0 or b[3] is not None)
+    H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    pack = _SettingsPack(raster_settings, device)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+    objs = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if with_obj
+            else _zero_scalar(device).expand(NUM_OBJECTS, H, W))
+    radii = torch.empty(Pa + Pb, dtype=torch.int32, device=device)
+    nren = ctypes.c_int64(0)
+    if not with_obj:
+        a[3] = b[3] = None
+    with torch.cuda.device(device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        rc = lib.gsr_forward_raw2(ctypes.byref(pack.c), Pa, *[_ptr(t) for t in a], Pb, *[_ptr(t) for t in b], _ptr(color),
+                                  _ptr(objs) if with_obj else None, _ptr(radii), ctypes.byref(nren), stream)
+    if rc != 0:
+        raise (Exception if rc == 1 else RuntimeError)(_err(lib))
+    return color, radii, objs
+
+
 def rasterize_gaussians(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
@@ -585,5 +627,6 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
+           "rasterize_gaussians_raw2",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

@@ -7,11 +7,15 @@ with alpha 0.5 / epsilon 5.0, ``configs/config.yaml:47-48``) and clear the gradi
 party and out of scope: a fixed random convolutional "surrogate detector" supplies a
 differentiable scalar per render, or any callable ``loss_fn(renders[B,3,H,W]) -> scalar`` can be passed in.
 
-Differences from the reference that are deliberate and documented in SURVEY.md section 3.1:
-  * gradients are zeroed every iteration (the reference's optimizer.zero_grad is a no-op on the live tensors, so its
-    .grad accumulates over iterations); the per-step gradient is what gets all-reduced in multi-GPU runs;
-  * with torch.distributed initialised, the batch's views are sharded over ranks and the attribute gradients are
-    sum-all-reduced once per iteration (gsplat_attack.dist) before the identical step on every rank.
+Defaults that differ from the reference, each with a switch that restores its behaviour:
+  * gradients are zeroed every iteration; ``accumulate_grads=True`` reproduces the reference, whose
+    optimizer.zero_grad is a no-op on the live tensors so that .grad accumulates over iterations (attack.py:602-604);
+  * one loss and one backward per view; ``batch_loss=True`` stacks the B renders and calls the loss once, with all B
+    rasteriser contexts alive through one backward (attack.py:476-494);
+  * the success check after each step (attack.py:513-569) renders target + frozen background WITHOUT the deep copy and
+    the seven concatenations (``render_pair``); ``run_attack`` is the batch schedule around it;
+  * with torch.distributed initialised, the batch's views are sharded over ranks and the per-step attribute gradients
+    are sum-all-reduced once per iteration (gsplat_attack.dist) before the identical step on every rank.
 """
 from __future__ import annotations
 
@@ -28,7 +32,7 @@ from torch import nn
 from . import dist as gdist
 from . import pgd
 from .streams import StreamRing
-from .renderer import PipelineParams, render
+from .renderer import PipelineParams, render, render_pair
 
 GROUPS = ("color", "position", "scaling", "rotation", "opacity")
 
@@ -61,29 +65,77 @@ def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsi
               "rotation": ("_rotation", "rotation"), "opacity": ("_opacity", "opacity")}
     for g in groups:
         if g == "color":
+            # the reference steps only when both colour gradients exist (attack.py:496)
+            if model._features_rest.grad is None or model._features_dc.grad is None:
+                continue
             fn[(g, norm)]()
         else:
             attr, name = single[g]
+            if getattr(model, attr).grad is None:      # no gradient reached this group (e.g. a rank without views)
+                continue
             getattr(pgd, f"gaussian_{name}_{norm}_attack")(model, alpha, epsilon, originals[attr])
+
+
+def _world():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def gather_success(flags: Sequence[bool], n_views: int, rank: int, world: int, device) -> List[bool]:
+    """The batch's per-view success flags on every rank (reference attack.py:556-560 counts them on one GPU): rank r
+    owns views r, r+world, ...; one tiny all-reduce of a B-element vector."""
+    full = torch.zeros(n_views, dtype=torch.int32, device=device)
+    idx = gdist.views_of_rank(n_views, rank, world)
+    if idx:
+        full[torch.tensor(idx, device=device)] = torch.tensor([int(bool(f)) for f in flags], dtype=torch.int32, device=device)
+    if world > 1:
+        if device.type == "cuda" and torch.distributed.get_backend() == "gloo":
+            full = full.cpu()
+        torch.distributed.all_reduce(full)
+    return [bool(v) for v in full.tolist()]
 
 
 def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5, epsilon: float = 5.0,
                groups: Iterable[str] = ("color",), norm: str = "l2", bg: Optional[torch.Tensor] = None,
                loss_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, pipe: Optional[PipelineParams] = None,
-               log: Optional[Callable[[dict], None]] = None, streams: int = 3) -> List[float]:
-    """Runs `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
+               log: Optional[Callable[[dict], None]] = None, streams: int = 3, accumulate_grads: bool = False,
+               batch_loss: bool = False, loss_reduction: str = "sum", background=None,
+               success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
+               originals: Optional[dict] = None) -> List[float]:
+    """Runs up to `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
     initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
-    pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order."""
+    pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order.
+
+    Reference-faithful switches (all off by default):
+      accumulate_grads  .grad is NOT cleared between iterations -- what the reference does in effect: its
+                        optimizer.zero_grad (attack.py:602) does not hold the live tensors, so every step uses the SUM of
+                        all gradients so far.  Multi-GPU: the running sum is kept on every rank from the all-reduced
+                        per-step gradients, so ranks stay identical.
+      batch_loss        the B renders are stacked and `loss_fn` is called ONCE on [B,3,H,W], one backward through all B
+                        live rasteriser contexts (attack.py:476-494), instead of one loss per view.  A detector loss that
+                        normalises over the batch needs this.  loss_reduction="mean" declares that loss_fn averages over
+                        its inputs: each rank's loss is then weighted by (its views / B) so that the all-reduced gradient
+                        is that of the single-GPU batch (SURVEY.md section 8e caveat).
+      background, success_fn, save_path
+                        after every step the target is re-rendered together with the frozen `background` model
+                        (render_pair: no deep copy, no concatenation; attack.py:513-530), success_fn(image, view index)
+                        says whether the detector was fooled on that view, the B flags are gathered over the ranks, and
+                        when at least B-1 views succeed (attack.py:560) the loop stops and the attacked model is written
+                        to save_path (attack.py:566-568).  The flags of the last iteration are in log records
+                        ("successes") and in pgd_attack.last_successes."""
     groups = tuple(groups)
-    assert all(g in GROUPS for g in groups) and norm in ("l2", "linf")
+    assert all(g in GROUPS for g in groups) and norm in ("l2", "linf") and loss_reduction in ("sum", "mean")
     dev = model.get_xyz.device
     pipe = pipe or PipelineParams(skip_objects=True)
     bg = torch.zeros(3, device=dev) if bg is None else bg.to(dev)
     loss_fn = loss_fn or SurrogateDetector().to(dev)
-    rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) \
-        if torch.distributed.is_available() and torch.distributed.is_initialized() else (0, 1)
-    mine = [cameras[i] for i in gdist.views_of_rank(len(cameras), rank, world)]
-    originals = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
+    rank, world = _world()
+    my_idx = gdist.views_of_rank(len(cameras), rank, world)
+    mine = [cameras[i] for i in my_idx]
+    if originals is None:
+        originals = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
+    pgd_attack.last_successes = None
     # A colour-only attack needs no geometry gradients: freeze those parameters for the duration of the attack and the
     # rasteriser's backward drops the geometry sums and the projection chain rule (the reference computes and discards
     # them: all seven tensors are re-wrapped with requires_grad=True, SURVEY.md section 3.1 quirk 2).
@@ -96,44 +148,104 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             if p.requires_grad:
                 p.requires_grad_(False)
                 frozen.append(p)
+    reduce_names = ("_features_dc", "_features_rest") if frozen else gdist.ATTACK_PARAMS
+    running = {}                                           # accumulate_grads with world > 1: the running sums
     try:
         history = []
-        ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" else None
+        ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" and not batch_loss else None
         for it in range(iters):
             t0 = time.perf_counter()
-            model.zero_grad()
+            if not accumulate_grads or world > 1:
+                model.zero_grad()                          # multi-GPU: .grad holds THIS step's gradient until reduced
             losses = []
-            for cam in mine:                                   # one forward+backward per view: peak memory = one view per stream
-                with (ring.next() if ring is not None else contextlib.nullcontext()):
-                    img = render(cam, model, pipe, bg)["render"]
-                    loss = loss_fn(img[None])
+            if batch_loss:
+                if mine:
+                    renders = torch.stack([render(cam, model, pipe, bg)["render"] for cam in mine])
+                    loss = loss_fn(renders)
+                    if loss_reduction == "mean":
+                        loss = loss * (len(mine) / len(cameras))
                     loss.backward()
                     losses.append(loss.detach())
-            if ring is not None:
-                ring.join()
+            else:
+                for cam in mine:                           # one forward+backward per view: peak memory = one view per stream
+                    with (ring.next() if ring is not None else contextlib.nullcontext()):
+                        img = render(cam, model, pipe, bg)["render"]
+                        loss = loss_fn(img[None])
+                        if loss_reduction == "mean":
+                            loss = loss / len(cameras)
+                        loss.backward()
+                        losses.append(loss.detach())
+                if ring is not None:
+                    ring.join()
             total = torch.stack(losses).sum() if losses else torch.zeros((), device=dev)
             if world > 1:
-                if frozen:
-                    gdist.allreduce_attribute_grads(model, names=("_features_dc", "_features_rest"))   # 192 MB instead of 236
-                else:
-                    gdist.allreduce_attribute_grads(model)
+                gdist.allreduce_attribute_grads(model, names=reduce_names)     # one bucket: 236 MB, or 192 MB colour-only
                 torch.distributed.all_reduce(total)
+                if accumulate_grads:
+                    for n in reduce_names:
+                        p = getattr(model, n)
+                        running[n] = p.grad.clone() if n not in running else running[n].add_(p.grad)
+                        p.grad = running[n]
             _step(model, originals, groups, norm, alpha, epsilon)
             history.append(float(total))
+            rec = {"iter": it, "loss": history[-1], "views": len(cameras)}
+            done = False
+            if success_fn is not None:
+                imgs = render_combined(model, background, mine, bg, pipe)
+                flags = gather_success([success_fn(im, i) for im, i in zip(imgs, my_idx)], len(cameras), rank, world, dev)
+                pgd_attack.last_successes = flags
+                rec["successes"] = flags
+                done = sum(flags) >= len(cameras) - 1      # attack.py:560: all views, or all but one
             if log is not None:
                 if dev.type == "cuda":
                     torch.cuda.synchronize()
-                log({"iter": it, "loss": history[-1], "seconds": time.perf_counter() - t0, "views": len(cameras)})
+                rec["seconds"] = time.perf_counter() - t0
+                log(rec)
+            if done:
+                if save_path is not None and rank == 0:
+                    model.save_ply(save_path)
+                break
     finally:
         for p in frozen:
             p.requires_grad_(True)
     return history
 
 
+pgd_attack.last_successes = None
+
+
+def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5, max_iters: int = 20,
+               success_fn: Callable[[torch.Tensor, int], bool], save_path: Optional[str] = None, **kw) -> dict:
+    """The batch schedule of the reference's run() (attack.py:463-475, 560-569): the pending views are attacked
+    `batch_size` at a time; a batch that reaches B-1 successes is retired, one that exhausts `max_iters` iterations is
+    dropped, and when no view is pending the attacked model is saved.  Perturbations accumulate across batches: every
+    batch projects onto the eps-ball around the ORIGINAL attributes (attack.py:397-403 captures them once).
+    -> {"batches": [{"views", "iters", "success", "loss"}], "all_succeeded"}."""
+    pending = list(range(len(cameras)))
+    originals = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
+    report = []
+    while pending:
+        cur = pending[:batch_size]
+        batch = [cameras[i] for i in cur]
+        hist = pgd_attack(model, batch, iters=max_iters - 1, background=background,      # attack.py:470: the iteration
+                          success_fn=lambda im, j: success_fn(im, cur[j]),                # budget's last slot drops the batch
+                          originals=originals, **kw)
+        flags = pgd_attack.last_successes or []
+        ok = sum(flags) >= len(cur) - 1
+        report.append({"views": cur, "iters": len(hist), "success": bool(ok), "loss": hist[-1] if hist else None})
+        pending = pending[len(cur):]
+    done = all(b["success"] for b in report)
+    rank, _ = _world()
+    if done and save_path is not None and rank == 0:
+        model.save_ply(save_path)
+    return {"batches": report, "all_succeeded": done}
+
+
 def combine_with_background(attacked, background):
-    """The scene the reference evaluates after every step: the attacked target Gaussians followed by the frozen
-    background (reference attack.py:513-520: deepcopy + seven concat_setup calls).  Here: one concatenation per
-    attribute into a fresh model, no deep copy of the attacked one."""
+    """The scene the reference evaluates after every step, as an explicit model: the attacked target Gaussians followed
+    by the frozen background (reference attack.py:513-520: deepcopy + seven concat_setup calls).  Only for callers that
+    need the concatenated model itself (e.g. to save it); rendering it goes through render_combined, which does not
+    build it."""
     from .gaussian_model import GaussianModel
     cat = {k: torch.cat((a.detach(), b.detach().to(a.device)), dim=0)
            for k, a, b in ((n, getattr(attacked, n), getattr(background, n)) for n in GaussianModel._PARAM_ATTRS)}
@@ -144,10 +256,13 @@ def combine_with_background(attacked, background):
 
 @torch.no_grad()
 def render_combined(attacked, background, cameras: Sequence, bg: torch.Tensor, pipe: Optional[PipelineParams] = None):
-    """Forward-only renders of target + background for the success check (reference attack.py:522-530)."""
+    """Forward-only renders of target + background for the success check (reference attack.py:522-530).  The two
+    parameter sets go to the rasteriser side by side (render_pair -> gsr_forward_raw2): no deep copy of the model, no
+    concatenation of its seven tensors per PGD iteration.  background None: the target alone."""
     pipe = pipe or PipelineParams(skip_objects=True)
-    scene = combine_with_background(attacked, background)
-    return [render(cam, scene, pipe, bg)["render"] for cam in cameras]
+    if background is None:
+        return [render(cam, attacked, pipe, bg)["render"] for cam in cameras]
+    return [render_pair(cam, attacked, background, pipe, bg)["render"] for cam in cameras]
 
 
 def main():

@@ -11,7 +11,8 @@ import math
 
 import torch
 
-from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
+from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw,
+                                         rasterize_gaussians_raw2)
 
 from .sh import eval_sh
 
@@ -103,3 +104,20 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         kw["shs"] = pc.get_features
     image, radii, objects = GaussianRasterizer(raster_settings=st)(**kw)
     return _result(image, screenspace_points, radii, objects)
+
+
+@torch.no_grad()
+def render_pair(viewpoint_camera, pc_a, pc_b, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
+    """render() of the scene "pc_a followed by pc_b" without building it: the attacked target plus the frozen
+    background, which the reference re-renders after every PGD step from a deep copy with all seven tensors
+    concatenated (attack.py:513-530).  Forward only (the reference never differentiates that render); same dict as
+    render(), `viewspace_points` None, the Gaussian-indexed entries cover pc_a then pc_b."""
+    if not (_has_raw_layout(pc_a) and _has_raw_layout(pc_b)):
+        raise ValueError("render_pair needs two models in the reference's raw storage layout on a HIP device")
+    st = _settings(viewpoint_camera, pc_a, pipe, bg_color, scaling_modifier)
+
+    def raw(pc):
+        return (pc._xyz, pc._features_dc, pc._features_rest, pc._objects_dc, pc._opacity, pc._scaling, pc._rotation)
+    image, radii, objects = rasterize_gaussians_raw2(raw(pc_a), raw(pc_b), st,
+                                                     objects=not bool(getattr(pipe, "skip_objects", False)))
+    return _result(image, None, radii, objects)

@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_FILE = "r02_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r02.sh)
 
 
 def log(msg: str) -> None:
@@ -149,6 +150,10 @@ def main():
                          "kernels of one view overlap the compositing kernels of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed forward-only / PGD-iteration extras")
+    ap.add_argument("--one-camera", action="store_true",
+                    help="render the same camera every step (round-1 behaviour) instead of cycling the 8 ring cameras")
+    ap.add_argument("--dense-pairs", type=float, default=10e6,
+                    help="target pair count of the second, denser data point (scale_modifier is searched for it); 0 = skip")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
     args = ap.parse_args()
 
@@ -180,6 +185,16 @@ def main():
                                    n_views=n_views)
     cam = cams[rank % n_views]
     H, W = cam.image_height, cam.image_width
+    # every timed step renders the NEXT camera of the 8-view ring (rank r, step i: view (i * world + r) mod 8), so that
+    # no step re-renders what the previous one left in the caches
+    step_no = [0]
+
+    def next_cam():
+        if args.one_camera:
+            return cam
+        c = cams[(step_no[0] * world + rank) % n_views]
+        step_no[0] += 1
+        return c
     P = model.get_xyz.shape[0]
     pipe = PipelineParams(skip_objects=not args.objects, viewspace_grad=not args.color_only,
                           fused_activations=not args.classic)
@@ -191,9 +206,11 @@ def main():
 
     info = {}
 
+    scale_mod = [1.0]
+
     def step():
         model.zero_grad()
-        out = render(cam, model, pipe, bg)
+        out = render(next_cam(), model, pipe, bg, scale_mod[0])
         out["render"].backward(gc)
         if world > 1:
             gdist.allreduce_attribute_grads(model)
@@ -221,9 +238,25 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             log(f"warmup step {i} done, N={D.last_num_rendered(out['render'])}")
-    info["N"] = D.last_num_rendered(out["render"])
-    info["V"] = int((out["radii"] > 0).sum().item())
     del out
+    # pair / visible counts of every camera of the ring (the roofline figures use their means)
+    per_cam = []
+    with torch.no_grad():
+        for c_ in (cams[:n_views] if not args.one_camera else [cam]):
+            o_ = render(c_, model, pipe, bg)
+            per_cam.append((int((o_["radii"] > 0).sum().item()), o_))
+    # num_rendered of a forward-only call: read it from a grad-enabled render's context
+    Ns = []
+    for c_ in (cams[:n_views] if not args.one_camera else [cam]):
+        o_ = render(c_, model, pipe, bg)
+        Ns.append(D.last_num_rendered(o_["render"]))
+        del o_
+    info["N_per_camera"] = Ns
+    info["V_per_camera"] = [v for v, _ in per_cam]
+    info["N"] = int(round(sum(Ns) / len(Ns)))
+    info["V"] = int(round(sum(info["V_per_camera"]) / len(per_cam)))
+    del per_cam
+    step_no[0] = 0
 
     # Timed region: only the dominant kernel stage (K7, the backward composite) is bracketed by HIP events on the
     # launch stream -- two event records per step; bracketing all seven stages costs ~10 us of queue gap each.
@@ -244,6 +277,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if rank == 0:
         log(f"timed region done: {args.steps} steps in {elapsed:.3f} s (host enqueue {t_enq:.3f} s)")
+        if elapsed < 0.1:
+            log(f"WARNING: the timed region lasted {elapsed * 1e3:.1f} ms; use --steps >= 300 for a stable number")
     dom_ms_timed = D.profile_read()[DOMINANT][0] / args.steps
     # Untimed extra pass with every stage bracketed: the per-stage breakdown reported under "stages".
     D.profile(True)
@@ -280,10 +315,10 @@ def main():
         traffic = None
         valu = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
-                    "preprocess_bwd": "void gsr::k_preprocess_bwd<true, true, true>",
-                    "preprocess": "void gsr::k_preprocess<true, true>"}.get(dom)
+                    "preprocess_bwd": "void gsr::k_pre_bwd<true, true>",
+                    "preprocess": "void gsr::k_pre_fwd<true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
                 n_valu = pmc["per_kernel"][kern].get("SQ_INSTS_VALU")
@@ -319,6 +354,9 @@ def main():
                                    + (", gradients on SH coefficients only" if args.color_only else "")
                                    + (", classic activated-tensor surface" if args.classic else ""),
                        "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
+                       "cameras": "one fixed camera" if args.one_camera else
+                                  f"the {n_views} ring cameras in turn (V and N are means over them)",
+                       "N_pairs_per_camera": info["N_per_camera"], "V_visible_per_camera": info["V_per_camera"],
                        "streams": args.streams,
                        "parallelism": f"views sharded 1/GPU, dp{world}"
                                       + (f", consecutive views pipelined over {args.streams} HIP streams per GPU"
@@ -326,6 +364,9 @@ def main():
                                       + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
+                         "this workload (not measured inside this run; FETCH_SIZE doubled per MI355X_MICROARCH.md)",
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
                          # the same kernel with nothing beside it (untimed one-stream pass): in the timed region its
                          # launches share the chip with the other streams' kernels
@@ -338,6 +379,39 @@ def main():
         }
         if valu is not None:
             result["roofline"]["valu"] = valu
+        if world == 1 and not args.no_extras and args.dense_pairs > 0:
+            # Second data point: the same scene with the splats scaled up until a view emits ~10 M pairs (BASELINE.md's
+            # nominal N; the SURVEY section 8d distributions give 3 M).  scale_modifier is render()'s own argument.
+            log("dense data point: searching scale_modifier ...")
+            lo, hi = 1.0, 6.0
+            for _ in range(7):
+                mid = 0.5 * (lo + hi)
+                n_mid = D.last_num_rendered(render(cam, model, pipe, bg, mid)["render"])
+                lo, hi = (mid, hi) if n_mid < args.dense_pairs else (lo, mid)
+            scale_mod[0] = 0.5 * (lo + hi)
+            n_dense = []
+            for c_ in cams[:n_views]:
+                o_ = render(c_, model, pipe, bg, scale_mod[0])
+                n_dense.append(D.last_num_rendered(o_["render"]))
+                del o_
+            step_no[0] = 0
+            run_steps(12)
+            torch.cuda.synchronize()
+            nd = max(40, min(args.steps, 150))
+            t0 = time.perf_counter()
+            run_steps(nd)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            Nd = sum(n_dense) / len(n_dense)
+            Bd = 304 * P + 548 * V + 116 * Nd + 40 * HW            # V of the unscaled scene: a lower bound
+            result["dense"] = {"value": round(nd / dt, 2), "unit": "views/s", "ms_per_step": round(dt / nd * 1e3, 4),
+                               "steps": nd, "scale_modifier": round(scale_mod[0], 4), "N_pairs": int(round(Nd)),
+                               "N_pairs_per_camera": n_dense,
+                               "pipeline_GBps": round(Bd / (dt / nd) / 1e9, 1),
+                               "workload": "same scene and cameras, every splat scaled by scale_modifier so that a view "
+                                           "emits ~10 M (tile, Gaussian) pairs (BASELINE.md section 3 nominal)"}
+            scale_mod[0] = 1.0
+            step_no[0] = 0
         if world == 1 and not args.no_extras:
             # SURVEY.md section 8d "also report": forward-only rate and one PGD iteration (untimed extras)
             log("extras: forward-only views, PGD iterations ...")

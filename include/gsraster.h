@@ -133,6 +133,19 @@ int gsr_backward_raw(GsrCtx* ctx, const float* grad_color, const float* grad_obj
                      float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
                      float* dlog_scaling, float* drotation_raw, void* stream);
 
+/* Forward-only render of TWO parameter sets as one scene: the attacked target (a) followed by the frozen background (b),
+ * Gaussians numbered a then b (radii [Pa+Pb]).  Replaces what the reference does after every PGD step to check the
+ * attack: deep-copy the attacked model, append the background to each of its seven tensors (seven concat_setup calls,
+ * ~300 MB at 1 M Gaussians) and render the copy (reference attack.py:513-530).  Same image, bit for bit, as
+ * gsr_forward_raw on the concatenated tensors; nothing is copied, no context is kept (the reference never
+ * differentiates this render).  objects_dc_*: both or neither. */
+int gsr_forward_raw2(const GsrSettings* settings, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                     const float* features_rest_a, const float* objects_dc_a, const float* opacity_logit_a,
+                     const float* log_scaling_a, const float* rotation_raw_a, int32_t Pb, const float* xyz_b,
+                     const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
+                     const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
+                     float* out_color, float* out_objects, int32_t* radii, int64_t* num_rendered, void* stream);
+
 /* Releases the context's workspace back to the pool (stream-ordered: safe right after enqueueing backward). */
 void gsr_ctx_free(GsrCtx* ctx);
 

@@ -213,7 +213,7 @@ def _project(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=No
 
 
 DEBUG_COUNTS = None
-ERR_SAFETY = 8.0   # error bar = ERR_SAFETY * |float32 run - float64 run| + a few ulps
+ERR_SAFETY = 3.0   # error bar = ERR_SAFETY * |float32 run - float64 run| + a few ulps
 
 
 def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
@@ -244,11 +244,11 @@ def preprocess(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=
         d = torch.nan_to_num(d, nan=0.0, posinf=0.0, neginf=0.0)
         return ERR_SAFETY * d + floor
     e_rr = bar(rr, q2["rr"], 8 * f32eps * rr.detach().double().abs())
-    e_px = bar(px, q2["px"], 4 * f32eps * max(W, 1))
-    e_py = bar(py, q2["py"], 4 * f32eps * max(H, 1))
+    e_px = bar(px, q2["px"], 0.5 * f32eps * max(W, 1))
+    e_py = bar(py, q2["py"], 0.5 * f32eps * max(H, 1))
     # depth: the oracle orders by float32(depth); an implementation's own float32 depth differs from that by its
     # rounding, which the shadow run measures (3x: it is an order statistic, not a continuous quantity) plus two ulps
-    e_z = (3.0 / ERR_SAFETY) * bar(tz, q2["tz"], 0.0) + 2 * f32eps * tz.detach().double().abs()
+    e_z = bar(tz, q2["tz"], 0.0) + 2 * f32eps * tz.detach().double().abs()
     e_con = bar(conic, q2["conic"], 8 * f32eps * conic.detach().double().abs())
 
     gx = (W + TILE - 1) // TILE
@@ -491,8 +491,10 @@ def rasterize(means3D, means2D, opacities, st: Settings, shs=None, sh_objs=None,
             # T' = prod (1 - alpha): relative bar = sum over the contributing entries of alpha/(1-alpha) * bar(alpha)
             # (an alpha held at the 0.99 cap has no error of its own)
             capped = a_raw >= 0.99 * (1.0 + e_al)
-            e_T = torch.cumsum(torch.where(valid & ~capped, a_eff / one_m * e_al, torch.zeros_like(e_al)), dim=1) \
-                + 4e-7 * torch.cumsum(valid.to(dtype), dim=1) + tol
+            # (the entries of a list are different Gaussians with independent errors: root of the sum of squares)
+            term = torch.where(valid & ~capped, a_eff / one_m * e_al, torch.zeros_like(e_al))
+            e_T = 3.0 * torch.sqrt(torch.cumsum(term * term, dim=1)) \
+                + 3e-7 * torch.sqrt(torch.cumsum(valid.to(dtype), dim=1)) + tol
             frT = (reach & valid & ((T_incl * 1e4 - 1.0).abs() < e_T)).any(dim=1)           # T' ~ 1e-4
             if DEBUG_COUNTS is not None:
                 DEBUG_COUNTS["T"] = DEBUG_COUNTS.get("T", 0) + int(frT.sum())

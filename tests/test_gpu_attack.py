@@ -145,3 +145,108 @@ def test_render_with_a_reference_style_pipe_object_takes_the_fused_path():
     assert (out["render_object"] - ref["render_object"]).abs().max().item() < 2e-6
     out["render"].sum().backward()
     assert model._scaling.grad is not None and out["viewspace_points"].grad is not None
+
+
+def test_render_pair_equals_the_concatenated_scene_with_objects_and_radii():
+    """gsr_forward_raw2 (two parameter sets side by side) against render() of the explicitly concatenated model:
+    image, object map and radii bit for bit, at a size where the lists are long (segments, both tile splits)."""
+    from gsplat_attack.attack import combine_with_background
+    from gsplat_attack.renderer import PipelineParams, render, render_pair
+    from gsplat_attack.scenes import make_scene
+    model, cams, _ = make_scene("nyc-1M", device="cuda", P=60000, width=640, height=360, n_views=2)
+    P = model.get_xyz.shape[0]
+    cut = 2 * P // 5 + 3                                   # not a multiple of 64: a wave straddles the two segments
+    mask = torch.zeros(P, dtype=torch.bool, device="cuda")
+    mask[:cut] = True
+    target, background = model.clone(), model.clone()
+    target.removal_setup(~mask)                            # first `cut` rows
+    background.removal_setup(mask)                         # the rest
+    bg = torch.tensor([0.3, 0.1, 0.2], device="cuda")
+    whole = combine_with_background(target, background)
+    for objects in (False, True):
+        pipe = PipelineParams(skip_objects=not objects)
+        with torch.no_grad():
+            ref = render(cams[1], whole, pipe, bg)
+        got = render_pair(cams[1], target, background, pipe, bg)
+        assert torch.equal(ref["render"], got["render"])
+        assert torch.equal(ref["radii"], got["radii"]) and got["radii"].numel() == P
+        assert torch.equal(ref["render_object"], got["render_object"])
+    assert float(got["render_object"].abs().max()) > 0
+    # degenerate splits
+    empty = target.clone()
+    empty.removal_setup(torch.ones(cut, dtype=torch.bool, device="cuda"))
+    assert empty.get_xyz.shape[0] == 0
+    with torch.no_grad():
+        ref = render(cams[0], target, PipelineParams(skip_objects=True), bg)["render"]
+    assert torch.equal(render_pair(cams[0], target, empty, PipelineParams(skip_objects=True), bg)["render"], ref)
+    assert torch.equal(render_pair(cams[0], empty, target, PipelineParams(skip_objects=True), bg)["render"], ref)
+
+
+def test_reference_loop_switches_match_a_straight_line_transcription():
+    """pgd_attack(accumulate_grads=True, batch_loss=True) against the reference loop written out with plain PyTorch
+    calls (attack.py:476-499 + :602-604 as it actually behaves): B renders stacked, ONE loss, one backward, the L2
+    colour step of gsplat_attack.pgd (pinned to attack.py:138-173 by the golden fixtures), .grad never cleared."""
+    from gsplat_attack import pgd
+    from gsplat_attack.attack import SurrogateDetector, pgd_attack
+    from gsplat_attack.renderer import PipelineParams, render
+    model, cams, _ = _scene(n_views=3)
+    twin = model.clone()
+    det = SurrogateDetector().to("cuda")
+    bg = torch.tensor([0.1, 0.1, 0.1], device="cuda")
+    hist = pgd_attack(model, cams, iters=2, alpha=0.5, epsilon=5.0, groups=("color",), norm="l2", bg=bg, loss_fn=det,
+                      accumulate_grads=True, batch_loss=True, streams=1)
+    # transcription (geometry frozen like pgd_attack does for a colour attack: same gradients on the colour tensors)
+    o_rest, o_dc = twin._features_rest.detach().clone(), twin._features_dc.detach().clone()
+    pipe = PipelineParams(skip_objects=True)
+    want = []
+    for it in range(2):
+        renders = torch.stack([render(cam, twin, pipe, bg)["render"] for cam in cams])
+        loss = det(renders)
+        loss.backward()                                    # .grad accumulates: nothing zeroes it (attack.py:602 is a no-op)
+        want.append(float(loss))
+        pgd.gaussian_color_l2_attack(twin, 0.5, 5.0, o_rest, o_dc)
+    torch.cuda.synchronize()
+    assert hist == pytest.approx(want, rel=1e-5)
+    for n in ("_features_dc", "_features_rest"):
+        a, b = getattr(model, n).detach(), getattr(twin, n).detach()
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item()), n
+    # and the switches matter: zeroing the gradients each iteration gives a different second step
+    third = twin.clone()
+    for n, o in (("_features_rest", o_rest), ("_features_dc", o_dc)):
+        getattr(third, n).data.copy_(o)
+    pgd_attack(third, cams, iters=2, alpha=0.5, epsilon=5.0, groups=("color",), norm="l2", bg=bg, loss_fn=det,
+               batch_loss=True, streams=1)
+    assert (third._features_rest.detach() - twin._features_rest.detach()).abs().max().item() > 1e-4
+
+
+def test_success_bookkeeping_stops_the_loop_and_saves_the_model(tmp_path):
+    """Success flags per view after every step from the target + background re-render; the loop stops at B-1 successes
+    and writes the attacked model (attack.py:556-569)."""
+    from gsplat_attack.attack import pgd_attack, run_attack
+    from gsplat_attack.gaussian_model import GaussianModel
+    model, cams, _ = _scene(n_views=3)
+    P = model.get_xyz.shape[0]
+    mask = torch.zeros(P, dtype=torch.bool, device="cuda")
+    mask[: P // 2] = True
+    target, background = model.clone(), model.clone()
+    target.removal_setup(~mask)
+    background.removal_setup(mask)
+    seen = []
+
+    def success(img, view):                                # "fooled" once the image moved away from its first version
+        seen.append((view, tuple(img.shape)))
+        first.setdefault(view, img.clone())
+        return bool((img - first[view]).abs().mean() > 2e-4)
+    first = {}
+    recs = []
+    path = str(tmp_path / "adv.ply")
+    hist = pgd_attack(target, cams, iters=12, background=background, success_fn=success, save_path=path, log=recs.append,
+                      streams=1)
+    assert 1 < len(hist) < 12 and sum(recs[-1]["successes"]) >= 2 and not any(recs[0]["successes"])
+    assert all(s == (3, 192, 320) for _, s in seen)
+    back = GaussianModel.load_ply(path, device="cuda")
+    assert torch.allclose(back._features_dc, target._features_dc.detach(), atol=1e-6)
+    # the batch schedule around it: 3 views in batches of 2
+    first.clear()
+    rep = run_attack(target.clone(), cams, background=background, batch_size=2, max_iters=10, success_fn=success, streams=1)
+    assert [b["views"] for b in rep["batches"]] == [[0, 1], [2]] and rep["all_succeeded"]

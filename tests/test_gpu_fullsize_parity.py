@@ -107,7 +107,7 @@ def hip_raw(model, cam, bg, gc, flags=0, fused=True, objects=False, go=None, col
     return out, grads
 
 
-def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=5e-2, objects=False):
+def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=0.12, objects=False):
     color = out["render"].detach().cpu().double()
     err = (color - ro.color.detach()).abs().max(dim=0).values
     solid = m & ~ro.fragile_px

@@ -409,7 +409,7 @@ def test_lists_longer_than_the_schedule_bins():
     shs = torch.randn(P, 16, 3, generator=g) * 0.3
     inp = dict(means3D=xyz, shs=shs, opacities=opac, scales=scales, rotations=rots)
     cam = look_at_camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), fovx=0.5, width=48, height=48)
-    check(inp, cam, torch.tensor([0.2, 0.1, 0.3]), frag_frac=2e-2, elem_frac=3e-3)
+    check(inp, cam, torch.tensor([0.2, 0.1, 0.3]), frag_frac=8e-2, elem_frac=3e-3)
     # the lists really are that long
     dev = torch.device("cuda:0")
     st = settings_for(cam, torch.zeros(3), 3, 1.0, cls=D.GaussianRasterizationSettings, device=dev)
