@@ -345,7 +345,6 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const size_t Pp = (size_t)std::max(P, 1);
   // ---- kept slab ---------------------------------------------------------------------------
   SlabPlan kp;
-  kp.add<float4>(3 * Pp);   // R records (depth order)
   kp.add<float4>(3 * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<unsigned long long>(2); kp.add<uint32_t>(ntiles);
@@ -368,8 +367,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     return set_err(GSR_ERR_NOMEM, "gsr_forward: workspace allocation failed (P=%d, %dx%d)", P, W, H);
   }
   Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
-  c->R0 = ks.take<float4>(3 * Pp); c->R1 = c->R0 + 1; c->R2 = c->R0 + 2;   // interleaved 48-byte records
-  c->G0 = ks.take<float4>(3 * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;
+  c->G0 = ks.take<float4>(3 * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;   // interleaved 48-byte records
+  c->R0 = c->G0; c->R1 = c->G1; c->R2 = c->G2;                              // the compositors gather them by Gaussian index
   c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   c->total64 = ks.take<unsigned long long>(2);
@@ -451,7 +450,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     {
       StageTimer t(GSR_STAGE_BIN, st);
       uint32_t* cnt = orderB;   // free again after the sort
-      hipLaunchKernelGGL(k_pack, gridP, blk, 0, st, P, c->order, skey, G0, G1, G2, c->R0, c->R1, c->R2, cnt);
+      (void)skey;
+      hipLaunchKernelGGL(k_rank_counts, gridP, blk, 0, st, P, c->order, tcnt, cnt);
       scan_exclusive_u32(cnt, c->off, (uint32_t)P, psums, c->off + P, st);
       F_LAUNCH("pack/scan");
       F_TRY("read pair count", hipEventSynchronize(n_ready));
@@ -483,8 +483,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     {
       StageTimer t(GSR_STAGE_BIN, st);
       const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
-      hipLaunchKernelGGL(k_emit, dim3((N + EMIT_SLOTS - 1) / EMIT_SLOTS), blk, 0, st, c->off, (uint32_t)P, N, c->R0, c->R1,
-                         c->R2, gridx, W, H, (uint32_t)ntiles, cull, tileA, rankA);
+      hipLaunchKernelGGL(k_emit, dim3((N + EMIT_SLOTS - 1) / EMIT_SLOTS), blk, 0, st, c->off, c->order, (uint32_t)P, N, c->G0,
+                         c->G1, c->G2, gridx, W, H, (uint32_t)ntiles, cull, tileA, rankA);
       F_LAUNCH("emit");
     }
     int res;

@@ -7,10 +7,10 @@
 //                 rectx_bits = minx | maxx<<12 | clampbits<<24,  recty_bits = miny | maxy<<12   (tile units)
 //   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF when culled
 //   order[r]      Gaussian index of depth rank r (stable radix argsort of dkey)
-//   R0,R1,R2[REC * r]   the same records gathered into depth order; R2.y = bits(g)
 //   off[r]        exclusive scan of tiles touched in depth order, off[P] = N (numbers the emitted pairs)
 //   offg[g]       the same scan in storage order (numbers the backward's partial rows)
-//   pair_tile/pair_rank[N]  (tile id, rank) pairs, emitted rank-major, then stably sorted by tile id
+//   pair_tile/pair_rank[N]  (tile id, Gaussian | strip mask << 28) pairs, emitted in depth-rank order, then stably
+//                 sorted by tile id (=> depth order inside a tile)
 //   ranges[t]     [start,end) of tile t in the sorted pair list
 //   final_T, n_contrib [H*W]  per-pixel transmittance / last contributing list position (1-based)
 //   part[N][12]   backward: per-(tile,Gaussian) partial sums written at the pair's EMISSION slot, so
@@ -185,29 +185,14 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// gather the records into depth order and count the tiles each rank touches
+// tiles touched per depth rank (input of the rank-order scan that numbers the emitted pairs).  The splat records stay
+// where K1 wrote them, in storage order: a tile list's consecutive entries are hundreds of ranks apart, so a
+// depth-ordered copy of the records would buy its readers (K6 / K7 gathers) nothing.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack(int P, const uint32_t* __restrict__ order,
-                                              const uint32_t* __restrict__ skey, const float4* __restrict__ G0,
-                                              const float4* __restrict__ G1, const float4* __restrict__ G2,
-                                              float4* __restrict__ R0, float4* __restrict__ R1,
-                                              float4* __restrict__ R2, uint32_t* __restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_rank_counts(int P, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ tcnt, uint32_t* __restrict__ cnt) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P) return;
-  const uint32_t g = order[r];
-  if (skey[r] == 0xFFFFFFFFu) {   // culled: all such ranks sit at the tail
-    cnt[r] = 0;
-    R2[REC * r] = make_float4(0.f, __uint_as_float(g), 0.f, 0.f);
-    return;
-  }
-  const float4 a = G0[REC * g], b = G1[REC * g], c = G2[REC * g];
-  const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
-  const uint32_t wx = ((rx >> 12) & RECT_MASK) - (rx & RECT_MASK);
-  const uint32_t wy = ((ry >> 12) & RECT_MASK) - (ry & RECT_MASK);
-  cnt[r] = wx * wy;
-  R0[REC * r] = a;
-  R1[REC * r] = b;
-  R2[REC * r] = make_float4(c.x, __uint_as_float(g), c.z, c.w);
+  if (r < P) cnt[r] = tcnt[order[r]];          // culled Gaussians (all at the tail of the order): 0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,7 +214,8 @@ __device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo,
 // tail and are never composited.  The same test per 16x4 strip gives a 4-bit mask that rides in the top bits of
 // the pair's value, so K6/K7 skip strips with scalar bit tests instead of evaluating the splat there.  The rendered image, radii and gradients are unchanged by construction
 // (tile_can_contribute is conservative); only the work shrinks.  `cull` = 0 keeps every pair.
-__global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, uint32_t P, uint32_t N,
+__global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
+                                              uint32_t P, uint32_t N,
                                               const float4* __restrict__ R0, const float4* __restrict__ R1,
                                               const float4* __restrict__ R2, int gridx, int W, int H,
                                               uint32_t ntiles, int cull, uint32_t* __restrict__ pair_tile,
@@ -254,7 +240,8 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
     } else {
       r = upper_rank(off, r_lo, r_hi + 1, e); o = off[r];
     }
-    const float4 c = R2[REC * r];
+    const uint32_t g = order[r];                           // the pair's value: the Gaussian (storage index)
+    const float4 c = R2[REC * g];
     const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
     const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
     const uint32_t local = e - o;
@@ -263,7 +250,7 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
     uint32_t key = ty * (uint32_t)gridx + tx;
     uint32_t mask = 0xFu;   // one bit per 16x4 strip of the tile that the Gaussian can reach
     if (cull) {
-      const float4 a = R0[REC * r], b = R1[REC * r];
+      const float4 a = R0[REC * g], b = R1[REC * g];
       const float x0 = (float)(tx * TILE);
       const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
       mask = 0;
@@ -278,7 +265,7 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
       if (mask == 0) key = ntiles;
     }
     pair_tile[e] = key;
-    pair_rank[e] = r | (mask << RANK_BITS);
+    pair_rank[e] = g | (mask << RANK_BITS);
   }
 }
 
@@ -418,42 +405,43 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
   if (segoff == nullptr) return;
   __syncthreads();
   const uint32_t seg_len = 1u << seg_shift;
-  const int chunk = (ntiles + 1023) / 1024;
-  const int i0 = min(t * chunk, ntiles), i1 = min(i0 + chunk, ntiles);
-  uint32_t mine = 0;
-  if (seg_shift != 0u) {
-    for (int i = i0; i < i1; ++i) {
+  uint32_t carry = 0;                                  // records of the tiles in front of this round (uniform)
+  for (int i0 = 0; i0 < ntiles; i0 += 1024) {          // 1024 tiles per round, coalesced
+    const int i = i0 + t;
+    uint32_t nseg = 0;
+    if (i < ntiles && seg_shift != 0u) {
       const uint2 r = ranges[i];
       const uint32_t len = r.y - r.x;
-      if (len > seg_len) mine += (len + seg_len - 1u) >> seg_shift;
+      if (len > seg_len) nseg = (len + seg_len - 1u) >> seg_shift;
     }
-  }
-  uint32_t inc2 = mine;
+    uint32_t inc2 = nseg;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)inc2, d, 64);
-    if (lane >= d) inc2 += o;
-  }
-  if (lane == 63) wsum[wave] = inc2;
-  __syncthreads();
-  uint32_t run = inc2 - mine;
-  for (int w = 0; w < wave; ++w) run += wsum[w];
-  for (int i = i0; i < i1; ++i) {
-    const uint2 r = ranges[i];
-    const uint32_t len = r.y - r.x;
-    uint32_t off = SEG_NONE;
-    if (seg_shift != 0u && len > seg_len) {
-      const uint32_t nseg = (len + seg_len - 1u) >> seg_shift;
-      if (run + nseg <= rec_cap) {
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc2, d, 64);
+      if (lane >= d) inc2 += o;
+    }
+    __syncthreads();                                   // wsum is re-used every round
+    if (lane == 63) wsum[wave] = inc2;
+    __syncthreads();
+    uint32_t run = carry + inc2 - nseg, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t ws = wsum[w];
+      if (w < wave) run += ws;
+      total += ws;
+    }
+    if (i < ntiles) {
+      uint32_t off = SEG_NONE;
+      if (nseg != 0u && run + nseg <= rec_cap) {
         off = run;
         for (uint32_t j = 1; j < nseg; ++j) rec_item[run + j - 1u] = make_uint2((uint32_t)i, j);
         rec_item[run + nseg - 1u] = make_uint2((uint32_t)i, 0u);
       }
-      run += nseg;                                  // counted either way: the scan above did
+      segoff[i] = off;
     }
-    segoff[i] = off;
+    carry += total;
   }
-  if (t == 1023) *nrec_out = min(run, rec_cap);
+  if (t == 0) *nrec_out = min(carry, rec_cap);
 }
 __device__ __forceinline__ void set_wave_priority(uint32_t prio) {
   if (prio == 3u) __builtin_amdgcn_s_setprio(3);
@@ -539,7 +527,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       if (OBJ) {
-        const uint32_t og = __float_as_uint(c.y);
+        const uint32_t og = r;                              // the pair's value IS the Gaussian's storage index
         const float4* src = reinterpret_cast<const float4*>(og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ
                                                                                   : a.sh_objs + (size_t)og * NUM_OBJ);
         float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
@@ -837,9 +825,9 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
-      sslot[lane] = (a.offg[__float_as_uint(c.y)] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
+      sslot[lane] = (a.offg[r] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
       if (OBJ) {
-        const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)__float_as_uint(c.y) * NUM_OBJ);
+        const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)r * NUM_OBJ);
         float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
@@ -866,6 +854,43 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = 0.f;
       }
       bool hit = false;
+      // One strip's share of this entry.  `cand`: the pixel may contribute (prefilter on p2 and on its last contributor).
+      auto strip = [&](const int k, const float dy, const float p2, const bool cand) {
+        const float G = __builtin_amdgcn_exp2f(p2);
+        const float oG = e1.y * G;
+        const float alpha = fminf(ALPHA_CAP, oG);
+        const bool valid = cand && (p2 <= 0.f) && (alpha >= ALPHA_MIN);
+        // An entry this pixel skips is carried through the recursions as alpha = 0, which leaves T, the
+        // running colour term and every sum bit-for-bit unchanged (x*1, x+0, 0*x are exact): one select
+        // here instead of one per state variable.
+        const float ae = valid ? alpha : 0.f;
+        const float inv1m = __builtin_amdgcn_rcpf(1.f - ae);
+        T[k] *= inv1m;
+        const float w = ae * T[k];
+        dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
+        if (OBJ) {
+#pragma unroll
+          for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = fmaf(w, gO[k][c], dobj[c]);
+        }
+        if (GEOM) {
+          float cg = fmaf(e1.z, g0[k], fmaf(e1.w, g1[k], e2.x * g2[k]));
+          if (OBJ) {
+#pragma unroll
+            for (int c = 0; c < NUM_OBJ; ++c) cg = fmaf(so[j][c], gO[k][c], cg);
+          }
+          const float dcg = cg - Acc[k];
+          const float dLda = valid ? T[k] * dcg : 0.f;
+          Acc[k] = fmaf(ae, dcg, Acc[k]);                  // ae*cg + (1-ae)*Acc: now includes this entry
+          dop = fmaf(G, dLda, dop);
+          const float q = oG * dLda;
+          const float qy = q * dy;
+          sq += q; sqy += qy; sqyy = fmaf(qy, dy, sqyy);
+        }
+      };
+      // A strip is entered only if the entry's mask has it, and evaluated only if some pixel of it is a candidate.
+      // (Measured alternatives, both slower on S-nyc-1M: evaluating every strip of the mask without the ballot branch
+      // 0.330 -> 0.347 ms, evaluating strips in straight-line pairs for two interleaved dependency chains -> 0.398 ms.
+      // The kernel is bound by the NUMBER of vector instructions, not by their latency.)
 #pragma unroll
       for (int k = 0; k < NPX; ++k) {
         if (m & (1u << k)) {
@@ -874,36 +899,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
           const bool cand = (p2 >= e2.y) && (pos <= ncon[k]);
           if (__ballot(cand) != 0ull) {
             hit = true;
-            const float G = __builtin_amdgcn_exp2f(p2);
-            const float oG = e1.y * G;
-            const float alpha = fminf(ALPHA_CAP, oG);
-            const bool valid = cand && (p2 <= 0.f) && (alpha >= ALPHA_MIN);
-            // An entry this pixel skips is carried through the recursions as alpha = 0, which leaves T, the
-            // running colour term and every sum bit-for-bit unchanged (x*1, x+0, 0*x are exact): one select
-            // here instead of one per state variable.
-            const float ae = valid ? alpha : 0.f;
-            const float inv1m = __builtin_amdgcn_rcpf(1.f - ae);
-            T[k] *= inv1m;
-            const float w = ae * T[k];
-            dr = fmaf(w, g0[k], dr); dg = fmaf(w, g1[k], dg); db = fmaf(w, g2[k], db);
-            if (OBJ) {
-#pragma unroll
-              for (int c = 0; c < NUM_OBJ; ++c) dobj[c] = fmaf(w, gO[k][c], dobj[c]);
-            }
-            if (GEOM) {
-              float cg = fmaf(e1.z, g0[k], fmaf(e1.w, g1[k], e2.x * g2[k]));
-              if (OBJ) {
-#pragma unroll
-                for (int c = 0; c < NUM_OBJ; ++c) cg = fmaf(so[j][c], gO[k][c], cg);
-              }
-              const float dcg = cg - Acc[k];
-              const float dLda = valid ? T[k] * dcg : 0.f;
-              Acc[k] = fmaf(ae, dcg, Acc[k]);                  // ae*cg + (1-ae)*Acc: now includes this entry
-              dop = fmaf(G, dLda, dop);
-              const float q = oG * dLda;
-              const float qy = q * dy;
-              sq += q; sqy += qy; sqyy = fmaf(qy, dy, sqyy);
-            }
+            strip(k, dy, p2, cand);
           }
         }
       }

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace gsr {
 
@@ -131,12 +132,17 @@ inline void scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, ui
 // ---- stable LSD radix sort pass over (key,val) pairs ------------------------------------------------
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
-constexpr int RS_ROUNDS = 16;                       // 64-element rounds per wave
-constexpr int RS_CHUNK = RS_WAVES * RS_ROUNDS * 64; // 4096 elements per block
+// 64-element rounds per wave: 16 (4096 elements per block: long digit runs, the choice for tens of millions of keys) or
+// 8 (2048 per block: twice the blocks -- a 1 M-key pass is latency-bound and 245 blocks do not even cover the 256 CUs)
+constexpr int RS_ROUNDS_MAX = 16;
+constexpr int RS_ROUNDS_MIN = 8;
 constexpr int RS_BINS = 256;
+constexpr int rs_chunk(int rounds) { return RS_WAVES * rounds * 64; }
 
+template <int RS_ROUNDS>
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                            uint32_t mask, uint32_t* __restrict__ table, uint32_t nb) {
+  constexpr int RS_CHUNK = rs_chunk(RS_ROUNDS);
   __shared__ uint32_t h[RS_BINS];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -171,6 +177,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restri
 
 // table: per-digit exclusive-scanned rows [256][nb] + rowsum[256] (k_radix_rowscan).  iota != 0: values are the
 // element indices (first pass of an argsort).
+template <int RS_ROUNDS>
 __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out,
@@ -178,6 +185,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
                                                               uint32_t mask, const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ rowsum, uint32_t nb,
                                                               int iota) {
+  constexpr int RS_CHUNK = rs_chunk(RS_ROUNDS);
   __shared__ uint32_t wcnt[RS_WAVES][RS_BINS];
   __shared__ uint32_t gbase[RS_BINS];
   __shared__ uint32_t tmp[4];
@@ -249,7 +257,13 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
   }
 }
 
-inline uint32_t radix_table_words(uint32_t n) { return RS_BINS * ((n + RS_CHUNK - 1) / RS_CHUNK); }
+inline uint32_t radix_table_words(uint32_t n) { return RS_BINS * ((n + rs_chunk(RS_ROUNDS_MIN) - 1) / rs_chunk(RS_ROUNDS_MIN)); }
+
+inline int radix_rounds_for(uint32_t n) {
+  static const int env = [] { const char* e = getenv("GSR_RS_ROUNDS"); int v = e ? atoi(e) : 0; return (v == 8 || v == 16) ? v : 0; }();
+  if (env) return env;
+  return n <= (8u << 20) ? RS_ROUNDS_MIN : RS_ROUNDS_MAX;
+}
 
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong; returns 0 if the result is in (k0,v0), 1 if in
 // (k1,v1).  iota_first: the values of the first pass are the element indices (v0 is then never read).
@@ -259,7 +273,9 @@ inline int radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* 
   if (n == 0 || end_bit <= begin_bit) return 0;
   const int bits = end_bit - begin_bit;
   const int passes = (bits + 7) / 8;
-  const uint32_t nb = (n + RS_CHUNK - 1) / RS_CHUNK;
+  const int rounds = radix_rounds_for(n);
+  const uint32_t chunk = (uint32_t)rs_chunk(rounds);
+  const uint32_t nb = (n + chunk - 1) / chunk;
   int cur = 0, bit = begin_bit;
   for (int p = 0; p < passes; ++p) {
     // spread the bits evenly over the passes (13 bits -> 7 + 6): longer digit runs per block
@@ -267,10 +283,18 @@ inline int radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* 
     const uint32_t mask = (1u << w) - 1u;
     uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
     uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
-    hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(RS_THREADS), 0, st, ki, n, bit, mask, table, nb);
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_BINS), dim3(RS_THREADS), 0, st, table, nb, sums);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask, table, sums,
-                       nb, (iota_first && p == 0) ? 1 : 0);
+    const int iota = (iota_first && p == 0) ? 1 : 0;
+    if (rounds == RS_ROUNDS_MIN) {
+      hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MIN>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, bit, mask, table, nb);
+      hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_BINS), dim3(RS_THREADS), 0, st, table, nb, sums);
+      hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MIN>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
+                         table, sums, nb, iota);
+    } else {
+      hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MAX>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, bit, mask, table, nb);
+      hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_BINS), dim3(RS_THREADS), 0, st, table, nb, sums);
+      hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MAX>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, bit, mask,
+                         table, sums, nb, iota);
+    }
     cur ^= 1;
     bit += w;
   }

@@ -10,6 +10,8 @@ OUT=$R/gpurun_out/r02
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+# the same with ONE stream: kernel durations without other views' kernels beside them
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $BENCH --streams 1 > $OUT/bench_stats1.json 2> $OUT/bench_stats1.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- $BENCH > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- $BENCH > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/sq -o q -- $BENCH > /dev/null 2> $OUT/sq.err
@@ -41,5 +43,6 @@ json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline 
 print(json.dumps({k: v["hbm_bytes_fetch_x2"] / 1e6 for k, v in res.items()}, indent=1))
 PY
 cp $OUT/stats/s_kernel_stats.csv $R/gpurun_out/r02_kernel_stats.csv
+cp $OUT/stats1/s_kernel_stats.csv $R/gpurun_out/r02_kernel_stats_1stream.csv
 cp $OUT/pmc_traffic.json $R/gpurun_out/r02_pmc_traffic.json
 cp $OUT/bench_stats.json $R/gpurun_out/r02_bench_under_rocprof.json

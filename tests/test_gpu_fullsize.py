@@ -81,7 +81,10 @@ def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
     img = render(cam, model, PipelineParams(skip_objects=True), torch.zeros(3, device=dev))["render"]
     ranges = D.export_state(img, "ranges").view(-1, 2).long()
     pairs = D.export_state(img, "pair_rank").long()
-    ranks = pairs & ((1 << 28) - 1)
+    order0 = D.export_state(img, "order").long()
+    inv = torch.empty_like(order0)
+    inv[order0] = torch.arange(order0.numel(), device=dev)
+    ranks = inv[pairs & ((1 << 28) - 1)]                 # a pair's value is its Gaussian; its depth rank through `order`
     assert int((pairs >> 28).max()) <= 15
     lens = ranges[:, 1] - ranges[:, 0]
     assert int(lens.min()) >= 0 and int(lens.sum()) <= pairs.numel()

@@ -203,9 +203,9 @@ def test_cfg2_hydrant_full_800px_sh_gradients_vs_windowed_oracle():
     ro, rgrads, gc, _ = oracle_raw("hydrant-full", 0, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), color_only=True)
     assert set(grads) == {"f_dc", "f_rest"}
-    compare(out, grads, ro, rgrads, m, names=("f_dc", "f_rest"))
+    compare(out, grads, ro, rgrads, m, names=("f_dc", "f_rest"), frag_frac=0.25)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev))
-    compare(out, grads, ro, rgrads, m)
+    compare(out, grads, ro, rgrads, m, frag_frac=0.25)
 
 
 def test_cfg5_airport_4k_full_backward_vs_windowed_oracle():
