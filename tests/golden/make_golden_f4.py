@@ -96,6 +96,43 @@ def main():
     out["res_cases"] = np.array(cases, dtype=np.float64)
     out["res_out"] = np.array(res, dtype=np.int64)
 
+    # scene/gaussian_model.py:377-411: the PLY property order and the arrays save_ply hands to plyfile (plyfile itself is
+    # absent; a recorder stands in for it and keeps the structured array the reference built)
+    import torch
+    import scene.gaussian_model as gm
+    captured = {}
+
+    class _El:
+        @staticmethod
+        def describe(arr, name):
+            captured["elements"], captured["name"] = arr.copy(), name
+            return arr
+
+    class _Pd:
+        def __init__(self, els):
+            pass
+
+        def write(self, path):
+            captured["path"] = path
+    gm.PlyElement, gm.PlyData = _El, _Pd
+    gm.mkdir_p = lambda p: None
+    m = gm.GaussianModel(3)
+    gen = torch.Generator().manual_seed(11)
+    P = 9
+    m._xyz = torch.randn(P, 3, generator=gen)
+    m._features_dc = torch.randn(P, 1, 3, generator=gen)
+    m._features_rest = torch.randn(P, 15, 3, generator=gen)
+    m._opacity = torch.randn(P, 1, generator=gen)
+    m._scaling = torch.randn(P, 3, generator=gen)
+    m._rotation = torch.randn(P, 4, generator=gen)
+    m._objects_dc = torch.randn(P, 1, 16, generator=gen)
+    out["ply_attribute_names"] = np.array(m.construct_list_of_attributes())
+    m.save_ply("/tmp/unused/point_cloud.ply")
+    out["ply_elements_bytes"] = np.frombuffer(captured["elements"].tobytes(), dtype=np.uint8)
+    out["ply_elements_descr"] = np.array([f"{n}:{t}" for n, t in captured["elements"].dtype.descr])
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_objects_dc"):
+        out["ply_in" + n] = getattr(m, n).numpy()
+
     _stub("gaussian_renderer", render=None, GaussianModel=object)
     _stub("scene", Scene=object)
     _stub("scene.gaussian_model", GaussianModel=object)   # not needed by the captured functions

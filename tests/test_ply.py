@@ -126,3 +126,23 @@ def test_create_from_pcd_initialisation():
     d2.sort(axis=1)
     want = np.log(np.sqrt(np.maximum(d2[:, 1:4].mean(axis=1), 1e-7)))
     assert np.allclose(m._scaling.detach().numpy(), np.repeat(want[:, None], 3, 1), atol=1e-4)
+
+
+def test_written_file_body_equals_the_reference_save_ply_elements(tmp_path):
+    """The vertex element of a file written here, byte for byte, against the structured array the reference's own
+    save_ply builds for the same tensors (scene/gaussian_model.py:393-411; captured by tests/golden/make_golden_f4.py with
+    a recorder in place of the absent plyfile, whose binary_little_endian writer emits exactly that array after the
+    header), plus the property order of construct_list_of_attributes (:377-391)."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_f4.npz"))
+    t = {n: torch.from_numpy(ref["ply_in" + n]) for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling",
+                                                          "_rotation", "_objects_dc")}
+    m = GaussianModel.from_tensors(t["_xyz"], t["_features_dc"], t["_features_rest"], t["_scaling"], t["_rotation"],
+                                   t["_opacity"], t["_objects_dc"])
+    path = str(tmp_path / "p.ply")
+    m.save_ply(path)
+    head, body = open(path, "rb").read().split(b"end_header\n", 1)
+    names = [l.split()[2] for l in head.decode().strip().split("\n")[3:]]
+    assert names == [str(n) for n in ref["ply_attribute_names"]] == ply.gaussian_attribute_names()
+    assert [d.split(":")[1] for d in ref["ply_elements_descr"]] == ["<f4"] * len(names)
+    assert body == ref["ply_elements_bytes"].tobytes()
