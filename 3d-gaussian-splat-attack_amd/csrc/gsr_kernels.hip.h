@@ -652,15 +652,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // atomics, bitwise reproducible.  Row = (Sq dx, Sq dy, Sq dx^2, Sq dx dy, Sq dy^2, S G dL/dalpha,
 // S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha.
 // The 64-lane sums are not butterflies (a DPP add issues at half the rate of a plain one and nine values
-// need 9 x 6 of them): one v_permlane32_swap step folds the nine per-lane values into five registers,
-// those are parked in LDS (ds_write does not occupy the VALU), and every RED_B contributing entries the
-// wave sums them TRANSPOSED: lane L adds the 16 floats of chunk L with plain v_add (4 ds_read_b128), one
-// DPP add joins the two chunks of a value, and the lanes store their row words directly.
+// need 9 x 6 of them): the per-lane values are parked in LDS as they are (ds_write does not occupy the VALU;
+// only dg and db are folded into one register so that an entry is 32 chunks), and every second contributing
+// entry the wave sums them TRANSPOSED: lane L adds the 16 floats of chunk L with plain v_add (4 ds_read_b128), two
+// DPP adds join the four chunks of a value, and the lanes store their row words directly.
 // ------------------------------------------------------------------------------------------------
-constexpr int RED_B = 3;          // contributing entries parked between two transposed sums (3 x 20 chunks = 60 lanes)
 constexpr int RED_ROW = 20;       // a 16-float chunk padded to 5 float4: ds_read_b128 at an odd float4 stride is conflict free
-constexpr int RED_REG = 4 * RED_ROW;      // one register: four 16-lane rows
-constexpr int RED_ENTRY = 5 * RED_REG;    // five registers per entry
+constexpr int RED_REG = 4 * RED_ROW;      // one parked register: four 16-lane chunks
 struct RenderBwdArgs {
   const uint2* ranges;
   const uint32_t* pair_rank;
@@ -700,10 +698,14 @@ constexpr int PART_F4 = 3;
 template <bool OBJ, int NPX, bool GEOM>
 __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   constexpr int NSUB = PXL / NPX;
-  constexpr int NREG = GEOM ? 5 : 2;              // registers parked per contributing entry
-  constexpr int RB = GEOM ? RED_B : 8;            // entries between two transposed sums (RB * 4 * NREG <= 64 lanes)
+  // Registers parked per contributing entry: the per-lane sums as they are, except that the LAST one holds two values
+  // (dg in lanes < 32, db in lanes >= 32, folded by one v_permlane32_swap + add): 8 registers for the nine sums,
+  // 2 for the three colour sums.  (v_permlane32_swap issues at 8.5 cycles per wave on gfx950 against 2.8 for a plain
+  // add -- tests/ubench/valu_rate.hip -- so only the one fold that makes the chunk count a power of two is kept;
+  // folding all nine values into five registers cost five of them per entry.)
+  constexpr int NREG = GEOM ? 8 : 2;
+  constexpr int RB = 64 / (4 * NREG);             // entries between two transposed sums: 2, or 8 (4 * NREG chunks each)
   constexpr int RENTRY = NREG * RED_REG;
-  constexpr int TAGV = GEOM ? 9 : 3;              // the unused last value: its two lanes stamp the tag words
   __shared__ float4 s0[64];
   __shared__ float4 s1[64];
   __shared__ float2 s2[64];
@@ -749,11 +751,15 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   if (clocked && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
   const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
-  const int red_e = lane / (4 * NREG), red_v = 2 * ((lane % (4 * NREG)) >> 2) + ((lane & 3) >> 1), red_sub = lane & 1;
-  // row word this lane stores (the unused last value's two lanes stamp the tag words 9 and 10; without the geometry
-  // sums the three colour sums still go to their usual words 6..8)
-  const int red_word = red_v == TAGV ? 9 + red_sub : (red_sub == 0 ? red_v + (GEOM ? 0 : 6) : -1);
-  const float red_tag = __uint_as_float(red_sub ? a.tag_hi : a.tag_lo);
+  // transposed-sum roles: lane = (entry e, register rr, chunk ch); row word this lane stores: chunk 0 of register rr
+  // stores value rr (the colour sums keep their words 6..8 without the geometry sums), the folded last register
+  // stores dg from chunk 0 and db from chunk 2, chunks 1 and 3 of register 0 stamp the tag words 9 and 10
+  const int red_e = lane / (4 * NREG), red_rr = (lane % (4 * NREG)) >> 2, red_ch = lane & 3;
+  const bool red_last = red_rr == NREG - 1;
+  const int red_word = red_last ? (red_ch == 0 ? 7 : (red_ch == 2 ? 8 : -1))
+                                : (red_ch == 0 ? red_rr + (GEOM ? 0 : 6)
+                                               : (red_rr == 0 && red_ch == 1 ? 9 : (red_rr == 0 && red_ch == 3 ? 10 : -1)));
+  const float red_tag = __uint_as_float(red_word == 10 ? a.tag_hi : a.tag_lo);
   int red_j = 0;       // lane b: batch index j of the b-th parked entry
   int red_n = 0;       // parked entries (wave uniform)
   const int x = tx * TILE + (lane & 15);
@@ -904,32 +910,27 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
         }
       }
       if (hit) {
-        // nine per-lane sums -> five registers (lanes < 32: value 2n, lanes >= 32: value 2n+1), parked in LDS
-        float a3 = dr, b3 = dg;                          // values 6,7  (colour only: values 0,1)
-        float a4 = db, b4 = 0.f;                         // values 8,9  (colour only: values 2,3)
+        // the per-lane sums are parked in LDS (ds_write does not occupy the VALU); dg and db share one register:
+        // v_permlane32_swap exchanges the upper half of one register with the lower half of another, adding the two
+        // afterwards leaves dg (summed over lanes l, l+32) in lanes < 32 and db in lanes >= 32.  (The clang builtin
+        // returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the VALU-write ->
+        // permlane-read wait states, which hipcc does not insert around asm.)
+        float fa = dg, fb = db;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(fa), "+v"(fb));
         float* w = &sred[red_n * RENTRY + red_wofs];
         if (GEOM) {
-        float a0 = sq * dx, b0 = sqy;                    // values 0,1 : S q dx    | S q dy
-        float a1 = a0 * dx, b1 = sqy * dx;               // values 2,3 : S q dx^2  | S q dx dy
-        float a2 = sqyy, b2 = dop;                       // values 4,5 : S q dy^2  | S G dL/dalpha
-        // v_permlane32_swap exchanges the upper half of one register with the lower half of another: adding the
-        // two afterwards leaves value a (summed over lanes l, l+32) in lanes < 32 and value b in lanes >= 32.  (The
-        // clang builtin returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the
-        // VALU-write -> permlane-read wait states, which hipcc does not insert around asm.)
-        asm volatile("s_nop 1\n\t"
-                     "v_permlane32_swap_b32 %0, %5\n\t"
-                     "v_permlane32_swap_b32 %1, %6\n\t"
-                     "v_permlane32_swap_b32 %2, %7\n\t"
-                     "v_permlane32_swap_b32 %3, %8\n\t"
-                     "v_permlane32_swap_b32 %4, %9"
-                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4));
-        w[0] = a0 + b0; w[RED_REG] = a1 + b1; w[2 * RED_REG] = a2 + b2; w[3 * RED_REG] = a3 + b3; w[4 * RED_REG] = a4 + b4;
+          const float a0 = sq * dx;
+          w[0] = a0;                                     // value 0: S q dx
+          w[RED_REG] = sqy;                              // value 1: S q dy
+          w[2 * RED_REG] = a0 * dx;                      // value 2: S q dx^2
+          w[3 * RED_REG] = sqy * dx;                     // value 3: S q dx dy
+          w[4 * RED_REG] = sqyy;                         // value 4: S q dy^2
+          w[5 * RED_REG] = dop;                          // value 5: S G dL/dalpha
+          w[6 * RED_REG] = dr;                           // value 6
+          w[7 * RED_REG] = fa + fb;                      // values 7 | 8
         } else {
-          asm volatile("s_nop 1\n\t"
-                       "v_permlane32_swap_b32 %0, %2\n\t"
-                       "v_permlane32_swap_b32 %1, %3"
-                       : "+v"(a3), "+v"(a4), "+v"(b3), "+v"(b4));
-          w[0] = a3 + b3; w[RED_REG] = a4 + b4;
+          w[0] = dr;
+          w[RED_REG] = fa + fb;
         }
         red_j = lane == red_n ? j : red_j;
         ++red_n;
@@ -956,12 +957,13 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
           const float4 q0 = ch[0], q1 = ch[1], q2 = ch[2], q3 = ch[3];
           float t = (((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w))) +
                     (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
-          t += dpp_mov<0xB1, 0xF>(t);                    // lanes 2m, 2m+1 hold the two chunks of one value
+          t += dpp_mov<0xB1, 0xF>(t);                    // chunks 0+1 and 2+3 of a register
+          const float t4 = t + dpp_mov<0x4E, 0xF>(t);    // all four chunks: the value of an unfolded register
           if (red_word >= 0) {
             float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[jm] * PART_F4);
             // words 9 and 10 carry this backward call's 64-bit tag: rows that no wave writes keep whatever the
             // workspace held and are recognised as stale by K8/K9, so the partial-row buffer is never cleared
-            row[red_word] = red_v == TAGV ? red_tag : t;
+            row[red_word] = red_word >= 9 ? red_tag : (red_last ? t : t4);
           }
         }
         red_n = 0;

@@ -22,6 +22,16 @@ __global__ void __launch_bounds__(64) k(float* out, int iters, float s) {
         if (MODE == 2) { if (i == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i])); else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(s)); }
         if (MODE == 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
         if (MODE == 4) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+        if (MODE == 5) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(s) : "vcc");
+        if (MODE == 6) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(s) : "vcc");
+        if (MODE == 7) asm volatile("v_cmp_ge_f32 s[20:21], %0, %1" : : "v"(a[i]), "v"(s) : "s20", "s21");
+        if (MODE == 8) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 9) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 10) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+        if (MODE == 11) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+        if (MODE == 12) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 13) asm volatile("v_cmp_le_u32 s[20:21], %0, %1\n\ts_and_b64 s[22:23], s[20:21], vcc" : : "v"(a[i]), "v"(s) : "s20", "s21", "s22", "s23");
+        if (MODE == 14) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
       }
     }
   }
@@ -53,12 +63,22 @@ void run(const char* name, int wps) {
 }
 
 int main() {
-  for (int wps : {1, 2, 4, 8}) {
+  for (int wps : {1, 5, 8}) {
     run<0>("v_fma_f32", wps);
     run<1>("v_pk_fma_f32", wps);
     run<2>("1 v_exp + 7 v_fma", wps);
     run<3>("v_add_f32", wps);
     run<4>("v_add_f32_dpp", wps);
+    run<5>("v_cmp(vcc)+v_cndmask pair", wps);
+    run<6>("v_cndmask_b32", wps);
+    run<7>("v_cmp_ge_f32 -> sgpr", wps);
+    run<8>("v_min_f32", wps);
+    run<9>("v_mul_f32", wps);
+    run<10>("v_rcp_f32", wps);
+    run<11>("v_exp_f32", wps);
+    run<12>("v_sub_u32", wps);
+    run<13>("v_cmp->sgpr + s_and", wps);
+    run<14>("v_permlane32_swap", wps);
   }
   return 0;
 }
