@@ -253,15 +253,7 @@ __global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, 
       const float4 a = R0[REC * g], b = R1[REC * g];
       const float x0 = (float)(tx * TILE);
       const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
-      mask = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float y0 = (float)(ty * TILE + 4 * k);
-        if (y0 <= (float)(H - 1)) {
-          const float y1 = fminf(y0 + 3.0f, (float)(H - 1));
-          if (tile_can_contribute(a.x, a.y, a.z, a.w, b.x, b.y, x0, y0, x1, y1)) mask |= 1u << k;
-        }
-      }
+      mask = strip_masks4(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, (float)(ty * TILE), (float)(H - 1));
       if (mask == 0) key = ntiles;
     }
     pair_tile[e] = key;

@@ -404,6 +404,44 @@ GSR_HD bool tile_can_contribute(float cx, float cy, float A, float B, float C, f
   return qmin <= bound;
 }
 
+// The same test for the four 16x4 strips of a tile at once (strip k = pixel rows y0 + 4k .. y0 + 4k + 3, clipped to
+// the image height): bit k of the result is set when strip k can be reached.  What is shared between the strips --
+// the threshold, the two column offsets, the two reciprocals that place the minimum on an edge -- is computed once
+// (k_emit calls this per (tile, Gaussian) pair: four independent calls cost four logf and sixteen divisions).
+GSR_HD uint32_t strip_masks4(float cx, float cy, float A, float B, float C, float o, float x0, float x1, float y0,
+                             float ymax) {
+  if (!(A > 0.f) || !(C > 0.f)) {                       // not a proper conic: leave the pair alone
+    uint32_t m = 0;
+    for (int k = 0; k < 4; ++k) if (y0 + 4.f * (float)k <= ymax) m |= 1u << k;
+    return m;
+  }
+  const float tau = 2.0f * logf(255.0f * o);
+  const float bound = tau + 1e-4f * fabsf(tau) + 1e-3f;
+  if (!(bound >= 0.f)) return 0u;
+  const float dxl = x0 - cx, dxh = x1 - cx;
+  const bool inx = dxl <= 0.f && dxh >= 0.f;
+  const float invC = 1.0f / C, invA = 1.0f / A;
+  const float tyl = -B * dxl * invC, tyh = -B * dxh * invC;     // unconstrained minimiser of Q along the two columns
+  const float qxl = A * dxl * dxl, qxh = A * dxh * dxh;
+  uint32_t mask = 0;
+  for (int k = 0; k < 4; ++k) {
+    const float ya = y0 + 4.f * (float)k;
+    if (!(ya <= ymax)) break;
+    const float yb = fminf(ya + 3.0f, ymax);
+    const float dyl = ya - cy, dyh = yb - cy;
+    bool hit = inx && dyl <= 0.f && dyh >= 0.f;
+    if (!hit) {
+      const float d0 = gsr_clampf(tyl, dyl, dyh), d1 = gsr_clampf(tyh, dyl, dyh);
+      float qmin = fminf(qxl + (2.f * B * dxl + C * d0) * d0, qxh + (2.f * B * dxh + C * d1) * d1);
+      const float e0 = gsr_clampf(-B * dyl * invA, dxl, dxh), e1 = gsr_clampf(-B * dyh * invA, dxl, dxh);
+      qmin = fminf(qmin, fminf((A * e0 + 2.f * B * dyl) * e0 + C * dyl * dyl, (A * e1 + 2.f * B * dyh) * e1 + C * dyh * dyh));
+      hit = qmin <= bound;
+    }
+    if (hit) mask |= 1u << k;
+  }
+  return mask;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-(pixel, Gaussian) blend weight (K6 inner step).  Returns false when the entry is skipped.
 // ---------------------------------------------------------------------------------------------

@@ -70,4 +70,12 @@ void hm_tile_can_contribute(int n, const float* geo, float x0, float y0, float x
   }
 }
 
+// geo [n,6] as above; out[n] = strip_masks4 of the tile whose first pixel centre is (x0, y0), image height ymax + 1
+void hm_strip_masks4(int n, const float* geo, float x0, float x1, float y0, float ymax, int* out) {
+  for (int i = 0; i < n; ++i) {
+    const float* g = geo + 6 * i;
+    out[i] = (int)strip_masks4(g[0], g[1], g[2], g[3], g[4], g[5], x0, x1, y0, ymax);
+  }
+}
+
 }  // extern "C"

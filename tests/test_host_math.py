@@ -151,3 +151,47 @@ def test_tile_footprint_test_is_conservative(lib):
     kept_useless = (~touches & (out == 1)).sum()
     assert kept_useless < 0.35 * (~touches).sum()        # the test is tight, not just safe
     assert 0.1 < touches.mean() < 0.9
+
+
+def test_strip_masks_are_conservative_and_tight(lib):
+    """strip_masks4 (what k_emit stores in a pair's top bits, and K6 / K7 skip strips on WITHOUT re-checking) must have
+    the bit of every 16x4 strip in which some pixel passes the reference's alpha test, for whole and clipped tiles, and
+    must agree with four tile_can_contribute calls on all but a sliver of cases."""
+    rng = np.random.default_rng(1)
+    n = 6000
+    th = rng.uniform(0, math.pi, n)
+    s1, s2 = np.exp(rng.uniform(-1.5, 2.5, n)), np.exp(rng.uniform(-1.5, 2.5, n))
+    c, s = np.cos(th), np.sin(th)
+    a = (c * c) * s1 * s1 + (s * s) * s2 * s2 + 0.3
+    b = c * s * (s1 * s1 - s2 * s2)
+    cc = (s * s) * s1 * s1 + (c * c) * s2 * s2 + 0.3
+    det = a * cc - b * b
+    A, B, C = cc / det, -b / det, a / det
+    cx, cy = rng.uniform(-24, 40, n), rng.uniform(-24, 40, n)
+    o = np.concatenate([rng.uniform(0, 1, n // 2), rng.uniform(0, 0.02, n - n // 2)])
+    geo = np.ascontiguousarray(np.stack([cx, cy, A, B, C, o], 1).astype(np.float32))
+    g64 = geo.astype(np.float64)
+    lib.hm_strip_masks4.argtypes = [ctypes.c_int, ctypes.c_void_p] + [ctypes.c_float] * 4 + [ctypes.c_void_p]
+    for ymax, x1 in ((15.0, 15.0), (9.0, 15.0), (15.0, 6.0), (2.0, 11.0)):      # whole tile, clipped below / right
+        out = np.zeros(n, np.int32)
+        lib.hm_strip_masks4(n, ptr(geo), cf(0.0), cf(x1), cf(0.0), cf(ymax), ptr(out))
+        xs, ys = np.meshgrid(np.arange(x1 + 1), np.arange(ymax + 1))
+        dx = g64[:, 0, None, None] - xs[None]
+        dy = g64[:, 1, None, None] - ys[None]
+        power = -0.5 * (g64[:, 2, None, None] * dx * dx + g64[:, 4, None, None] * dy * dy) - g64[:, 3, None, None] * dx * dy
+        alpha = np.minimum(0.99, g64[:, 5, None, None] * np.exp(np.minimum(power, 0)))
+        ok = (power <= 0) & (alpha >= 1.0 / 255.0)
+        same = 0
+        for k in range(4):
+            rows = slice(4 * k, min(4 * k + 4, int(ymax) + 1))
+            if 4 * k > ymax:
+                assert not ((out >> k) & 1).any(), "a strip outside the image was marked"
+                continue
+            touches = ok[:, rows, :].any(axis=(1, 2))
+            bit = ((out >> k) & 1).astype(bool)
+            assert not (touches & ~bit).any(), f"strip {k}: a contributing strip was dropped (ymax {ymax}, x1 {x1})"
+            ref = np.zeros(n, np.int32)
+            lib.hm_tile_can_contribute(n, ptr(geo), cf(0.0), cf(4.0 * k), cf(x1), cf(min(4.0 * k + 3.0, ymax)), ptr(ref))
+            same += int((ref.astype(bool) == bit).sum())
+            assert (~touches & bit).sum() < 0.35 * max((~touches).sum(), 1)
+        assert same >= 0.999 * n * (int(ymax) // 4 + 1)
