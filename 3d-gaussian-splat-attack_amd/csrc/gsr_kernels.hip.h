@@ -347,7 +347,13 @@ __device__ __forceinline__ int item_of_block(int b, int nitems, int mode) {
 // lists issue ahead of their SIMD's other waves.  Results do not depend on the schedule.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCHED_BINS = 1024;
+constexpr int SCHED_LDS_TILES = 12288;               // 48 KB of list lengths (1080p has 8160 tiles)
 constexpr uint32_t SCHED_TILE_MASK = (1u << 28) - 1u;
+__device__ __forceinline__ uint32_t wave_max_u32_fwd(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+  return v;
+}
 // seg_shift = 0: no tile is split.  rec_cap: capacity of the boundary-record buffer (a tile whose records would not
 // fit stays unsplit); nrec_out receives the number of records in use.
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2* __restrict__ ranges,
@@ -357,7 +363,16 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
+  // the tiles' list lengths are read from HBM once and kept in LDS for the three passes below (up to SCHED_LDS_TILES
+  // tiles; beyond that -- 4K images -- the later passes read `ranges` again)
+  __shared__ uint32_t slen[SCHED_LDS_TILES];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool in_lds = ntiles <= SCHED_LDS_TILES;
+  auto tile_len = [&](int i) -> uint32_t {
+    if (in_lds) return slen[i];
+    const uint2 r = ranges[i];
+    return r.y - r.x;
+  };
   hist[t] = 0;
   if (t == 0) smax = 0;
   __syncthreads();
@@ -365,10 +380,12 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
   for (int i = t; i < ntiles; i += 1024) {
     const uint2 r = ranges[i];
     const uint32_t len = r.y - r.x;
+    if (in_lds) slen[i] = len;
     atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
     mymax = max(mymax, len);
   }
-  atomicMax(&smax, mymax);
+  mymax = wave_max_u32_fwd(mymax);
+  if (lane == 0) atomicMax(&smax, mymax);
   __syncthreads();
   // exclusive scan over the bins in DESCENDING length order: thread t owns bin 1023 - t
   const uint32_t v = hist[SCHED_BINS - 1 - t];
@@ -385,12 +402,11 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
   __syncthreads();
   hist[SCHED_BINS - 1 - t] = base + inc - v;      // becomes the bin's cursor
   __syncthreads();
-  const uint32_t longest = smax + 1u;
+  const float prio_scale = 4.0f / (float)(smax + 1u);
   for (int i = t; i < ntiles; i += 1024) {
-    const uint2 r = ranges[i];
-    const uint32_t len = r.y - r.x;
+    const uint32_t len = tile_len(i);
     const uint32_t p = atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
-    const uint32_t prio = (uint32_t)(((uint64_t)len * 4u) / longest);      // 0..3
+    const uint32_t prio = min(3u, (uint32_t)((float)len * prio_scale));    // 0..3: length relative to the longest list
     sched[p] = (uint32_t)i | (prio << 28);
   }
   // ---- boundary records of the split tiles: exclusive scan of nseg over the tiles, in tile order ------------------
@@ -402,8 +418,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
     const int i = i0 + t;
     uint32_t nseg = 0;
     if (i < ntiles && seg_shift != 0u) {
-      const uint2 r = ranges[i];
-      const uint32_t len = r.y - r.x;
+      const uint32_t len = tile_len(i);
       if (len > seg_len) nseg = (len + seg_len - 1u) >> seg_shift;
     }
     uint32_t inc2 = nseg;

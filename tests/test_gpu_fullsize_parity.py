@@ -55,13 +55,13 @@ def window_mask(wins, H, W):
     return m
 
 
-def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, keys=None):
+def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, keys=None, scale=1.0):
     """oracle-R float64 on the CPU twin of the scene, autograd down to the RAW parameters through the getters.
     keys = (depth keys, radii) exported from the HIP forward: the oracle composites in the order of those float32 keys
     once they are within a few ulps of its own float64 depth (oracle_r.check_depth_keys)."""
     from gsplat_attack.scenes import make_scene
     ref, rcams, _ = make_scene(key, device="cpu", n_views=cam_i + 1, **(scale_kw or {}))
-    st = settings_for(rcams[cam_i], bg)
+    st = settings_for(rcams[cam_i], bg, 3, scale)
     depth_key = None
     if keys is not None:
         depth_key = keys[0]
@@ -79,7 +79,7 @@ def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, 
     return ro, grads, gc, go
 
 
-def hip_raw(model, cam, bg, gc, flags=0, fused=True, objects=False, go=None, color_only=False):
+def hip_raw(model, cam, bg, gc, flags=0, fused=True, objects=False, go=None, color_only=False, scale=1.0):
     from gsplat_attack.renderer import PipelineParams, render
     D = _hip()
     model.zero_grad()
@@ -93,7 +93,7 @@ def hip_raw(model, cam, bg, gc, flags=0, fused=True, objects=False, go=None, col
     try:
         D.set_flags(flags)
         out = render(cam, model, PipelineParams(fused_activations=fused, skip_objects=not objects,
-                                                viewspace_grad=not color_only), bg)
+                                                viewspace_grad=not color_only), bg, scale)
         loss = (out["render"] * gc).sum()
         if go is not None:
             loss = loss + (out["render_object"] * go).sum()
@@ -139,11 +139,11 @@ def _scene_on_gpu(key, n_views):
     return dev, model, cams
 
 
-def _windows_for(D, model, cam, bg):
+def _windows_for(D, model, cam, bg, scale=1.0):
     from gsplat_attack.renderer import PipelineParams, render
     H, W = cam.image_height, cam.image_width
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    out = render(cam, model, PipelineParams(skip_objects=True), bg)
+    out = render(cam, model, PipelineParams(skip_objects=True), bg, scale)
     img = out["render"]
     ranges = D.export_state(img, "ranges").view(-1, 2).long()
     wins, longest = pick_windows(ranges, gx, gy)
@@ -173,6 +173,27 @@ def test_cfg3_nyc_1m_1080p_all_gradients_vs_windowed_oracle():
         out2, grads2 = hip_raw(model, cam, bg.to(dev), gc.to(dev), flags=flags)
         assert (out2["render"] - out["render"]).abs().max().item() <= 2e-6, flags
         compare(out2, grads2, ro, rgrads, m)
+
+
+def test_dense_10m_pairs_vs_windowed_oracle():
+    """The benchmark's second data point: S-nyc-1M with every splat scaled by 2.43 (scale_modifier, render()'s own
+    argument) so that a view emits ~10 M (tile, Gaussian) pairs -- lists of several thousand entries, many segments per
+    tile -- against the windowed oracle."""
+    D = _hip()
+    dev, model, cams = _scene_on_gpu("nyc-1M", 2)
+    cam = cams[1]
+    bg = torch.tensor([0.0, 0.1, 0.0])
+    scale = 2.43
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev), scale)
+    assert longest > 2000, longest
+    wins = wins[:3]                                                       # three 3x3 windows of ~4000-entry lists
+    m = window_mask(wins, 1080, 1920)
+    gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(31)) * m
+    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 1, bg, gc, wins, keys=keys, scale=scale)
+    assert ro.num_rendered > 20000
+    out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), scale=scale)
+    rep = compare(out, grads, ro, rgrads, m, frag_frac=0.25)
+    print("dense windows", wins, "longest list", longest, rep)
 
 
 def test_cfg3_classic_activated_surface_vs_windowed_oracle():
