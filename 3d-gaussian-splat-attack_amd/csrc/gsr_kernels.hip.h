@@ -660,7 +660,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha.
 // The 64-lane sums are not butterflies (a DPP add issues at half the rate of a plain one and nine values
 // need 9 x 6 of them): the per-lane values are parked in LDS as they are (ds_write does not occupy the VALU;
-// only dg and db are folded into one register so that an entry is 32 chunks), and every second contributing
+// only dg and db are folded into one register so that an entry is 32 chunks), and after every contributing
 // entry the wave sums them TRANSPOSED: lane L adds the 16 floats of chunk L with plain v_add (4 ds_read_b128), two
 // DPP adds join the four chunks of a value, and the lanes store their row words directly.
 // ------------------------------------------------------------------------------------------------
@@ -702,8 +702,12 @@ constexpr int PART_F4 = 3;
 // GEOM = false: only dL/dcolour (and dL/dobject features) is wanted -- the colour attack, BASELINE configs 2 and 3.
 // The walk then keeps T and the blend weight only (no running colour term, no dL/dalpha, no conic / mean / opacity
 // sums): three sums per entry instead of nine, two parked registers instead of five, eight entries per transposed sum.
+// Six waves per SIMD for the one-wave-per-tile kernels without object channels: registers capped at 80 (8 bytes of
+// scratch per lane) and the parked-sum buffer kept to 2.5 KB, so that neither registers nor LDS (5.4 KB per wave)
+// stop the sixth wave.  Measured on S-nyc-1M: 0.332 -> 0.323 ms, pipelined 1233 -> 1267 views/s; seven and eight
+// waves per SIMD spill 36 / 64 bytes per lane and run 0.365 / 0.51 ms.
 template <bool OBJ, int NPX, bool GEOM>
-__global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
+__global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(RenderBwdArgs a) {
   constexpr int NSUB = PXL / NPX;
   // Registers parked per contributing entry: the per-lane sums as they are, except that the LAST one holds two values
   // (dg in lanes < 32, db in lanes >= 32, folded by one v_permlane32_swap + add): 8 registers for the nine sums,
@@ -711,7 +715,7 @@ __global__ void __launch_bounds__(64) k_render_bwd(RenderBwdArgs a) {
   // add -- tests/ubench/valu_rate.hip -- so only the one fold that makes the chunk count a power of two is kept;
   // folding all nine values into five registers cost five of them per entry.)
   constexpr int NREG = GEOM ? 8 : 2;
-  constexpr int RB = 64 / (4 * NREG);             // entries between two transposed sums: 2, or 8 (4 * NREG chunks each)
+  constexpr int RB = GEOM ? 1 : 4;                // entries between two transposed sums (RB * 4 * NREG chunks <= 64 lanes)
   constexpr int RENTRY = NREG * RED_REG;
   __shared__ float4 s0[64];
   __shared__ float4 s1[64];

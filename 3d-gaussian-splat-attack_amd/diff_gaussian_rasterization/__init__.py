@@ -72,7 +72,8 @@ class _CSettings(ctypes.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    # GSR_LIBRARY: another build of the same library (A/B runs of kernel variants on one box); default: the in-tree one
+    return os.environ.get("GSR_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def _load():
