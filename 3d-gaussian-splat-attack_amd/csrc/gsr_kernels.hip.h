@@ -660,12 +660,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha.
 // The 64-lane sums are not butterflies (a DPP add issues at half the rate of a plain one and nine values
 // need 9 x 6 of them): the per-lane values are parked in LDS as they are (ds_write does not occupy the VALU;
-// only dg and db are folded into one register so that an entry is 32 chunks), and after every contributing
-// entry the wave sums them TRANSPOSED: lane L adds the 16 floats of chunk L with plain v_add (4 ds_read_b128), two
-// DPP adds join the four chunks of a value, and the lanes store their row words directly.
+// only dg and db are folded into one register so that an entry is 64 chunks of 8 floats), and after every
+// contributing entry the wave sums them TRANSPOSED: lane L adds the 8 floats of chunk L with plain v_add (2
+// ds_read_b128), three DPP adds join the eight chunks of a value, and the lanes store their row words directly.
 // ------------------------------------------------------------------------------------------------
-constexpr int RED_ROW = 20;       // a 16-float chunk padded to 5 float4: ds_read_b128 at an odd float4 stride is conflict free
-constexpr int RED_REG = 4 * RED_ROW;      // one parked register: four 16-lane chunks
+constexpr int RED_ROW = 12;       // an 8-float chunk padded to 3 float4: ds_read_b128 at an odd float4 stride is conflict free
+constexpr int RED_REG = 8 * RED_ROW;      // one parked register: eight 8-lane chunks
 struct RenderBwdArgs {
   const uint2* ranges;
   const uint32_t* pair_rank;
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   // add -- tests/ubench/valu_rate.hip -- so only the one fold that makes the chunk count a power of two is kept;
   // folding all nine values into five registers cost five of them per entry.)
   constexpr int NREG = GEOM ? 8 : 2;
-  constexpr int RB = GEOM ? 1 : 4;                // entries between two transposed sums (RB * 4 * NREG chunks <= 64 lanes)
+  constexpr int RB = 64 / (8 * NREG);             // entries between two transposed sums: 1, or 4 (8 * NREG chunks each)
   constexpr int RENTRY = NREG * RED_REG;
   __shared__ float4 s0[64];
   __shared__ float4 s1[64];
@@ -761,15 +761,15 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   const bool clocked = a.wave_clock != nullptr && seg == 0u;
   if (clocked && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
-  const int red_wofs = (lane >> 4) * RED_ROW + (lane & 15);     // where this lane parks its partials
-  // transposed-sum roles: lane = (entry e, register rr, chunk ch); row word this lane stores: chunk 0 of register rr
-  // stores value rr (the colour sums keep their words 6..8 without the geometry sums), the folded last register
-  // stores dg from chunk 0 and db from chunk 2, chunks 1 and 3 of register 0 stamp the tag words 9 and 10
-  const int red_e = lane / (4 * NREG), red_rr = (lane % (4 * NREG)) >> 2, red_ch = lane & 3;
+  const int red_wofs = (lane >> 3) * RED_ROW + (lane & 7);      // where this lane parks its partials
+  // transposed-sum roles: lane = (entry e, register rr, chunk ch of 8 floats); row word this lane stores: chunk 0 of
+  // register rr stores value rr (the colour sums keep their words 6..8 without the geometry sums), the folded last
+  // register stores dg from chunk 0 and db from chunk 4, chunks 1 and 2 of register 0 stamp the tag words 9 and 10
+  const int red_e = lane / (8 * NREG), red_rr = (lane % (8 * NREG)) >> 3, red_ch = lane & 7;
   const bool red_last = red_rr == NREG - 1;
-  const int red_word = red_last ? (red_ch == 0 ? 7 : (red_ch == 2 ? 8 : -1))
+  const int red_word = red_last ? (red_ch == 0 ? 7 : (red_ch == 4 ? 8 : -1))
                                 : (red_ch == 0 ? red_rr + (GEOM ? 0 : 6)
-                                               : (red_rr == 0 && red_ch == 1 ? 9 : (red_rr == 0 && red_ch == 3 ? 10 : -1)));
+                                               : (red_rr == 0 && red_ch == 1 ? 9 : (red_rr == 0 && red_ch == 2 ? 10 : -1)));
   const float red_tag = __uint_as_float(red_word == 10 ? a.tag_hi : a.tag_lo);
   int red_j = 0;       // lane b: batch index j of the b-th parked entry
   int red_n = 0;       // parked entries (wave uniform)
@@ -965,11 +965,11 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         const int jm = __builtin_amdgcn_ds_bpermute(red_e << 2, red_j);
         if (red_e < red_n) {
           const float4* ch = reinterpret_cast<const float4*>(&sred[RED_ROW * lane]);
-          const float4 q0 = ch[0], q1 = ch[1], q2 = ch[2], q3 = ch[3];
-          float t = (((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w))) +
-                    (((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w)));
-          t += dpp_mov<0xB1, 0xF>(t);                    // chunks 0+1 and 2+3 of a register
-          const float t4 = t + dpp_mov<0x4E, 0xF>(t);    // all four chunks: the value of an unfolded register
+          const float4 q0 = ch[0], q1 = ch[1];
+          float t = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+          t += dpp_mov<0xB1, 0xF>(t);                    // quad_perm [1,0,3,2]
+          t += dpp_mov<0x4E, 0xF>(t);                    // quad_perm [2,3,0,1]: chunks 0..3 and 4..7 of a register
+          const float t4 = t + dpp_mov<0x141, 0xF>(t);   // row_half_mirror: all eight chunks, an unfolded register's value
           if (red_word >= 0) {
             float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[jm] * PART_F4);
             // words 9 and 10 carry this backward call's 64-bit tag: rows that no wave writes keep whatever the
