@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           const bool valid = (p2 <= 0.f) && (alpha >= ALPHA_MIN);   // finished pixels: p2 = -inf, alpha = 0
           const float Tn = T[k] * (1.f - alpha);
           const bool stop = valid && (Tn < T_STOP);
-          const bool contrib = valid && !(Tn < T_STOP);
+          const bool contrib = valid && !stop;
           const float w = contrib ? alpha * T[k] : 0.f;
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
           if (OBJ) {
