@@ -8,7 +8,8 @@ from gsplat_attack.scenes import make_scene
 from gsplat_attack.renderer import PipelineParams, render
 
 dev = torch.device("cuda:0")
-model, cams, spec = make_scene("nyc-1M", device=dev, n_views=8)
+SCENE = os.environ.get("DIAG_SCENE", "nyc-1M")
+model, cams, spec = make_scene(SCENE, device=dev, n_views=8)
 pipe = PipelineParams(skip_objects=True)
 bg = torch.zeros(3, device=dev)
 cam = cams[0]
@@ -27,13 +28,14 @@ nt = ln.numel()
 FWD = len(sys.argv) > 1 and sys.argv[1] == "fwd"
 if FWD:
     lib.gsr_debug_wave_clock_fwd.argtypes = [ctypes.c_void_p]
-    clk = torch.zeros(2 * nt, 2, dtype=torch.int64, device=dev)
+    NW = 4 if nt < 4096 else 2                     # forward waves per tile (the library's choice from the tile count)
+    clk = torch.zeros(NW * nt, 2, dtype=torch.int64, device=dev)
     lib.gsr_debug_wave_clock_fwd(ctypes.c_void_p(clk.data_ptr()))
     out2 = render(cam, model, pipe, bg)
     torch.cuda.synchronize()
     lib.gsr_debug_wave_clock_fwd(None)
-    ln = ln.repeat_interleave(2)
-    nt = 2 * nt
+    ln = ln.repeat_interleave(NW)
+    nt = NW * nt
 else:
     clk = torch.zeros(nt, 2, dtype=torch.int64, device=dev)
     lib.gsr_debug_wave_clock(ctypes.c_void_p(clk.data_ptr()))
