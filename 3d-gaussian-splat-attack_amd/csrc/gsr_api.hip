@@ -239,8 +239,6 @@ struct GsrCtx {
   uint32_t* segoff = nullptr;
   uint2* rec_item = nullptr;
   uint32_t* nrec = nullptr;
-  float* segP = nullptr;          // segmented forward: per-segment transmittance products / last contributors
-  uint32_t* segL = nullptr;
   uint32_t seg_shift = 0, rec_cap = 0;
   size_t keep_bytes = 0;
   float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;   // splat records in depth order
@@ -269,7 +267,6 @@ constexpr unsigned long long MAX_PAIRS = 1ull << 31;   // 32-bit pair numbering 
 static int flag_fwd_npx(uint32_t f) { const int v = (f >> 4) & 7u; return v == 1 ? 1 : v == 2 ? 2 : v == 3 ? 4 : 0; }
 static int flag_bwd_npx(uint32_t f) { const int v = (f >> 8) & 3u; return v == 1 ? 2 : v == 2 ? 4 : 0; }
 static int flag_tile_map(uint32_t f) { const int v = (f >> 12) & 7u; return (v >= 1 && v <= 4) ? v - 1 : 3; }
-static int flag_fwd_seg(uint32_t f) { return (int)((f >> 17) & 3u); }     // 0 library's choice, 1 on, 2 off
 
 static int ceil_log2(uint32_t v) {
   int b = 0;
@@ -520,30 +517,19 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     // for a forward-only call, not under GSR_FLAG_NO_SEGMENTS.
     static const int seg_shift_env = [] { const char* e = getenv("GSR_SEG_SHIFT"); int v = e ? atoi(e) : 8; return (v >= 6 && v <= 16) ? v : 8; }();
     ra.bnd = nullptr; ra.segoff = nullptr; ra.seg_shift = 0;
-    ra.fwd_seg = 0; ra.segP = nullptr; ra.segL = nullptr; ra.rec_item = nullptr; ra.nrec = nullptr;
-    // The forward itself composites split tiles per segment when the image has fewer tiles than the chip has wave slots
-    // (gsr_kernels.hip.h, "Segmented forward"); GSR_FLAG_FWD_SEGMENTS(1|2) forces it on / off.
-    const bool seg_ok = N > 0 && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS);
-    const bool fwd_seg = seg_ok && (flag_fwd_seg(s->flags) == 1 || (flag_fwd_seg(s->flags) == 0 && ntiles < 4096));
-    if (seg_ok && (ctx_out || fwd_seg)) {
+    if (N > 0 && ctx_out && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
       const uint32_t per = N >> seg_shift_env;
       c->seg_shift = (uint32_t)seg_shift_env;
       c->rec_cap = per + std::min<uint32_t>((uint32_t)ntiles, per) + 1u;   // sum over split tiles of ceil(len / seg)
       SlabPlan gp;
       gp.add<float4>((size_t)c->rec_cap * PXL * 64); gp.add<uint2>(c->rec_cap); gp.add<uint32_t>(ntiles); gp.add<uint32_t>(4);
-      if (fwd_seg) { gp.add<float>((size_t)c->rec_cap * PXL * 64); gp.add<uint32_t>((size_t)c->rec_cap * PXL * 64); }
       c->seg_blk = pool_alloc(dev, gp.bytes + 256, st);
       if (!c->seg_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: segment boundary buffer (N=%u) allocation failed", N));
       Slab gs{static_cast<char*>(c->seg_blk), gp.bytes + 256, 0};
       c->bnd = gs.take<float4>((size_t)c->rec_cap * PXL * 64); c->rec_item = gs.take<uint2>(c->rec_cap);
       c->segoff = gs.take<uint32_t>(ntiles); c->nrec = gs.take<uint32_t>(4);
-      if (fwd_seg) {
-        c->segP = gs.take<float>((size_t)c->rec_cap * PXL * 64);
-        c->segL = gs.take<uint32_t>((size_t)c->rec_cap * PXL * 64);
-      }
       F_TRY("segments", hipMemsetAsync(c->rec_item, 0, sizeof(uint2) * c->rec_cap, st));
       ra.bnd = c->bnd; ra.segoff = c->segoff; ra.seg_shift = c->seg_shift;
-      ra.fwd_seg = fwd_seg ? 1 : 0; ra.segP = c->segP; ra.segL = c->segL; ra.rec_item = c->rec_item; ra.nrec = c->nrec;
     }
     if (map_mode_f == 3 || c->bnd)
       hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift, c->segoff,
@@ -563,21 +549,6 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<false, 4>), gridT, blkT, 0, st, ra);
       else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<false, 2>), gridT, blkT, 0, st, ra);
       else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
-    }
-    if (ra.fwd_seg) {
-      // split tiles: products per segment, the reference's walk per segment, then the in-order combination
-      const dim3 gridS(c->rec_cap * (unsigned)(PXL / fwd_npx));
-      if (fwd_npx == 4) {
-        hipLaunchKernelGGL((k_render_fwd<false, 4, 1>), gridS, blkT, 0, st, ra);
-        hipLaunchKernelGGL((k_render_fwd<false, 4, 2>), gridS, blkT, 0, st, ra);
-      } else if (fwd_npx == 2) {
-        hipLaunchKernelGGL((k_render_fwd<false, 2, 1>), gridS, blkT, 0, st, ra);
-        hipLaunchKernelGGL((k_render_fwd<false, 2, 2>), gridS, blkT, 0, st, ra);
-      } else {
-        hipLaunchKernelGGL((k_render_fwd<false, 1, 1>), gridS, blkT, 0, st, ra);
-        hipLaunchKernelGGL((k_render_fwd<false, 1, 2>), gridS, blkT, 0, st, ra);
-      }
-      hipLaunchKernelGGL(k_fwd_combine, dim3(c->rec_cap), dim3(256), 0, st, ra);
     }
     F_LAUNCH("render forward");
   }

@@ -301,30 +301,8 @@ struct RenderArgs {
   float4* bnd;            // [records][256] (T, C_r, C_g, C_b) per pixel, pixel = strip * 64 + lane
   const uint32_t* segoff; // [ntiles] first boundary record of the tile, SEG_NONE for tiles that are not split
   uint32_t seg_shift;     // log2 of the segment length
-  // segmented FORWARD (see "Segmented forward" below): split tiles are composited by k_render_fwd<.,.,1|2> +
-  // k_fwd_combine, one work item per segment, and the whole-list kernel skips them
-  int fwd_seg;
-  float* segP;            // [records][256] per-pixel product of (1 - alpha) over the segment (pass 1)
-  uint32_t* segL;         // [records][256] last contributor of the segment | FSEG_STOPPED | FSEG_PARKED (pass 2)
-  const uint2* rec_item;
-  const uint32_t* nrec;
   unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock_fwd): [ntiles * NSUB][2] start/end, 100 MHz
 };
-
-// ------------------------------------------------------------------------------------------------
-// Segmented forward.  An image with fewer tiles than the chip has wave slots (< 4096 tiles) cannot hide a deep list:
-// on S-hydrant-full (2500 tiles) 17 % of the wave-slot time of the whole-list kernel is used, and its 190 us are the
-// walk of a few hundred ~1400-entry lists whose pixels never saturate.  There the split tiles are composited per
-// SEGMENT, with the associativity of (T, C) again: pass 1 (MODE 1) gives every segment's per-pixel transmittance product
-// P_s; pass 2 (MODE 2) starts segment s from T_in = P_0 ... P_{s-1} (a pixel with T_in < 1e-4 stopped in front of the
-// segment: it is parked) and runs the reference's walk over the segment's entries from C = 0; k_fwd_combine adds the
-// segments' colours in order up to the one the pixel stopped in, writes the image, final T and last contributor, and
-// leaves the boundary states the backward's segments start from in the very records the whole-list walk would have
-// written.  The stop test sees T_in through a product in another association than the sequential walk's: the two can
-// disagree only where T(1 - alpha) is within rounding of 1e-4.
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t FSEG_STOPPED = 0x80000000u;   // the pixel met the T < 1e-4 stop inside this segment
-constexpr uint32_t FSEG_PARKED = 0x40000000u;    // the pixel had stopped in front of this segment
 
 // ------------------------------------------------------------------------------------------------
 // Segments.  Front-to-back compositing is associative in (T, C): the state after list position b, (T_b, C_b), is all
@@ -499,9 +477,7 @@ constexpr float PX_OFF = 1.0e30f;   // y coordinate of a finished / out-of-image
 // NPX = pixels per lane: 4 -> one wave per tile, 2 -> two waves (16x8 halves), 1 -> four waves (16x4 strips).
 // Fewer pixels per wave = shorter dependent chain per list entry and more, smaller work items for the
 // dispatcher to balance (a tile's list length sets its wave's run time); more = staging amortised further.
-// MODE 0: the whole list of a tile (split tiles: boundary states stored on the way, or skipped under fwd_seg);
-// MODE 1 / 2: one SEGMENT of a split tile per work item (blockIdx = record * NSUB + part), see "Segmented forward".
-template <bool OBJ, int NPX, int MODE = 0>
+template <bool OBJ, int NPX>
 __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   constexpr int NSUB = PXL / NPX;
   __shared__ float4 s0[64];
@@ -510,14 +486,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
   const int lane = threadIdx.x;
   int item;
-  uint32_t seg = 0;
-  if (MODE != 0) {
-    const uint32_t r = blockIdx.x / NSUB;
-    if (r >= *a.nrec) return;
-    const uint2 it = a.rec_item[r];
-    item = (int)it.x * NSUB + (int)(blockIdx.x % NSUB);
-    seg = it.y;                                        // 1 .. nseg-1: segment index + 1 (interior record); 0: the last one
-  } else if (a.map_mode == 3) {
+  if (a.map_mode == 3) {
     if ((int)blockIdx.x >= a.ntiles * NSUB) return;
     const uint32_t sc = a.sched[blockIdx.x / NSUB];
     item = (int)(sc & SCHED_TILE_MASK) * NSUB + (int)(blockIdx.x % NSUB);
@@ -532,17 +501,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
   // a split tile (see "Segments"): this wave stores (T, C) of its pixels at every segment boundary it walks past
   const uint32_t rec0 = (!OBJ && a.bnd != nullptr) ? a.segoff[tile] : SEG_NONE;
   const uint32_t seg_mask = (1u << a.seg_shift) - 1u;
-  if (MODE == 0 && !OBJ && a.fwd_seg && rec0 != SEG_NONE) return;      // composited per segment elsewhere
-  // list positions [w0, w1) this wave walks
-  uint32_t w0 = rg.x, w1 = rg.y, srec = 0;
-  if (MODE != 0) {
-    const uint32_t nseg = (rg.y - rg.x + seg_mask) >> a.seg_shift;
-    const uint32_t sidx = seg == 0u ? nseg - 1u : seg - 1u;
-    srec = rec0 + sidx;
-    w0 = rg.x + (sidx << a.seg_shift);
-    w1 = min(w0 + (1u << a.seg_shift), rg.y);
-  }
-  if (MODE == 0 && a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)x;
   int y[NPX];
@@ -558,22 +517,16 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     T[k] = 1.f;
     C[k][0] = C[k][1] = C[k][2] = 0.f;
     last[k] = 0;
-    if (MODE == 2) {
-      // transmittance in front of the segment: the product of the earlier segments' products, in list order
-      const size_t px = (size_t)(sub * NPX + k) * 64 + lane;
-      for (uint32_t q = rec0; q < srec; ++q) T[k] *= a.segP[(size_t)q * (PXL * 64) + px];
-      if (inside && T[k] < T_STOP) { pyf[k] = PX_OFF; last[k] = FSEG_PARKED; }   // stopped in front of this segment
-    }
-    if (__ballot(pyf[k] < PX_OFF) != 0ull) alive |= 1u << k;
+    if (__ballot(inside) != 0ull) alive |= 1u << k;
     if (OBJ) {
 #pragma unroll
       for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = 0.f;
     }
   }
-  for (uint32_t base = w0; base < w1 && alive; base += 64) {
+  for (uint32_t base = rg.x; base < rg.y && alive; base += 64) {
     const uint32_t i = base + lane;
     uint32_t mine = 0;
-    if (i < w1) {
+    if (i < rg.y) {
       const uint32_t pv = a.pair_rank[i];
       const uint32_t r = pv & RANK_MASK;
       const float4 c = a.R2[REC * r];
@@ -623,10 +576,6 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           const float G = __builtin_amdgcn_exp2f(p2);
           const float alpha = fminf(ALPHA_CAP, e1.y * G);
           const bool valid = (p2 <= 0.f) && (alpha >= ALPHA_MIN);   // finished pixels: p2 = -inf, alpha = 0
-          if (MODE == 1) {                                          // pass 1: the segment's transmittance product only
-            T[k] = valid ? T[k] * (1.f - alpha) : T[k];
-            continue;
-          }
           const float Tn = T[k] * (1.f - alpha);
           const bool stop = valid && (Tn < T_STOP);
           const bool contrib = valid && !stop;
@@ -638,7 +587,6 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           }
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
-          if (MODE == 2) last[k] = stop ? (last[k] | FSEG_STOPPED) : last[k];
           pyf[k] = stop ? PX_OFF : pyf[k];
           if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
         }
@@ -648,7 +596,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
     }
     }
     __builtin_amdgcn_wave_barrier();
-    if (MODE == 0 && !OBJ && rec0 != SEG_NONE) {
+    if (!OBJ && rec0 != SEG_NONE) {
       const uint32_t pos_end = base - rg.x + 64u;       // list positions 1 .. pos_end are behind us
       if ((pos_end & seg_mask) == 0u && pos_end < rg.y - rg.x) {
         float4* rec = a.bnd + ((size_t)(rec0 + (pos_end >> a.seg_shift) - 1u) * PXL + sub * NPX) * 64 + lane;
@@ -657,27 +605,13 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       }
     }
   }
-  if (MODE == 1) {
-#pragma unroll
-    for (int k = 0; k < NPX; ++k) a.segP[(size_t)srec * (PXL * 64) + (size_t)(sub * NPX + k) * 64 + lane] = T[k];
-    return;
-  }
-  if (MODE == 2) {
-#pragma unroll
-    for (int k = 0; k < NPX; ++k) {
-      const size_t px = (size_t)srec * (PXL * 64) + (size_t)(sub * NPX + k) * 64 + lane;
-      a.bnd[px] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
-      a.segL[px] = last[k];
-    }
-    return;
-  }
   if (!OBJ && rec0 != SEG_NONE) {                       // final state of a split tile: record rec0 + nseg - 1
     const uint32_t nseg = (rg.y - rg.x + seg_mask) >> a.seg_shift;
     float4* rec = a.bnd + ((size_t)(rec0 + nseg - 1u) * PXL + sub * NPX) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < NPX; ++k) rec[k * 64] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
   }
-  if (MODE == 0 && a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
+  if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
 #pragma unroll
@@ -694,45 +628,6 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
         for (int c = 0; c < NUM_OBJ; ++c) a.out_objects[c * HW + pix] = O[k][c];
       }
     }
-  }
-}
-
-// Last pass of the segmented forward: one 256-thread block per split tile (launched one per record; the block of the
-// tile's LAST record does the work), thread = pixel in the records' (strip, lane) order.
-__global__ void __launch_bounds__(256) k_fwd_combine(RenderArgs a) {
-  const uint32_t r = blockIdx.x;
-  if (r >= *a.nrec) return;
-  const uint2 it = a.rec_item[r];
-  if (it.y != 0u) return;                               // not a tile's last record
-  const int tile = (int)it.x;
-  const uint32_t rec0 = a.segoff[tile];
-  const uint32_t nseg = r - rec0 + 1u;
-  const int p = threadIdx.x, lane = p & 63, strip = p >> 6;
-  const int tx = tile % a.gridx, ty = tile / a.gridx;
-  const int x = tx * TILE + (lane & 15), y = ty * TILE + 4 * strip + (lane >> 4);
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  uint32_t last = 0;
-  bool done = false;
-  for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
-    const size_t idx = (size_t)(rec0 + sgi) * (PXL * 64) + p;
-    const float4 v = a.bnd[idx];
-    const uint32_t L = a.segL[idx];
-    if (L & FSEG_PARKED) done = true;
-    if (!done) {
-      C0 += v.y; C1 += v.z; C2 += v.w;
-      T = v.x;
-      last = max(last, L & ~(FSEG_STOPPED | FSEG_PARKED));
-      if (L & FSEG_STOPPED) done = true;
-    }
-    a.bnd[idx] = make_float4(T, C0, C1, C2);            // the state behind this segment: what the backward starts from
-  }
-  if (x < a.W && y < a.H) {
-    const size_t HW = (size_t)a.H * a.W, pix = (size_t)y * a.W + x;
-    a.out_color[pix] = C0 + T * a.bg[0];
-    a.out_color[HW + pix] = C1 + T * a.bg[1];
-    a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
-    a.final_T[pix] = T;
-    a.n_contrib[pix] = last;
   }
 }
 

@@ -39,11 +39,6 @@ def flag_bwd_split(npx: int) -> int:
     return {0: 0, 2: 1, 4: 2}[npx] << 8
 
 
-def flag_fwd_segments(mode: int) -> int:
-    """GSR_FLAG_FWD_SEGMENTS: 1 = the forward composites split tiles per segment, 2 = never, 0 = library's choice."""
-    return (mode & 3) << 17
-
-
 def flag_tile_map(mode: int) -> int:
     """GSR_FLAG_TILE_MAP: block -> tile map 0..3 (3 = longest list first, the default)."""
     return ((mode & 3) + 1) << 12

@@ -57,9 +57,6 @@ enum {
 #define GSR_FLAG_BWD_SPLIT(n) ((uint32_t)((n) == 2 ? 1u : (n) == 4 ? 2u : 0u) << 8)
 #define GSR_FLAG_TILE_MAP(m) ((uint32_t)(((m) & 3u) + 1u) << 12)
 #define GSR_FLAG_NO_SEGMENTS (1u << 16)
-/*   GSR_FLAG_FWD_SEGMENTS(m)  m = 1: the FORWARD composites split tiles per segment too (three launches; the
- *                                    library's choice for images of fewer than 4096 tiles), m = 2: never */
-#define GSR_FLAG_FWD_SEGMENTS(m) ((uint32_t)((m) & 3u) << 17)
 
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the
