@@ -30,9 +30,10 @@ def _hip():
     return D
 
 
-def pick_windows(ranges, gx, gy, half=1):
+def pick_windows(ranges, gx, gy, half=1, extra=0, seed=0):
     """Tile windows (tx0, ty0, tx1, ty1) from the HIP forward's per-tile list lengths: around the longest list, around a
-    dense tile (99th percentile), the bottom-right border, the bottom border under the densest column, mid-image."""
+    dense tile (99th percentile), the bottom-right border, the bottom border under the densest column, mid-image, plus
+    `extra` seeded random 2x2 windows among the non-empty tiles."""
     lens = (ranges[:, 1] - ranges[:, 0]).view(gy, gx).cpu()
 
     def around(ty, tx):
@@ -45,6 +46,12 @@ def pick_windows(ranges, gx, gy, half=1):
     wins = [around(t_long // gx, t_long % gx), around(t_dense // gx, t_dense % gx),
             (gx - 2, gy - 2, gx, gy), (max(col - 1, 0), gy - 1, min(col + 1, gx), gy),
             around(gy // 2, gx // 2)]
+    if extra:
+        g = torch.Generator().manual_seed(seed)
+        nz = torch.nonzero(flat > 0).flatten()
+        for t in nz[torch.randperm(nz.numel(), generator=g)[:extra]].tolist():
+            ty, tx = t // gx, t % gx
+            wins.append((tx, ty, min(tx + 2, gx), min(ty + 2, gy)))
     return wins, int(flat.max())
 
 
@@ -139,14 +146,14 @@ def _scene_on_gpu(key, n_views):
     return dev, model, cams
 
 
-def _windows_for(D, model, cam, bg, scale=1.0):
+def _windows_for(D, model, cam, bg, scale=1.0, extra=0):
     from gsplat_attack.renderer import PipelineParams, render
     H, W = cam.image_height, cam.image_width
     gx, gy = (W + 15) // 16, (H + 15) // 16
     out = render(cam, model, PipelineParams(skip_objects=True), bg, scale)
     img = out["render"]
     ranges = D.export_state(img, "ranges").view(-1, 2).long()
-    wins, longest = pick_windows(ranges, gx, gy)
+    wins, longest = pick_windows(ranges, gx, gy, extra=extra, seed=gx * gy)
     radii = out["radii"].cpu()
     depth = D.export_state(img, "G").view(-1, 12)[:, 9].cpu()
     depth = torch.where(radii > 0, depth, torch.zeros_like(depth))       # records of culled Gaussians are not written
@@ -160,7 +167,7 @@ def test_cfg3_nyc_1m_1080p_all_gradients_vs_windowed_oracle():
     dev, model, cams = _scene_on_gpu("nyc-1M", 3)
     cam = cams[2]
     bg = torch.tensor([0.1, 0.2, 0.3])
-    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev), extra=10)   # 5 chosen + 10 random windows
     assert gx * gy >= 4096 and longest > 256, (gx * gy, longest)
     m = window_mask(wins, 1080, 1920)
     gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(99)) * m
