@@ -140,6 +140,20 @@ def test_lower_sh_degrees(deg):
     check(model_inputs(model), cams[0], torch.zeros(3), sh_degree=deg)
 
 
+@pytest.mark.parametrize("K,deg", [(9, 2), (4, 1), (1, 0), (25, 3)])
+def test_sh_storage_other_than_sixteen_coefficients(K, deg):
+    """shs [P,K,3] with K != 16 (a model trained at a lower maximum degree, or one that stores more than it uses): the
+    rasteriser's generic per-Gaussian kernels (one thread per Gaussian reading its own row), forward and backward."""
+    model, cams, _ = _scene(n_views=1)
+    inp = model_inputs(model)
+    g = torch.Generator().manual_seed(K)
+    P = inp["means3D"].shape[0]
+    shs = torch.randn(P, K, 3, generator=g) * 0.3
+    shs[:, 0] += torch.randn(P, 3, generator=g)
+    inp["shs"] = shs
+    check(inp, cams[0], torch.tensor([0.1, 0.3, 0.2]), sh_degree=deg)
+
+
 def test_ragged_image_size_and_close_camera():
     """Sizes that are not multiples of 16 and a camera inside the blob: exercises near-plane culling,
     the 1.3*tanfov clamp, rect clamping at the image border and huge screen-space splats."""
