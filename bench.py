@@ -150,6 +150,8 @@ def main():
                          "kernels of one view overlap the compositing kernels of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed forward-only / PGD-iteration extras")
+    ap.add_argument("--scale-modifier", type=float, default=1.0,
+                    help="render()'s scaling_modifier for the main timed region (diagnostic: 2.43 = the dense data point)")
     ap.add_argument("--one-camera", action="store_true",
                     help="render the same camera every step (round-1 behaviour) instead of cycling the 8 ring cameras")
     ap.add_argument("--dense-pairs", type=float, default=10e6,
@@ -206,7 +208,7 @@ def main():
 
     info = {}
 
-    scale_mod = [1.0]
+    scale_mod = [args.scale_modifier]
 
     def step():
         model.zero_grad()
@@ -243,12 +245,12 @@ def main():
     per_cam = []
     with torch.no_grad():
         for c_ in (cams[:n_views] if not args.one_camera else [cam]):
-            o_ = render(c_, model, pipe, bg)
+            o_ = render(c_, model, pipe, bg, scale_mod[0])
             per_cam.append((int((o_["radii"] > 0).sum().item()), o_))
     # num_rendered of a forward-only call: read it from a grad-enabled render's context
     Ns = []
     for c_ in (cams[:n_views] if not args.one_camera else [cam]):
-        o_ = render(c_, model, pipe, bg)
+        o_ = render(c_, model, pipe, bg, scale_mod[0])
         Ns.append(D.last_num_rendered(o_["render"]))
         del o_
     info["N_per_camera"] = Ns
@@ -410,7 +412,7 @@ def main():
                                "pipeline_GBps": round(Bd / (dt / nd) / 1e9, 1),
                                "workload": "same scene and cameras, every splat scaled by scale_modifier so that a view "
                                            "emits ~10 M (tile, Gaussian) pairs (BASELINE.md section 3 nominal)"}
-            scale_mod[0] = 1.0
+            scale_mod[0] = args.scale_modifier
             step_no[0] = 0
         if world == 1 and not args.no_extras:
             # SURVEY.md section 8d "also report": forward-only rate and one PGD iteration (untimed extras)
