@@ -62,12 +62,13 @@ def window_mask(wins, H, W):
     return m
 
 
-def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, keys=None, scale=1.0):
+def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, keys=None, scale=1.0, n_views=None):
     """oracle-R float64 on the CPU twin of the scene, autograd down to the RAW parameters through the getters.
     keys = (depth keys, radii) exported from the HIP forward: the oracle composites in the order of those float32 keys
     once they are within a few ulps of its own float64 depth (oracle_r.check_depth_keys)."""
     from gsplat_attack.scenes import make_scene
-    ref, rcams, _ = make_scene(key, device="cpu", n_views=cam_i + 1, **(scale_kw or {}))
+    # (the ring cameras depend on the ring's size: the twin must be built with the same number of views)
+    ref, rcams, _ = make_scene(key, device="cpu", n_views=n_views or cam_i + 1, **(scale_kw or {}))
     st = settings_for(rcams[cam_i], bg, 3, scale)
     depth_key = None
     if keys is not None:
@@ -252,6 +253,41 @@ def test_cfg5_airport_4k_full_backward_vs_windowed_oracle():
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), objects=True, go=go.to(dev))
     rep = compare(out, grads, ro, rgrads, m, names=RAW + ("objects_dc",), objects=True)
     print("cfg5 windows", wins, "longest list", longest, rep)
+
+
+def test_cfg4_views_of_a_batch_accumulate_at_full_size():
+    """BASELINE config 4's single-GPU logic at full size: three ring views of S-nyc-1M rendered and differentiated one
+    after the other (all five attribute groups, three HIP streams), .grad accumulating across them -- what each rank
+    of the view-sharded loop does before the all-reduce -- against the SUM of the windowed oracle's per-view gradients."""
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.streams import StreamRing
+    D = _hip()
+    dev, model, cams = _scene_on_gpu("nyc-1M", 6)
+    bg = torch.tensor([0.05, 0.0, 0.1])
+    views = [cams[1], cams[3], cams[5]]
+    per_view = []
+    for vi, cam in zip((1, 3, 5), views):
+        wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
+        wins = wins[:3]
+        m = window_mask(wins, 1080, 1920)
+        gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(40 + vi)) * m
+        ro, rgrads, gc, _ = oracle_raw("nyc-1M", vi, bg, gc, wins, keys=keys, n_views=6)
+        per_view.append((gc.to(dev), rgrads))
+    model.zero_grad()
+    ring = StreamRing(3, dev)
+    for cam, (gcd, _) in zip(views, per_view):
+        with ring.next():
+            render(cam, model, PipelineParams(skip_objects=True), bg.to(dev))["render"].backward(gcd)
+    ring.join()
+    torch.cuda.synchronize()
+    for n in RAW:
+        want = sum(rg[n] for _, rg in per_view)
+        norm, frac = grad_error(getattr_grad(model, n), want, elem_tol=5 * GRAD_TOL)
+        assert norm <= GRAD_TOL and frac <= 3e-3, (n, norm, frac)
+
+
+def getattr_grad(model, name):
+    return model.named_parameters()[name].grad.detach().cpu()
 
 
 def test_cfg3_pgd20_colour_attack_at_full_size():
