@@ -575,10 +575,15 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
           const float G = __builtin_amdgcn_exp2f(p2);
           const float alpha = fminf(ALPHA_CAP, e1.y * G);
-          const bool valid = (p2 <= 0.f) && (alpha >= ALPHA_MIN);   // finished pixels: p2 = -inf, alpha = 0
           const float Tn = T[k] * (1.f - alpha);
-          const bool stop = valid && (Tn < T_STOP);
-          const bool contrib = valid && !stop;
+          // lane masks kept as scalars (s_and / s_andn2 instead of a second pair of vector compares): valid = the
+          // reference's alpha test (finished pixels: p2 = -inf, alpha = 0), stop = the pixel ends in front of this
+          // entry, contrib = the entry is blended
+          const uint64_t vm = __builtin_amdgcn_ballot_w64(p2 <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+          const uint64_t lt = __builtin_amdgcn_ballot_w64(Tn < T_STOP);
+          const uint64_t sm = vm & lt, cb = vm & ~lt;
+          const bool stop = __builtin_amdgcn_inverse_ballot_w64(sm);
+          const bool contrib = __builtin_amdgcn_inverse_ballot_w64(cb);
           const float w = contrib ? alpha * T[k] : 0.f;
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
           if (OBJ) {
@@ -588,7 +593,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
           pyf[k] = stop ? PX_OFF : pyf[k];
-          if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
+          if (sm != 0ull && __builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
         }
       }
       }
@@ -760,16 +765,20 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   }
   const bool clocked = a.wave_clock != nullptr && seg == 0u;
   if (clocked && lane == 0) a.wave_clock[2 * item] = wall_clock64();
-  // transposed-sum roles: chunk L = (entry e, register n, row rho) holds 16 partials of value 2n + (rho>>1)
-  const int red_wofs = (lane >> 3) * RED_ROW + (lane & 7);      // where this lane parks its partials
-  // transposed-sum roles: lane = (entry e, register rr, chunk ch of 8 floats); row word this lane stores: chunk 0 of
-  // register rr stores value rr (the colour sums keep their words 6..8 without the geometry sums), the folded last
-  // register stores dg from chunk 0 and db from chunk 4, chunks 1 and 2 of register 0 stamp the tag words 9 and 10
+  // Where this lane parks its partials: a register is eight 8-float chunks at a stride of 12 floats (bank starts
+  // 0,12,24,4,16,28,8,20): the even chunks cover the 32 banks exactly once and so do the odd ones, so lanes 0..31 fill
+  // the even chunks and lanes 32..63 the odd ones -- each half-wave pass of a ds_write_b32 is conflict free.
+  const int red_wofs = (2 * ((lane & 31) >> 3) + (lane >> 5)) * RED_ROW + (lane & 7);
+  // transposed-sum roles: lane = (entry e, register rr, chunk ch of 8 floats).  The joins leave in chunks >= 4 first
+  // the total of the chunks of the same parity, then the total of all eight.  Row word this lane stores: chunk 4 of
+  // register rr stores value rr (the colour sums keep their words 6..8 without the geometry sums); the folded last
+  // register holds dg in its even chunks (lanes < 32 of the fold) and db in its odd ones: chunk 4 stores dg, chunk 5 db;
+  // chunks 6 and 7 of register 0 stamp the tag words 9 and 10
   const int red_e = lane / (8 * NREG), red_rr = (lane % (8 * NREG)) >> 3, red_ch = lane & 7;
   const bool red_last = red_rr == NREG - 1;
-  const int red_word = red_last ? (red_ch == 0 ? 7 : (red_ch == 4 ? 8 : -1))
-                                : (red_ch == 0 ? red_rr + (GEOM ? 0 : 6)
-                                               : (red_rr == 0 && red_ch == 1 ? 9 : (red_rr == 0 && red_ch == 2 ? 10 : -1)));
+  const int red_word = red_last ? (red_ch == 4 ? 7 : (red_ch == 5 ? 8 : -1))
+                                : (red_ch == 4 ? red_rr + (GEOM ? 0 : 6)
+                                               : (red_rr == 0 && red_ch == 6 ? 9 : (red_rr == 0 && red_ch == 7 ? 10 : -1)));
   const float red_tag = __uint_as_float(red_word == 10 ? a.tag_hi : a.tag_lo);
   int red_j = 0;       // lane b: batch index j of the b-th parked entry
   int red_n = 0;       // parked entries (wave uniform)
@@ -967,9 +976,9 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
           const float4* ch = reinterpret_cast<const float4*>(&sred[RED_ROW * lane]);
           const float4 q0 = ch[0], q1 = ch[1];
           float t = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
-          t += dpp_mov<0xB1, 0xF>(t);                    // quad_perm [1,0,3,2]
-          t += dpp_mov<0x4E, 0xF>(t);                    // quad_perm [2,3,0,1]: chunks 0..3 and 4..7 of a register
-          const float t4 = t + dpp_mov<0x141, 0xF>(t);   // row_half_mirror: all eight chunks, an unfolded register's value
+          t += dpp_mov<0x4E, 0xF>(t);                    // quad_perm [2,3,0,1]: chunks c, c ^ 2
+          t += dpp_mov<0x114, 0xF>(t);                   // row_shr:4: chunks >= 4 now hold their parity's total
+          const float t4 = t + dpp_mov<0xB1, 0xF>(t);    // quad_perm [1,0,3,2]: both parities, an unfolded register's value
           if (red_word >= 0) {
             float* row = reinterpret_cast<float*>(a.part + (size_t)sslot[jm] * PART_F4);
             // words 9 and 10 carry this backward call's 64-bit tag: rows that no wave writes keep whatever the
