@@ -1,4 +1,10 @@
 """Counterparts of the reference's callers and data formats either side of the rasteriser."""
+import os
+
+# View pipelining (gsplat_attack.streams) deals a batch's views over four HIP streams; the HIP runtime maps a process's
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, read at its first call) and streams sharing a queue
+# serialise.  Ask for eight unless the user chose a value; harmless when the runtime is already initialised.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def patch_reference(module_name: str = "gaussian_renderer") -> int:

@@ -99,7 +99,7 @@ def gather_success(flags: Sequence[bool], n_views: int, rank: int, world: int, d
 def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5, epsilon: float = 5.0,
                groups: Iterable[str] = ("color",), norm: str = "l2", bg: Optional[torch.Tensor] = None,
                loss_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, pipe: Optional[PipelineParams] = None,
-               log: Optional[Callable[[dict], None]] = None, streams: int = 3, accumulate_grads: bool = False,
+               log: Optional[Callable[[dict], None]] = None, streams: int = 4, accumulate_grads: bool = False,
                batch_loss: bool = False, loss_reduction: str = "sum", background=None,
                success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
                originals: Optional[dict] = None) -> List[float]:
@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--norm", default="l2")
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--epsilon", type=float, default=5.0)
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the rank's views are pipelined over")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the rank's views are pipelined over")
     args = ap.parse_args()
     from .scenes import make_scene
     rank, world, local = gdist.init_from_env()

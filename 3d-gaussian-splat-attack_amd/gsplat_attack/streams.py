@@ -3,9 +3,11 @@
 One view's forward + backward is a chain of ~35 dependent kernels of which only the two compositing kernels fill
 the chip; the sorts, scans and the per-Gaussian kernels in between leave most CUs idle.  The views of a PGD batch
 are independent until the optimiser step, so dealing them round-robin over a few streams lets the small kernels of
-one view run beside the compositing kernels of another (+25 % views/s on the benchmark scene with three streams).
+one view run beside the compositing kernels of another (+27 % views/s on the benchmark scene with four streams and
+GPU_MAX_HW_QUEUES=8, which gsplat_attack/__init__.py asks for: with the runtime's default of four hardware queues
+three streams are the optimum and a fourth loses 6 %).
 
-    ring = StreamRing(3, device)
+    ring = StreamRing(4, device)
     for cam in batch:
         with ring.next():                         # this view's kernels (and its loss) go to the ring's next stream
             loss_fn(render(cam, model, pipe, bg)["render"]).backward()

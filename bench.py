@@ -7,7 +7,7 @@ hand-written HIP) + one backward from a fixed dL/dC[3,H,W] down to .grad on all 
 (59 attack-relevant floats per Gaussian), object channels off.  With N > 1 every rank renders its own view of
 the ring (weak scaling) and the attribute gradients are sum-all-reduced over RCCL each step, inside the timed
 region.  Inputs are resident in HBM before the timed region starts.  Consecutive views are dealt round-robin over
---streams HIP streams (default 3; gsplat_attack.streams) so one view's sort/scan kernels run beside another's
+--streams HIP streams (default 4; gsplat_attack.streams) so one view's sort/scan kernels run beside another's
 compositing kernels -- exactly K views are still rendered and differentiated inside the timed region.
 
     python bench.py                       # N=1, defaults finish in ~2 minutes incl. the CPU baseline
@@ -30,6 +30,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "3d-gaussian-splat-attack_amd"))
 sys.path.insert(0, ROOT)
+# the HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise (read at its first
+# call): views pipelined over four streams (+ torch's own) need more, or kernels of independent views serialise
+# behind each other (same box: 4 queues / 3 streams 1276, 4 / 4 1200, 8 / 4 1310 views/s)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -145,7 +149,7 @@ def main():
                     help="activated tensors through GaussianRasterizer (what the reference's own render() does) instead of "
                          "the fused raw-parameter path")
     ap.add_argument("--no-cull", action="store_true", help="keep the full 3-sigma tile rects (A/B of the footprint cull)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the views are dealt over (view i runs on stream i %% S): the small sort/scan "
                          "kernels of one view overlap the compositing kernels of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
