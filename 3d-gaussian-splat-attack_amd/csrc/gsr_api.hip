@@ -4,6 +4,7 @@
 // (imported at reference gaussian_renderer/__init__.py:14).  No torch linkage: raw device pointers in,
 // kernels enqueued on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -201,14 +202,18 @@ hipEvent_t get_event_locked() {
 
 struct StageTimer {
   int stage; hipStream_t st; hipEvent_t a{}, b{}; bool on = false;
-  StageTimer(int s, hipStream_t stream) : stage(s), st(stream) {
+  // kernel_events: the stage is ONE kernel and the caller hands a and b to hipExtLaunchKernelGGL, which stamps them
+  // with the dispatch's own start and end (what a profiler reports as the kernel's duration); events recorded on the
+  // stream around a launch also count the time the dispatch waits behind other streams' kernels.
+  bool kernel_events;
+  StageTimer(int s, hipStream_t stream, bool kernel_ev = false) : stage(s), st(stream), kernel_events(kernel_ev) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     on = (g_prof >> stage) & 1u;
-    if (on) { a = get_event_locked(); b = get_event_locked(); (void)hipEventRecord(a, st); }
+    if (on) { a = get_event_locked(); b = get_event_locked(); if (!kernel_events) (void)hipEventRecord(a, st); }
   }
   ~StageTimer() {
     if (on) {
-      (void)hipEventRecord(b, st);
+      if (!kernel_events) (void)hipEventRecord(b, st);
       std::lock_guard<std::mutex> lk(g_prof_mu);
       g_spans.push_back(ProfSpan{stage, a, b});
     }
@@ -651,7 +656,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
   const uint32_t tag_lo = (uint32_t)z, tag_hi = (uint32_t)(z >> 32);
   if (N > 0) {
-    StageTimer t(GSR_STAGE_RENDER_BWD, st);
+    StageTimer t(GSR_STAGE_RENDER_BWD, st, true);
     RenderBwdArgs ra;
     ra.tag_lo = tag_lo; ra.tag_hi = tag_hi;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
@@ -666,21 +671,27 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->nrec;
     ra.seg_shift = c->seg_shift; ra.extra_blocks = segs ? c->rec_cap * nsub : 0u;
     const dim3 gridT(ra.extra_blocks + (unsigned)render_grid(c->ntiles * (int)nsub)), blk(64);
+#define LAUNCH_K7(kern)                                                                      \
+  do {                                                                                       \
+    if (t.on) hipExtLaunchKernelGGL(kern, gridT, blk, 0, st, t.a, t.b, 0, ra);               \
+    else hipLaunchKernelGGL(kern, gridT, blk, 0, st, ra);                                    \
+  } while (0)
     if (obj) {
       if (geom) {
-        if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4, true>), gridT, blk, 0, st, ra);
-        else hipLaunchKernelGGL((k_render_bwd<true, 2, true>), gridT, blk, 0, st, ra);
+        if (bwd_npx == 4) LAUNCH_K7((k_render_bwd<true, 4, true>));
+        else LAUNCH_K7((k_render_bwd<true, 2, true>));
       } else {
-        if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<true, 4, false>), gridT, blk, 0, st, ra);
-        else hipLaunchKernelGGL((k_render_bwd<true, 2, false>), gridT, blk, 0, st, ra);
+        if (bwd_npx == 4) LAUNCH_K7((k_render_bwd<true, 4, false>));
+        else LAUNCH_K7((k_render_bwd<true, 2, false>));
       }
     } else if (geom) {
-      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<false, 4, true>), gridT, blk, 0, st, ra);
-      else hipLaunchKernelGGL((k_render_bwd<false, 2, true>), gridT, blk, 0, st, ra);
+      if (bwd_npx == 4) LAUNCH_K7((k_render_bwd<false, 4, true>));
+      else LAUNCH_K7((k_render_bwd<false, 2, true>));
     } else {
-      if (bwd_npx == 4) hipLaunchKernelGGL((k_render_bwd<false, 4, false>), gridT, blk, 0, st, ra);
-      else hipLaunchKernelGGL((k_render_bwd<false, 2, false>), gridT, blk, 0, st, ra);
+      if (bwd_npx == 4) LAUNCH_K7((k_render_bwd<false, 4, false>));
+      else LAUNCH_K7((k_render_bwd<false, 2, false>));
     }
+#undef LAUNCH_K7
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "render backward: launch failed: %s", hipGetErrorString(e)));
   }

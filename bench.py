@@ -264,8 +264,10 @@ def main():
     del per_cam
     step_no[0] = 0
 
-    # Timed region: only the dominant kernel stage (K7, the backward composite) is bracketed by HIP events on the
-    # launch stream -- two event records per step; bracketing all seven stages costs ~10 us of queue gap each.
+    # Timed region: only the dominant kernel (K7, the backward composite) is timed, by two HIP events that
+    # hipExtLaunchKernelGGL stamps with the dispatch's own start and end on its launch stream (events recorded around
+    # the launch would also count the time the dispatch waits behind the other streams' kernels); bracketing all
+    # seven stages costs ~10 us of queue gap each.
     DOMINANT = "render_bwd"
     if streams is not None:
         run_steps(2 * len(streams))          # untimed: lets every stream build its own workspace blocks
