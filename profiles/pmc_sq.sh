@@ -22,7 +22,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/p*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if "render" in k or "preprocess" in k:
+        if "render" in k or "k_pre_" in k or "preprocess" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 json.dump(res, open(f"{out}/sq_summary.json", "w"), indent=1)
