@@ -545,14 +545,24 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
     const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : 2);
     const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
+    // the tile's waves as one workgroup that stages every batch once (k_render_fwd's WPB): S-nyc-1M gathers 596 -> 367 MB
+    // but runs 0.197 -> 0.224 ms (two workgroup barriers per batch, and the waves of a tile wait for each other), so
+    // it is opt-in: GSR_FLAG_FWD_SHARED, or GSR_K6_SHARED=1 in the environment
+    static const int k6_env = [] { const char* e = getenv("GSR_K6_SHARED"); return e ? atoi(e) : 0; }();
+    const bool k6_shared = k6_env != 0 || (s->flags & GSR_FLAG_FWD_SHARED) != 0;
+    const dim3 gridS(render_grid(ntiles)), blkS2(128), blkS4(256);
     if (out_objects && sh_objs) {
       if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
+      else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<true, 2, 2>), gridS, blkS2, 0, st, ra);
       else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<true, 2>), gridT, blkT, 0, st, ra);
+      else if (k6_shared) hipLaunchKernelGGL((k_render_fwd<true, 1, 4>), gridS, blkS4, 0, st, ra);
       else hipLaunchKernelGGL((k_render_fwd<true, 1>), gridT, blkT, 0, st, ra);
     } else {
       if (out_objects) F_TRY("objects", hipMemsetAsync(out_objects, 0, sizeof(float) * NUM_OBJ * HW, st));
       if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<false, 4>), gridT, blkT, 0, st, ra);
+      else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 2, 2>), gridS, blkS2, 0, st, ra);
       else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<false, 2>), gridT, blkT, 0, st, ra);
+      else if (k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 1, 4>), gridS, blkS4, 0, st, ra);
       else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
     }
     F_LAUNCH("render forward");

@@ -477,22 +477,29 @@ constexpr float PX_OFF = 1.0e30f;   // y coordinate of a finished / out-of-image
 // NPX = pixels per lane: 4 -> one wave per tile, 2 -> two waves (16x8 halves), 1 -> four waves (16x4 strips).
 // Fewer pixels per wave = shorter dependent chain per list entry and more, smaller work items for the
 // dispatcher to balance (a tile's list length sets its wave's run time); more = staging amortised further.
-template <bool OBJ, int NPX>
-__global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
+// WPB = waves per workgroup: 1 -> every wave is its own workgroup and stages the tile's list for itself; NSUB -> the
+// tile's waves form ONE workgroup and stage each batch (64 entries per wave) once for all of them: the records are
+// gathered once per tile instead of once per wave, at the price of two workgroup barriers per batch.
+template <bool OBJ, int NPX, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
   constexpr int NSUB = PXL / NPX;
-  __shared__ float4 s0[64];
-  __shared__ float4 s1[64];
-  __shared__ float2 s2[64];
-  __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
-  const int lane = threadIdx.x;
+  static_assert(WPB == 1 || WPB == NSUB, "a shared workgroup holds all the waves of a tile");
+  constexpr int BATCH = 64 * WPB;
+  __shared__ float4 s0[BATCH];
+  __shared__ float4 s1[BATCH];
+  __shared__ float2 s2[BATCH];
+  __shared__ float so[OBJ ? BATCH : 1][NUM_OBJ];
+  __shared__ uint32_t salive[WPB];
+  const int lane = threadIdx.x & 63;
+  const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to be
   int item;
   if (a.map_mode == 3) {
-    if ((int)blockIdx.x >= a.ntiles * NSUB) return;
-    const uint32_t sc = a.sched[blockIdx.x / NSUB];
-    item = (int)(sc & SCHED_TILE_MASK) * NSUB + (int)(blockIdx.x % NSUB);
+    if ((int)blockIdx.x * WPB >= a.ntiles * NSUB) return;
+    const uint32_t sc = a.sched[blockIdx.x * WPB / NSUB];
+    item = (int)(sc & SCHED_TILE_MASK) * NSUB + (WPB > 1 ? wv : (int)(blockIdx.x % NSUB));
     set_wave_priority(sc >> 28);
   } else {
-    item = item_of_block((int)blockIdx.x, a.ntiles * NSUB, a.map_mode);
+    item = item_of_block((int)blockIdx.x, a.ntiles * NSUB / WPB, a.map_mode) * WPB + wv;
     if (item >= a.ntiles * NSUB) return;
   }
   const int tile = item / NSUB, sub = item - tile * NSUB;
@@ -523,34 +530,45 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = 0.f;
     }
   }
-  for (uint32_t base = rg.x; base < rg.y && alive; base += 64) {
-    const uint32_t i = base + lane;
+  for (uint32_t base = rg.x; base < rg.y && (WPB > 1 || alive); base += BATCH) {
+    const int slot = (int)threadIdx.x;                    // the batch entry this thread stages
+    const uint32_t i = base + (uint32_t)slot;
     uint32_t mine = 0;
     if (i < rg.y) {
       const uint32_t pv = a.pair_rank[i];
       const uint32_t r = pv & RANK_MASK;
       const float4 c = a.R2[REC * r];
-      mine = ((pv >> RANK_BITS) >> (sub * NPX)) & ((1u << NPX) - 1u);
+      // staged mask bits: this wave's strips (own workgroup) or all four strips of the tile (shared workgroup)
+      mine = WPB > 1 ? (pv >> RANK_BITS) & 0xFu : ((pv >> RANK_BITS) >> (sub * NPX)) & ((1u << NPX) - 1u);
       const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
-      s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
+      s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = sp.c;
       if (OBJ) {
         const uint32_t og = r;                              // the pair's value IS the Gaussian's storage index
         const float4* src = reinterpret_cast<const float4*>(og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ
                                                                                   : a.sh_objs + (size_t)og * NUM_OBJ);
-        float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
+        float4* dst = reinterpret_cast<float4*>(&so[slot][0]);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
+    } else if (WPB > 1) {
+      s2[slot] = make_float2(0.f, 0.f);                   // past the end of the list: reaches no strip
     }
+    if (WPB > 1) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int jb = 0; jb < BATCH; jb += 64) {              // the batch, 64 entries at a time
+    if (WPB > 1) mine = (__float_as_uint(s2[jb + lane].y) >> (sub * NPX)) & ((1u << NPX) - 1u);
     // entries of the batch that reach this wave's strips: the walk visits only these (an entry of the tile that
     // touches only the other waves' strips costs nothing here)
     uint64_t todo = __ballot(mine != 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (todo != 0ull) {
+    if (todo != 0ull && alive) {
     int j = __builtin_ctzll(todo);
-    float4 n0 = s0[j], n1 = s1[j];
-    float2 n2 = s2[j];
+    float4 n0 = s0[jb + j], n1 = s1[jb + j];
+    float2 n2 = s2[jb + j];
     while (alive) {
       const float4 e0 = n0, e1 = n1;
       const float2 e2 = n2;
@@ -562,9 +580,9 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
       const bool more = jraw >= 0;
       j = jraw & 63;                          // prefetch the next entry while this one is composited
-      n0 = s0[j]; n1 = s1[j]; n2 = s2[j];
-      const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) & alive;
-      const uint32_t pos = base - rg.x + jc + 1;
+      n0 = s0[jb + j]; n1 = s1[jb + j]; n2 = s2[jb + j];
+      const uint32_t m = (__builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) >> (WPB > 1 ? sub * NPX : 0)) & alive;
+      const uint32_t pos = base - rg.x + (uint32_t)(jb + jc) + 1;
       if (m != 0u) {
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
@@ -599,7 +617,7 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
           if (OBJ) {
 #pragma unroll
-            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[jc][c], w, O[k][c]);
+            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[jb + jc][c], w, O[k][c]);
           }
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
@@ -615,14 +633,23 @@ __global__ void __launch_bounds__(64) k_render_fwd(RenderArgs a) {
       if (!more) break;
     }
     }
-    __builtin_amdgcn_wave_barrier();
+    if (WPB == 1) __builtin_amdgcn_wave_barrier();
     if (!OBJ && rec0 != SEG_NONE) {
-      const uint32_t pos_end = base - rg.x + 64u;       // list positions 1 .. pos_end are behind us
+      const uint32_t pos_end = base - rg.x + (uint32_t)jb + 64u;   // list positions 1 .. pos_end are behind us
       if ((pos_end & seg_mask) == 0u && pos_end < rg.y - rg.x) {
         float4* rec = a.bnd + ((size_t)(rec0 + (pos_end >> a.seg_shift) - 1u) * PXL + sub * NPX) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < NPX; ++k) rec[k * 64] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
       }
+    }
+    }
+    if (WPB > 1) {                                        // the workgroup goes on while any of its waves has pixels left
+      if (lane == 0) salive[wv] = alive;
+      __syncthreads();
+      uint32_t any = 0;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) any |= salive[w];
+      if (any == 0u) break;
     }
   }
   if (!OBJ && rec0 != SEG_NONE) {                       // final state of a split tile: record rec0 + nseg - 1

@@ -26,6 +26,7 @@ _lib = None
 
 FLAG_NO_CULL = 1          # GSR_FLAG_NO_CULL (include/gsraster.h)
 FLAG_NO_SEGMENTS = 1 << 16
+FLAG_FWD_SHARED = 1 << 17   # the forward waves of a tile share one staging of the list (opt-in; include/gsraster.h)
 _FLAGS = int(os.environ.get("GSR_FLAGS", "0"), 0)
 
 

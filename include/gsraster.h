@@ -52,11 +52,15 @@ enum {
  *   GSR_FLAG_BWD_SPLIT(n)  n = 2|4   pixels per lane in the backward compositor
  *   GSR_FLAG_TILE_MAP(m)   m = 0..3  block -> tile map: 0 image order, 1 one band per XCD, 2 32-tile bands round
  *                                    robin, 3 longest list first (default)
- *   GSR_FLAG_SEG(n)        n = 1     never split a long tile list over several waves (see gsr_backward) */
+ *   GSR_FLAG_NO_SEGMENTS             never split a long tile list over several waves (see gsr_backward)
+ *   GSR_FLAG_FWD_SHARED              the forward waves of a tile form one workgroup that stages each batch of the list
+ *                                    once for all of them (two or four waves per tile only): 38 % less gather traffic,
+ *                                    14 % slower on the benchmark scene -- off by default */
 #define GSR_FLAG_FWD_SPLIT(n) ((uint32_t)((n) == 1 ? 1u : (n) == 2 ? 2u : (n) == 4 ? 3u : 0u) << 4)
 #define GSR_FLAG_BWD_SPLIT(n) ((uint32_t)((n) == 2 ? 1u : (n) == 4 ? 2u : 0u) << 8)
 #define GSR_FLAG_TILE_MAP(m) ((uint32_t)(((m) & 3u) + 1u) << 12)
 #define GSR_FLAG_NO_SEGMENTS (1u << 16)
+#define GSR_FLAG_FWD_SHARED (1u << 17)
 
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the

@@ -177,7 +177,7 @@ def test_cfg3_nyc_1m_1080p_all_gradients_vs_windowed_oracle():
     rep = compare(out, grads, ro, rgrads, m)
     print("cfg3 windows", wins, "longest list", longest, rep)
     # the same view with long lists NOT split over waves and the other tile splits: same numbers within rounding
-    for flags in (D.FLAG_NO_SEGMENTS, D.flag_fwd_split(4) | D.flag_bwd_split(2), D.flag_fwd_split(1) | D.flag_tile_map(0)):
+    for flags in (D.FLAG_NO_SEGMENTS, D.FLAG_FWD_SHARED, D.flag_fwd_split(4) | D.flag_bwd_split(2), D.flag_fwd_split(1) | D.flag_tile_map(0)):
         out2, grads2 = hip_raw(model, cam, bg.to(dev), gc.to(dev), flags=flags)
         assert (out2["render"] - out["render"]).abs().max().item() <= 2e-6, flags
         compare(out2, grads2, ro, rgrads, m)
@@ -353,9 +353,10 @@ def test_every_tile_split_and_tile_map_against_the_oracle(fwd, bwd):
                                  depth_key=hip_depth_keys(inp, cam, bg))
     gc, _ = O.solid_grads(ref, gc)
     base = None
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4, 5):                       # 4, 5: the tile's forward waves as one workgroup (maps 3, 0)
         try:
-            D.set_flags(D.flag_fwd_split(fwd) | D.flag_bwd_split(bwd) | D.flag_tile_map(mode))
+            shared = D.FLAG_FWD_SHARED if mode >= 4 else 0
+            D.set_flags(D.flag_fwd_split(fwd) | D.flag_bwd_split(bwd) | D.flag_tile_map((3, 0)[mode - 4] if mode >= 4 else mode) | shared)
             color, radii, _, grads = run_hip(inp, cam, bg, gc)
         finally:
             D.set_flags(0)
