@@ -178,3 +178,29 @@ def test_hydrant_full_800px_sh_gradients():
     # degree-1 terms through the same dL/drgb -> both vanish on exactly the same (invisible) Gaussians
     vis = out["radii"] > 0
     assert g["f_dc"][~vis].abs().max().item() == 0.0 and g["f_rest"][~vis].abs().max().item() == 0.0
+
+
+def test_nyc_two_parameter_sets_render_as_the_concatenated_scene_at_full_size(nyc):
+    """gsr_forward_raw2 at BASELINE size: an attacked target (400 003 Gaussians) beside a frozen background (the other
+    599 997) gives the image and the radii of the one-million-Gaussian scene they concatenate to, bit for bit, with
+    and without the object channels (reference attack.py:513-530 builds that scene with seven torch.cat per
+    iteration and never differentiates its render)."""
+    D, dev, model, cam, gc = nyc
+    from gsplat_attack.renderer import PipelineParams, render, render_pair
+    P = model.get_xyz.shape[0]
+    cut = 400_003                                          # not a multiple of 64: one wave reads both sets
+    mask = torch.zeros(P, dtype=torch.bool, device=dev)
+    mask[:cut] = True
+    target, background = model.clone(), model.clone()
+    target.removal_setup(~mask)
+    background.removal_setup(mask)
+    bg = torch.tensor([0.2, 0.4, 0.1], device=dev)
+    for objects in (False, True):
+        pipe = PipelineParams(skip_objects=not objects)
+        with torch.no_grad():
+            ref = render(cam, model, pipe, bg)
+            got = render_pair(cam, target, background, pipe, bg)
+        assert torch.equal(ref["render"], got["render"])
+        assert torch.equal(ref["radii"], got["radii"]) and got["radii"].numel() == P
+        if objects:
+            assert torch.equal(ref["render_object"], got["render_object"])
