@@ -71,3 +71,17 @@ def test_scene_loads_the_highest_iteration_and_saves(tmp_path):
     assert os.path.exists(out) and GaussianModel.load_ply(out)._xyz.shape[0] == 25
     with pytest.raises(ValueError):
         Scene(str(tmp_path / "nowhere"))
+
+
+def test_importing_the_package_asks_for_eight_hardware_queues(monkeypatch):
+    """View pipelining deals a batch over four HIP streams; the runtime's default of four hardware queues makes them
+    share queues (gsplat_attack/__init__.py).  A value chosen by the user is left alone."""
+    import importlib
+    import os
+    import gsplat_attack
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(gsplat_attack)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    importlib.reload(gsplat_attack)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") == "2"
