@@ -324,7 +324,7 @@ def main():
         valu = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2>",
+            kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2, 1>",
                     "preprocess_bwd": "void gsr::k_pre_bwd<true, true>",
                     "preprocess": "void gsr::k_pre_fwd<true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):

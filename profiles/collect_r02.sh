@@ -9,9 +9,12 @@ R=$PWD
 OUT=$R/gpurun_out/r02
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/bench_stats.json 2> $OUT/bench_stats.err
+# kernel statistics over a run whose launches are almost all inside the timed region (300 steps), so that the average
+# duration of K7 is comparable with the bench line's live figure (r02_bench_under_rocprof.json is this run's line)
+STATS="python3 bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $STATS > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 # the same with ONE stream: kernel durations without other views' kernels beside them
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $BENCH --streams 1 > $OUT/bench_stats1.json 2> $OUT/bench_stats1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $STATS --streams 1 > $OUT/bench_stats1.json 2> $OUT/bench_stats1.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- $BENCH > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- $BENCH > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/sq -o q -- $BENCH > /dev/null 2> $OUT/sq.err
