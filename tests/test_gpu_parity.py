@@ -268,6 +268,32 @@ def test_footprint_cull_changes_nothing(scene):
             assert torch.equal(g0[k], g1[k]), f"gradient {k} differs between culled and full pair lists"
 
 
+@pytest.mark.parametrize("fwd", [1, 2])
+def test_forward_waves_of_a_tile_as_one_workgroup_give_the_same_bits(fwd):
+    """GSR_FLAG_FWD_SHARED (k_render_fwd<.,NPX,WPB>: one staging of the list per tile instead of one per wave) against
+    the default, with the 16 object channels composited too: image, object map, radii and every gradient bit for
+    bit -- the walk of each wave is the same, only who gathers the records differs."""
+    D = _hip()
+    model, cams, _ = _scene("nyc-1M", P=30000, width=400, height=240, n_views=1)
+    cam = cams[0]
+    inp = model_inputs(model)
+    gc = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(11))
+    res = {}
+    try:
+        for name, flags in (("own", D.flag_fwd_split(fwd)), ("shared", D.flag_fwd_split(fwd) | D.FLAG_FWD_SHARED)):
+            D.set_flags(flags)
+            res[name] = run_hip(inp, cam, torch.tensor([0.4, 0.1, 0.2]), gc)
+    finally:
+        D.set_flags(0)
+    c0, r0, o0, g0 = res["own"]
+    c1, r1, o1, g1 = res["shared"]
+    assert o0 is not None and float(o0.abs().max()) > 0
+    assert torch.equal(c0, c1) and torch.equal(r0, r1) and torch.equal(o0, o1)
+    for k in g0:
+        if g0[k] is not None:
+            assert torch.equal(g0[k], g1[k]), k
+
+
 def _render_grads(fused: bool, objects: bool, cam_i=0):
     from gsplat_attack.renderer import PipelineParams, render
     _hip()
