@@ -12,7 +12,7 @@ model, cams, spec = make_scene("nyc-1M", device=dev, n_views=8)
 pipe = PipelineParams(skip_objects=True)
 bg = torch.zeros(3, device=dev)
 gc = torch.randn(3, cams[0].image_height, cams[0].image_width, device=dev)
-ring = StreamRing(3, dev)
+ring = StreamRing(4, dev)
 def run(n):
     for i in range(n):
         with ring.next():
