@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -70,8 +72,20 @@ struct Pool {
 };
 
 constexpr int MAX_DEV = 32;
-constexpr size_t POOL_SOFT_CAP = size_t(24) << 30;   // of 288 GB: beyond this, free blocks of other streams are re-used
 Pool g_pool[MAX_DEV];
+
+// Soft cap of a device's pool: beyond it, free blocks last used on OTHER streams are re-used (behind a host-side wait
+// for that stream) instead of allocating more.  An eighth of the device's memory (36 GB of an MI355X's 288 GB), at
+// least 2 GB; GSR_POOL_CAP_MB overrides.
+size_t pool_soft_cap() {
+  static const size_t cap = [] {
+    if (const char* e = getenv("GSR_POOL_CAP_MB")) { const long long v = atoll(e); if (v > 0) return (size_t)v << 20; }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); return size_t(24) << 30; }
+    return std::max<size_t>(total_b / 8, size_t(2) << 30);
+  }();
+  return cap;
+}
 
 int cur_dev() {
   int d = 0;
@@ -94,7 +108,7 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
     int& slot = (b.stream == st) ? best : other;
     if (slot < 0 || b.bytes < pl.blocks[slot].bytes) slot = (int)i;
   }
-  if (best < 0 && other >= 0 && pl.total + bytes > POOL_SOFT_CAP) {
+  if (best < 0 && other >= 0 && pl.total + bytes > pool_soft_cap()) {
     (void)hipStreamSynchronize(pl.blocks[other].stream);   // cross-stream reuse: wait for the old user
     best = other;
   }
@@ -107,6 +121,7 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
   void* p = nullptr;
   // leave head-room so that a slowly growing pair count re-uses the block instead of reallocating
   const size_t want = bytes + bytes / 8;
+  size_t got = want;                                     // what the device allocation really holds
   if (hipMalloc(&p, want) != hipSuccess) {
     (void)hipGetLastError();
     if (other >= 0) {                                    // out of memory: take the other stream's block
@@ -125,13 +140,17 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
       pl.total -= b.bytes;
     }
     pl.blocks.swap(keep);
-    if (hipMalloc(&p, want) != hipSuccess && hipMalloc(&p, bytes) != hipSuccess) {
+    if (hipMalloc(&p, want) != hipSuccess) {
       (void)hipGetLastError();
-      return nullptr;
+      got = bytes;                                       // no head-room left: the block is recorded at its true size
+      if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
     }
   }
-  pl.blocks.push_back(Block{p, want, st, true});
-  pl.total += want;
+  pl.blocks.push_back(Block{p, got, st, true});
+  pl.total += got;
   return p;
 }
 
@@ -162,26 +181,147 @@ struct SlabPlan {
   void add(size_t n) { bytes = ((bytes + 255) & ~size_t(255)) + n * sizeof(T); }
 };
 
-// pinned host word + event for the one D2H read per forward (per calling thread and device)
-thread_local uint32_t* t_pinned[MAX_DEV] = {nullptr};
-thread_local hipEvent_t t_count_event[MAX_DEV] = {nullptr};
+// Host-visible slot of ONE forward's pair count.  The kernel that computes the count (k_storage_scan_hist) stores it
+// straight into this pinned, device-mapped host memory and then stores the forward's token behind a system-scope fence;
+// the host polls the token.  No copy and no event sits in the stream for it (a 32-byte device-to-host copy is a blit
+// kernel plus an event: ~15 us of the forward's critical path, measured).  Slots are pooled and belong to a forward (its
+// context, or the call itself when no context is kept), not to the calling thread.
+enum { HS_N64 = 0, HS_OVF = 2, HS_TOKEN = 3 };
+struct CountSlot {
+  volatile uint32_t* host = nullptr;     // 16 words, pinned + mapped
+  uint32_t* dev = nullptr;               // the same memory as the device sees it
+  uint32_t token = 0;                    // what the forward that owns the slot will write last
+};
+std::mutex g_slot_mu;
+std::vector<CountSlot> g_free_slots;
+std::atomic<uint32_t> g_token{1};
 
-uint32_t* pinned_word(int dev) {
-  if (!t_pinned[dev]) {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
-    t_pinned[dev] = static_cast<uint32_t*>(p);
+bool slot_get(CountSlot& s) {
+  bool have = false;
+  {
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    if (!g_free_slots.empty()) { s = g_free_slots.back(); g_free_slots.pop_back(); have = true; }
   }
-  return t_pinned[dev];
+  if (!have) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return false; }
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return false; }
+    s.host = static_cast<volatile uint32_t*>(p);
+    s.dev = static_cast<uint32_t*>(d);
+    s.host[HS_TOKEN] = 0u;
+  }
+  uint32_t t = g_token.fetch_add(1);
+  if (t == 0u) t = g_token.fetch_add(1);
+  s.token = t;
+  return true;
 }
 
-hipEvent_t count_event(int dev) {
-  if (!t_count_event[dev]) {
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    t_count_event[dev] = e;
+void slot_put(CountSlot& s) {
+  if (!s.host) return;
+  std::lock_guard<std::mutex> lk(g_slot_mu);
+  g_free_slots.push_back(s);
+  s = CountSlot{};
+}
+
+inline bool slot_landed(const CountSlot& s) { return s.host[HS_TOKEN] == s.token; }
+
+// Waits until the forward that owns the slot has published its count: spins briefly (the write lands a few tens of
+// microseconds after the forward's first kernels), then yields; falls back to a stream synchronise after two seconds.
+bool slot_wait(const CountSlot& s, hipStream_t st) {
+  for (int i = 0; i < 4000; ++i) {
+    if (slot_landed(s)) return true;
+    __builtin_ia32_pause();
   }
-  return t_count_event[dev];
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!slot_landed(s)) {
+    std::this_thread::yield();
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      if (hipStreamSynchronize(st) != hipSuccess) return false;
+      return slot_landed(s);
+    }
+  }
+  return true;
+}
+
+// Pair counts seen by earlier forwards, per (device, P, H, W): the capacity guess of an asynchronous-count forward
+// (GSR_FLAG_ASYNC_COUNT).  An entry is dropped when a forward overflowed its guess, so the next one counts synchronously.
+struct CapKey { int dev, P, H, W; };
+struct CapEntry { CapKey k; unsigned long long n; };
+std::mutex g_cap_mu;
+std::vector<CapEntry> g_caps;
+
+bool cap_lookup(const CapKey& k, unsigned long long& n) {
+  std::lock_guard<std::mutex> lk(g_cap_mu);
+  for (const CapEntry& e : g_caps)
+    if (e.k.dev == k.dev && e.k.P == k.P && e.k.H == k.H && e.k.W == k.W) { n = e.n; return true; }
+  return false;
+}
+
+void cap_store(const CapKey& k, unsigned long long n, bool erase) {
+  std::lock_guard<std::mutex> lk(g_cap_mu);
+  for (size_t i = 0; i < g_caps.size(); ++i) {
+    const CapKey& q = g_caps[i].k;
+    if (q.dev == k.dev && q.P == k.P && q.H == k.H && q.W == k.W) {
+      if (erase) { g_caps[i] = g_caps.back(); g_caps.pop_back(); }
+      else g_caps[i].n = n;
+      return;
+    }
+  }
+  if (!erase) {
+    if (g_caps.size() >= 256) g_caps.clear();
+    g_caps.push_back(CapEntry{k, n});
+  }
+}
+
+// Side stream of a caller stream: K1's colour half (SH -> RGB, the bulk of K1's bytes) runs there, beside the binning
+// chain of the same view, and is joined before the forward compositor.  One side stream + two events per
+// (device, caller stream), created on first use and kept.
+struct SideStream { int dev; hipStream_t main, side; hipEvent_t fork, join; };
+std::mutex g_side_mu;
+std::vector<SideStream> g_sides;
+
+bool side_stream_for(int dev, hipStream_t main, SideStream& out) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (const SideStream& s : g_sides)
+    if (s.dev == dev && s.main == main) { out = s; return true; }
+  SideStream s{dev, main, nullptr, nullptr, nullptr};
+  // lowest priority: its one kernel (SH -> RGB) has the whole binning chain's duration to finish in, and must not take
+  // wave slots from the chain's short kernels, which sit on the view's critical path
+  int least = 0, greatest = 0;
+  static const int prio_env = [] { const char* e = getenv("GSR_SIDE_PRIORITY"); return e ? atoi(e) : 1; }();
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+  if (hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, prio_env ? least : 0) != hipSuccess ||
+      hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  g_sides.push_back(s);
+  out = s;
+  return true;
+}
+
+// Count slots of forwards whose context was released before the copy landed (forward-only calls with an asynchronous
+// count): harvested, without blocking, at the start of later forwards.
+struct PendingSlot { CountSlot slot; CapKey key; };
+std::mutex g_pending_mu;
+std::vector<PendingSlot> g_pending;
+
+void pending_harvest() {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  for (size_t i = 0; i < g_pending.size();) {
+    PendingSlot& ps = g_pending[i];
+    if (slot_landed(ps.slot)) {
+      const unsigned long long n = (unsigned long long)ps.slot.host[HS_N64] | ((unsigned long long)ps.slot.host[HS_N64 + 1] << 32);
+      cap_store(ps.key, n, ps.slot.host[HS_OVF] != 0u);
+      slot_put(ps.slot);
+      g_pending[i] = g_pending.back();
+      g_pending.pop_back();
+    } else {
+      ++i;
+    }
+  }
 }
 
 // ---- per-stage profiling (process-wide: autograd runs backward on its own thread) ------------------
@@ -230,7 +370,14 @@ struct GsrCtx {
   GsrSettings st{};
   int P = 0, K = 0;
   int gridx = 0, gridy = 0, ntiles = 0;
-  uint32_t N = 0;
+  // Pairs: `nbound` is what the host sized every pair-proportional buffer and grid for -- the exact count when the
+  // forward waited for it, the capacity guess of an asynchronous-count forward otherwise; the device-side count lives
+  // in dv[DV_N] and reaches the host through `slot` (n_known: already read).
+  uint32_t nbound = 0;
+  bool n_known = false, overflow = false;
+  unsigned long long n64 = 0;
+  CountSlot slot;
+  hipStream_t fwd_stream = nullptr;   // the forward's stream (fallback of the count wait)
   // inputs (owned by the caller)
   bool raw = false;              // inputs are raw parameters (gsr_forward_raw)
   const float* sh_dc = nullptr;  // raw: _features_dc
@@ -243,11 +390,9 @@ struct GsrCtx {
   float4* bnd = nullptr;
   uint32_t* segoff = nullptr;
   uint2* rec_item = nullptr;
-  uint32_t* nrec = nullptr;
   uint32_t seg_shift = 0, rec_cap = 0;
   size_t keep_bytes = 0;
-  float4 *R0 = nullptr, *R1 = nullptr, *R2 = nullptr;   // splat records in depth order
-  float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // the same in storage order
+  float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // splat records, storage order (the compositors gather them)
   float* D = nullptr;             // [P,9] d rgb / d view direction (lane-group kernels, SH input, backward expected)
   bool lanegroup = false;         // K1 ran as k_pre_fwd: K8+K9 runs as k_pre_bwd
   uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
@@ -255,8 +400,21 @@ struct GsrCtx {
   uint32_t* sched = nullptr;      // [ntiles] tiles longest-list-first + priority class
   float* final_T = nullptr;
   uint32_t* n_contrib = nullptr;
-  unsigned long long* total64 = nullptr;   // exact (64-bit) number of pairs of the tile rects
+  uint32_t* dv = nullptr;         // device-side scalars of this forward (gsr_sort.hip.h: DV_*)
 };
+
+// Host copy of the forward's device-side scalars: waits for the (early) copy if it has not landed yet.
+static int ctx_resolve_count(GsrCtx* c) {
+  if (c->n_known || !c->slot.host) return GSR_OK;
+  if (!slot_wait(c->slot, c->fwd_stream)) return GSR_ERR_DEVICE;
+  c->n64 = (unsigned long long)c->slot.host[HS_N64] | ((unsigned long long)c->slot.host[HS_N64 + 1] << 32);
+  c->overflow = c->slot.host[HS_OVF] != 0u;
+  c->n_known = true;
+  const CapKey key{c->dev, c->P, c->st.image_height, c->st.image_width};
+  cap_store(key, c->n64, c->overflow);
+  slot_put(c->slot);
+  return GSR_OK;
+}
 
 static ViewArgs view_args(const GsrSettings& s) {
   ViewArgs va;
@@ -285,6 +443,15 @@ const char* gsr_last_error(void) { return g_err; }
 
 void gsr_ctx_free(GsrCtx* c) {
   if (!c) return;
+  if (c->slot.host) {                  // the count was never looked at: take it if it has landed, else leave the slot
+    if (slot_landed(c->slot)) {                            // to be harvested by a later forward (no host wait here)
+      (void)ctx_resolve_count(c);
+    } else {
+      std::lock_guard<std::mutex> lk(g_pending_mu);
+      g_pending.push_back(PendingSlot{c->slot, CapKey{c->dev, c->P, c->st.image_height, c->st.image_width}});
+      c->slot = CountSlot{};
+    }
+  }
   pool_free(c->dev, c->keep_blk);
   pool_free(c->dev, c->rank_blk);
   pool_free(c->dev, c->seg_blk);
@@ -348,11 +515,25 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->raw = raw; c->sh_dc = sh_dc;
 
   const size_t Pp = (size_t)std::max(P, 1);
+  pending_harvest();
+  // Asynchronous pair count (GSR_FLAG_ASYNC_COUNT, or GSR_ASYNC_COUNT=1 in the environment): the host does not wait
+  // for the pair count; buffers and grids are sized from the count an earlier forward of the same (P, H, W) saw, with
+  // head-room.  Without such an entry this forward counts synchronously (and leaves the entry behind).
+  static const int async_env = [] { const char* e = getenv("GSR_ASYNC_COUNT"); return e ? atoi(e) : 0; }();
+  unsigned long long cap_pairs = MAX_PAIRS - 1;
+  bool async_count = false;
+  if (P > 0 && (async_env != 0 || (s->flags & GSR_FLAG_ASYNC_COUNT))) {
+    unsigned long long seen = 0;
+    if (cap_lookup(CapKey{dev, P, H, W}, seen)) {
+      cap_pairs = std::min<unsigned long long>(seen + seen / 4 + 65536ull, MAX_PAIRS - 1);
+      async_count = true;
+    }
+  }
   // ---- kept slab ---------------------------------------------------------------------------
   SlabPlan kp;
   kp.add<float4>(3 * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
-  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<unsigned long long>(2); kp.add<uint32_t>(ntiles);
+  kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<uint32_t>(DV_WORDS); kp.add<uint32_t>(ntiles);
   // the SH layouts the reference uses (and precomputed colours) take the lane-group kernels
   c->lanegroup = raw || (shs && K == 16) || colors_precomp != nullptr;
   const bool want_D = c->lanegroup && shs != nullptr && ctx_out != nullptr;
@@ -360,11 +541,13 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
-  const uint32_t tblP = radix_table_words((uint32_t)Pp);
+  const uint32_t nbP = (uint32_t)((Pp + DCHUNK - 1) / DCHUNK);             // chunks of the storage scan / depth sort
+  const uint32_t nk1 = (uint32_t)((Pp + PREG_BLOCK - 1) / PREG_BLOCK);     // workgroups of K1's geometry half
+  const uint32_t nkc = (uint32_t)((Pp + PREF_BLOCK - 1) / PREF_BLOCK);     // ... of its colour half
   SlabPlan sp;
-  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey a/b, order b, tcnt
-  sp.add<uint32_t>(tblP); sp.add<uint32_t>(RS_BINS);
-  sp.add<uint32_t>(Pp / SCAN_CHUNK + 2); sp.add<unsigned long long>(Pp / SCAN_CHUNK + 2);
+  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey, k1, vtmp, v2, tcnt
+  sp.add<uint32_t>((size_t)RS_BINS_DEV * nbP); sp.add<uint32_t>(RS_BINS_DEV);
+  sp.add<uint4>(nk1); sp.add<uint32_t>(nbP + 2);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
     pool_free(dev, scratch_blk);
@@ -373,23 +556,25 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   }
   Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
   c->G0 = ks.take<float4>(3 * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;   // interleaved 48-byte records
-  c->R0 = c->G0; c->R1 = c->G1; c->R2 = c->G2;                              // the compositors gather them by Gaussian index
   c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
-  c->total64 = ks.take<unsigned long long>(2);
+  c->dv = ks.take<uint32_t>(DV_WORDS);
   c->sched = ks.take<uint32_t>(ntiles);
   if (want_D) c->D = ks.take<float>(9 * Pp);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
-  uint32_t* dkeyA = ss.take<uint32_t>(Pp); uint32_t* dkeyB = ss.take<uint32_t>(Pp); uint32_t* orderB = ss.take<uint32_t>(Pp);
-  uint32_t* tcnt = ss.take<uint32_t>(Pp);
-  uint32_t* table = ss.take<uint32_t>(tblP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS);
-  uint32_t* psums = ss.take<uint32_t>(Pp / SCAN_CHUNK + 2);
-  unsigned long long* psums64 = ss.take<unsigned long long>(Pp / SCAN_CHUNK + 2);
+  uint32_t* dkey = ss.take<uint32_t>(Pp); uint32_t* k1 = ss.take<uint32_t>(Pp); uint32_t* vtmp = ss.take<uint32_t>(Pp);
+  uint32_t* v2 = ss.take<uint32_t>(Pp); uint32_t* tcnt = ss.take<uint32_t>(Pp);
+  uint32_t* table = ss.take<uint32_t>((size_t)RS_BINS_DEV * nbP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS_DEV);
+  uint4* bout = ss.take<uint4>(nk1);
+  uint32_t* psums = ss.take<uint32_t>(nbP + 2);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
   void* tbl_blk = nullptr;
+  SideStream side{};
+  bool side_used = false;
   auto fail = [&](int code) {
+    if (side_used) (void)hipStreamWaitEvent(st, side.join, 0);   // nothing of this forward may outlive its workspace
     pool_free(dev, scratch_blk);
     pool_free(dev, tbl_blk);
     for (void* b : pairs_blk) if (b && b != c->rank_blk) pool_free(dev, b);
@@ -409,95 +594,133 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
 
   const ViewArgs va = view_args(*s);
   const dim3 blk(256);
-  const dim3 gridP((unsigned)((Pp + 255) / 256));
-  const dim3 blkPre(PRE_BLOCK), gridPre((unsigned)((Pp + PRE_BLOCK - 1) / PRE_BLOCK));
-  uint32_t N = 0;
+  const dim3 blkPre(PREG_BLOCK), gridPre(nk1), blkCol(PREF_BLOCK), gridCol(nkc);
+  const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
+  uint32_t nbound = 0;
   if (P > 0) {
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
+      PreBlockOut bo;
+      bo.bout = bout;
+      bo.ranges = P >= ntiles ? c->ranges : nullptr;      // the tile ranges are cleared by K1's first threads
+      bo.ntiles = ntiles;
+      if (!bo.ranges) {                                   // fewer Gaussians than tiles: spans (0xFFFFFFFF, 0) by two fills
+        F_TRY("ranges", hipMemset2DAsync(c->ranges, sizeof(uint2), 0xFF, sizeof(uint32_t), ntiles, st));
+        F_TRY("ranges", hipMemset2DAsync(reinterpret_cast<char*>(c->ranges) + sizeof(uint32_t), sizeof(uint2), 0, sizeof(uint32_t), ntiles, st));
+      }
       if (c->lanegroup) {
         PreArgs pa;
         pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
         pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
-        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkeyA; pa.tcnt = tcnt;
+        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt;
         pa.Pa = segb ? P - segb->Pb : P;
         pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
         pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
         pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
-        if (raw) hipLaunchKernelGGL((k_pre_fwd<true>), gridPre, blkPre, 0, st, pa);
-        else hipLaunchKernelGGL((k_pre_fwd<false>), gridPre, blkPre, 0, st, pa);
+        pa.cull = cull; pa.bo = bo;
+        if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
+        if (!colors_precomp) {
+          // colour half: on the side stream unless the caller turned that off (GSR_FLAG_NO_SIDE_STREAM / GSR_SIDE_STREAM=0)
+          static const int side_env = [] { const char* e = getenv("GSR_SIDE_STREAM"); return e ? atoi(e) : 1; }();
+          hipStream_t cs = st;
+          if (side_env != 0 && !(s->flags & GSR_FLAG_NO_SIDE_STREAM) && side_stream_for(dev, st, side)) {
+            F_TRY("side stream", hipEventRecord(side.fork, st));
+            F_TRY("side stream", hipStreamWaitEvent(side.side, side.fork, 0));
+            cs = side.side;
+            side_used = true;
+          }
+          if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridCol, blkCol, 0, cs, pa);
+          else hipLaunchKernelGGL((k_pre_color<false>), gridCol, blkCol, 0, cs, pa);
+          if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
+        }
       } else
-        hipLaunchKernelGGL((k_preprocess<false, false>), gridPre, blkPre, 0, st, P, K, va, means3D, scales, rotations,
-                           cov3D_precomp, opacities, shs, sh_dc, colors_precomp, radii, G0, G1, G2, dkeyA, tcnt);
-      // storage-order numbering of the (tile, Gaussian) pairs: where the backward puts its partial rows
-      scan_exclusive_u32(tcnt, c->offg, (uint32_t)P, psums, c->offg + P, st, psums64, c->total64);
+        hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, cull, means3D, scales, rotations, cov3D_precomp,
+                           opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
+      // storage-order numbering of the pairs (where the backward puts its partial rows), the depth sort's digit width
+      // and first histogram, the device-side pair count -- published to the host slot by the kernel itself: one launch
+      if (!slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
+      c->fwd_stream = st;
+      hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint32_t*)dkey,
+                         (const uint4*)bout, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
       F_LAUNCH("preprocess");
     }
-    // The total of that scan IS the pair count N the host needs to size the sort buffers.  Start its read-back
-    // now and wait for it only after the depth sort / gather / scan below are enqueued: the GPU keeps working
-    // while the host learns N, instead of idling through a stream synchronise later.
-    uint32_t* pinned = pinned_word(dev);
-    hipEvent_t n_ready = count_event(dev);
-    if (!pinned || !n_ready) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host word / event allocation failed"));
-    // one 8-byte copy: the exact 64-bit total (N is its low word once it is known to be below 2^31)
-    F_TRY("read pair count", hipMemcpyAsync(pinned + 2, c->total64, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    F_TRY("read pair count", hipEventRecord(n_ready, st));
-    uint32_t* skey;
     {
       StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-      // stable argsort of the depth keys: order[r] = Gaussian index of depth rank r
-      const int res = radix_sort_pairs(dkeyA, c->order, dkeyB, orderB, (uint32_t)P, 0, 32, true, table, tsums, st);
+      // Stable argsort of the live depth keys in three passes whose digit width the device chose from the keys' range:
+      // order[r] = Gaussian of depth rank r, r < V = dv[DV_V].  Pass 0 drops the Gaussians that emit nothing (its
+      // histogram came from k_storage_scan_hist), the last pass also gathers cnt[r] = tiles touched by rank r.
+      const uint32_t* nV = c->dv + DV_V;
+      DigitSpec d0{c->dv, 0, 0, 0u}, d1{c->dv, 1, 0, 0u}, d2{c->dv, 2, 0, 0u};
+      radix_pass<RS_BINS_DEV>(dkey, nullptr, k1, vtmp, (uint32_t)P, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
+                              c->dv + DV_V, nullptr, nullptr, st);
+      radix_pass<RS_BINS_DEV>(k1, vtmp, dkey, v2, (uint32_t)P, nV, d1, DROUNDS, table, tsums, true, 0, 0, nullptr, nullptr,
+                              nullptr, st);
+      radix_pass<RS_BINS_DEV>(dkey, v2, nullptr, c->order, (uint32_t)P, nV, d2, DROUNDS, table, tsums, true, 0, 0, nullptr,
+                              tcnt, vtmp, st);
       F_LAUNCH("depth sort");
-      // 4 passes => result back in (dkeyA, c->order); keep the code honest if the pass count changes
-      skey = res ? dkeyB : dkeyA;
-      if (res) F_TRY("depth sort", hipMemcpyAsync(c->order, orderB, sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, st));
     }
-    {
-      StageTimer t(GSR_STAGE_BIN, st);
-      uint32_t* cnt = orderB;   // free again after the sort
-      (void)skey;
-      hipLaunchKernelGGL(k_rank_counts, gridP, blk, 0, st, P, c->order, tcnt, cnt);
-      scan_exclusive_u32(cnt, c->off, (uint32_t)P, psums, c->off + P, st);
-      F_LAUNCH("pack/scan");
-      F_TRY("read pair count", hipEventSynchronize(n_ready));
-      unsigned long long exact = 0;
-      memcpy(&exact, pinned + 2, sizeof(exact));
-      N = (uint32_t)exact;
-      if (exact >= MAX_PAIRS)   // NSUB * N must stay below 2^32
+    if (!async_count) {
+      // (the rank-order scan is enqueued after this wait: it records the owners of the emission chunks' first slots, an
+      // array sized by N; the depth sort keeps the GPU busy well past the host's wake-up)
+      if (ctx_resolve_count(c) != GSR_OK) return fail(set_err(GSR_ERR_DEVICE, "gsr_forward: reading the pair count failed"));
+      if (c->n64 >= MAX_PAIRS)   // NSUB * N must stay below 2^32
         return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: %llu (tile, Gaussian) pairs exceed the supported %llu "
-                            "(splats cover too many tiles: check scales / scale_modifier)", exact, MAX_PAIRS));
+                            "(splats cover too many tiles: check scales / scale_modifier)", c->n64, MAX_PAIRS));
+      nbound = (uint32_t)c->n64;
+    } else {
+      nbound = (uint32_t)cap_pairs;
     }
   } else {
     F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
     F_TRY("init", hipMemsetAsync(c->offg, 0, sizeof(uint32_t), st));
+    F_TRY("init", hipMemsetAsync(c->dv, 0, sizeof(uint32_t) * DV_WORDS, st));
+    F_TRY("ranges", hipMemsetAsync(c->ranges, 0, sizeof(uint2) * ntiles, st));
+    c->n_known = true;
   }
-  c->N = N;
-  F_TRY("ranges", hipMemsetAsync(c->ranges, 0, sizeof(uint2) * ntiles, st));
-  if (N > 0) {
-    const uint32_t tblN = radix_table_words(N);
+  c->nbound = nbound;
+  if (nbound == 0 && P > 0) F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
+  if (nbound > 0) {
+    const int rounds = radix_rounds_for(nbound);
+    const uint32_t chunkN = (uint32_t)rs_chunk(rounds);
+    const uint32_t nbN = (nbound + chunkN - 1) / chunkN;
+    const uint32_t tblN = RS_BINS * nbN;
     for (int i = 0; i < 4; ++i) {
-      pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)N, st);
-      if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", N));
+      pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)nbound, st);
+      if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", nbound));
     }
-    tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS), st);
+    const uint32_t ngrain = nbound / EMIT_GRAIN + 4;            // chunk_first entries
+    tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS + ngrain), st);
     if (!tbl_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: sort table allocation failed"));
     uint32_t* tileA = static_cast<uint32_t*>(pairs_blk[0]); uint32_t* rankA = static_cast<uint32_t*>(pairs_blk[1]);
     uint32_t* tileB = static_cast<uint32_t*>(pairs_blk[2]); uint32_t* rankB = static_cast<uint32_t*>(pairs_blk[3]);
     uint32_t* tableN = static_cast<uint32_t*>(tbl_blk);
     uint32_t* tsumsN = tableN + tblN;
+    uint32_t* chunk_first = tsumsN + RS_BINS;
+    const int tile_bits = ceil_log2((uint32_t)ntiles + 1);   // keys are 0..ntiles (ntiles = culled pair)
     {
       StageTimer t(GSR_STAGE_BIN, st);
-      const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
-      hipLaunchKernelGGL(k_emit, dim3((N + EMIT_SLOTS - 1) / EMIT_SLOTS), blk, 0, st, c->off, c->order, (uint32_t)P, N, c->G0,
-                         c->G1, c->G2, gridx, W, H, (uint32_t)ntiles, cull, tileA, rankA);
+      // off[r] = pairs emitted by the ranks in front of r, off[V] = their total; chunk_first[c] = rank that owns slot
+      // c * EMIT_GRAIN
+      scan_exclusive_u32(vtmp, c->off, (uint32_t)P, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
+      F_LAUNCH("rank scan");
+      int sh0; uint32_t mask0;
+      radix_first_digit(tile_bits, sh0, mask0);
+      if (rounds == RS_ROUNDS_MIN)
+        hipLaunchKernelGGL((k_emit<RS_ROUNDS_MIN>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MIN) / EMIT_PER_THREAD), 0, st, (const uint32_t*)c->off, (const uint32_t*)c->order,
+                           (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
+                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
+      else
+        hipLaunchKernelGGL((k_emit<RS_ROUNDS_MAX>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MAX) / EMIT_PER_THREAD), 0, st, (const uint32_t*)c->off, (const uint32_t*)c->order,
+                           (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
+                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
       F_LAUNCH("emit");
     }
     int res;
     {
       StageTimer t(GSR_STAGE_TILE_SORT, st);
-      // keys are 0..ntiles (ntiles = culled pair): one more value than there are tiles
-      res = radix_sort_pairs(tileA, rankA, tileB, rankB, N, 0, ceil_log2((uint32_t)ntiles + 1), false, tableN, tsumsN, st);
-      hipLaunchKernelGGL(k_ranges, dim3((N + 255) / 256), blk, 0, st, N, (uint32_t)ntiles, res ? tileB : tileA, c->ranges);
+      res = radix_sort_pairs(tileA, rankA, tileB, rankB, nbound, c->dv + DV_N, 0, tile_bits, false, tableN, tsumsN, st, true,
+                             reinterpret_cast<uint32_t*>(c->ranges), (uint32_t)ntiles);
       F_LAUNCH("tile sort");
     }
     c->pair_rank = res ? rankB : rankA;
@@ -507,38 +730,40 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     for (void* b : pairs_blk) if (b != c->rank_blk) pool_free(dev, b);
     for (void*& b : pairs_blk) b = nullptr;
   }
+  if (side_used) F_TRY("side stream", hipStreamWaitEvent(st, side.join, 0));   // the colours are in place from here on
   {
     StageTimer t(GSR_STAGE_RENDER_FWD, st);
     RenderArgs ra;
-    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
+    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->G0; ra.R1 = c->G1; ra.R2 = c->G2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
     ra.sh_objs_b = segb ? segb->objects_dc : nullptr; ra.Pa = segb ? P - segb->Pb : P;
     const int map_mode_f = flag_tile_map(s->flags);
     ra.map_mode = map_mode_f;
     ra.sched = c->sched;
+    ra.dv = async_count ? c->dv : nullptr;
     ra.wave_clock = g_wave_clock_fwd.load();
     // Long tile lists are split into segments for the backward (gsr_kernels.hip.h, "Segments"): the forward stores the
     // per-pixel (T, C) at the segment boundaries.  Not with object channels (their 16 running sums are not stored), not
     // for a forward-only call, not under GSR_FLAG_NO_SEGMENTS.
     static const int seg_shift_env = [] { const char* e = getenv("GSR_SEG_SHIFT"); int v = e ? atoi(e) : 8; return (v >= 6 && v <= 16) ? v : 8; }();
     ra.bnd = nullptr; ra.segoff = nullptr; ra.seg_shift = 0;
-    if (N > 0 && ctx_out && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
-      const uint32_t per = N >> seg_shift_env;
+    if (nbound > 0 && ctx_out && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
+      const uint32_t per = nbound >> seg_shift_env;
       c->seg_shift = (uint32_t)seg_shift_env;
-      c->rec_cap = per + std::min<uint32_t>((uint32_t)ntiles, per) + 1u;   // sum over split tiles of ceil(len / seg)
+      // sum over split tiles of ceil(len / seg) <= N / seg + min(T, N / seg): every split tile's records always fit
+      c->rec_cap = per + std::min<uint32_t>((uint32_t)ntiles, per) + 1u;
       SlabPlan gp;
-      gp.add<float4>((size_t)c->rec_cap * PXL * 64); gp.add<uint2>(c->rec_cap); gp.add<uint32_t>(ntiles); gp.add<uint32_t>(4);
+      gp.add<float4>((size_t)c->rec_cap * PXL * 64); gp.add<uint2>(c->rec_cap); gp.add<uint32_t>(ntiles);
       c->seg_blk = pool_alloc(dev, gp.bytes + 256, st);
-      if (!c->seg_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: segment boundary buffer (N=%u) allocation failed", N));
+      if (!c->seg_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: segment boundary buffer (N=%u) allocation failed", nbound));
       Slab gs{static_cast<char*>(c->seg_blk), gp.bytes + 256, 0};
       c->bnd = gs.take<float4>((size_t)c->rec_cap * PXL * 64); c->rec_item = gs.take<uint2>(c->rec_cap);
-      c->segoff = gs.take<uint32_t>(ntiles); c->nrec = gs.take<uint32_t>(4);
-      F_TRY("segments", hipMemsetAsync(c->rec_item, 0, sizeof(uint2) * c->rec_cap, st));
+      c->segoff = gs.take<uint32_t>(ntiles);
       ra.bnd = c->bnd; ra.segoff = c->segoff; ra.seg_shift = c->seg_shift;
     }
-    if (map_mode_f == 3 || c->bnd)
-      hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift, c->segoff,
-                         c->rec_item, c->rec_cap, c->nrec);
+    // always: it also turns the empty spans the tile sort left untouched into (0, 0)
+    hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift,
+                         c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
     // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
@@ -568,7 +793,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     F_LAUNCH("render forward");
   }
   pool_free(dev, scratch_blk);
-  if (num_rendered) *num_rendered = (int64_t)N;
+  if (num_rendered) *num_rendered = c->n_known ? (int64_t)c->n64 : (int64_t)-1;   // -1: not known yet (asynchronous count)
   if (ctx_out) *ctx_out = c; else gsr_ctx_free(c);
   return GSR_OK;
 #undef F_TRY
@@ -636,7 +861,14 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   // Only colour-side gradients wanted (SH / precomputed colours / object features): K7 and K8+K9 drop the geometry
   // sums and the projection chain rule (the colour attack; BASELINE configs 2 and 3).
   const bool geom = dmeans3D || dmeans2D || dopacities || dscales || drotations || dcov3D;
-  const uint32_t N = c->N;
+  // an asynchronous-count forward: its pair count must have fitted the capacity guess (else the image it produced was
+  // poisoned with NaN and nothing downstream of it is meaningful)
+  if (ctx_resolve_count(c) != GSR_OK) return set_err(GSR_ERR_DEVICE, "gsr_backward: reading the forward's pair count failed");
+  if (c->overflow)
+    return set_err(GSR_ERR_OVERFLOW, "gsr_backward: the forward emitted %llu (tile, Gaussian) pairs, more than the capacity "
+                   "%u guessed from earlier views (GSR_FLAG_ASYNC_COUNT); its image was filled with NaN -- render again",
+                   c->n64, c->nbound);
+  const uint32_t N = c->nbound;
   void* part_blk = nullptr;
   void* pobj_blk = nullptr;
   float4* part = nullptr;
@@ -669,7 +901,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     StageTimer t(GSR_STAGE_RENDER_BWD, st, true);
     RenderBwdArgs ra;
     ra.tag_lo = tag_lo; ra.tag_hi = tag_hi;
-    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->R0; ra.R1 = c->R1; ra.R2 = c->R2;
+    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.offg = c->offg; ra.R0 = c->G0; ra.R1 = c->G1; ra.R2 = c->G2;
     ra.sh_objs = c->sh_objs; ra.bg = c->st.bg; ra.W = c->st.image_width; ra.H = c->st.image_height;
     ra.map_mode = flag_tile_map(c->st.flags);
     ra.sched = c->sched;
@@ -678,7 +910,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
     // split tiles: one extra work item per boundary record, in front of the per-tile items
     const bool segs = c->bnd != nullptr && !obj;
-    ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->nrec;
+    ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->dv + DV_NREC;
     ra.seg_shift = c->seg_shift; ra.extra_blocks = segs ? c->rec_cap * nsub : 0u;
     const dim3 gridT(ra.extra_blocks + (unsigned)render_grid(c->ntiles * (int)nsub)), blk(64);
 #define LAUNCH_K7(kern)                                                                      \
@@ -719,9 +951,6 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
     const dim3 gridK9((unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK));
-    // SH rows of 16 coefficients x 3 channels (the only layout the reference uses) go through LDS
-    const bool sh_lds = c->shs != nullptr && pa.dsh != nullptr && c->K == 16;
-    (void)sh_lds;
     if (c->raw && ((pa.dsh == nullptr) != (pa.dsh_dc == nullptr)))
       return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
     if (c->lanegroup && c->shs && geom && !c->D)
@@ -735,8 +964,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
         else hipLaunchKernelGGL((k_pre_bwd<false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
       }
     } else {
-      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<false, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-      else hipLaunchKernelGGL((k_preprocess_bwd<false, false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      else hipLaunchKernelGGL((k_preprocess_bwd<false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
@@ -788,9 +1017,13 @@ int gsr_query(int32_t what, int64_t* out) {
 int gsr_ctx_info(const GsrCtx* c, int32_t what, int64_t* out) {
   if (!c || !out) return set_err(GSR_ERR_INVALID, "gsr_ctx_info: null argument");
   switch (what) {
-    case 0: *out = (int64_t)c->N; return GSR_OK;
+    case 0:
+      if (ctx_resolve_count(const_cast<GsrCtx*>(c)) != GSR_OK) return set_err(GSR_ERR_DEVICE, "gsr_ctx_info: reading the pair count failed");
+      *out = (int64_t)c->n64;
+      return GSR_OK;
     case 1: *out = -1; return GSR_OK;
-    case 2: *out = (int64_t)(c->keep_bytes + sizeof(uint32_t) * (size_t)c->N); return GSR_OK;
+    case 2: *out = (int64_t)(c->keep_bytes + sizeof(uint32_t) * (size_t)c->nbound); return GSR_OK;
+    case 3: *out = (int64_t)c->nbound; return GSR_OK;
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_info: unknown item %d", what);
   }
 }
@@ -802,13 +1035,18 @@ int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, 
   size_t bytes = 0;
   switch (what) {
     case 0: src = c->ranges; bytes = sizeof(uint2) * (size_t)c->ntiles; break;
-    case 1: src = c->pair_rank; bytes = sizeof(uint32_t) * (size_t)c->N; break;
+    case 1:
+      if (ctx_resolve_count(const_cast<GsrCtx*>(c)) != GSR_OK) return set_err(GSR_ERR_DEVICE, "gsr_ctx_export: reading the pair count failed");
+      src = c->pair_rank; bytes = sizeof(uint32_t) * (size_t)(c->overflow ? 0 : c->n64);
+      break;
     case 2: src = c->n_contrib; bytes = sizeof(uint32_t) * HW; break;
     case 3: src = c->final_T; bytes = sizeof(float) * HW; break;
     case 4: src = c->order; bytes = sizeof(uint32_t) * (size_t)c->P; break;
     case 5: src = c->off; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
-    case 6: src = c->R0; bytes = sizeof(float4) * 3 * (size_t)c->P; break;   // depth-ordered records [P][3] float4
-    case 7: src = c->G0; bytes = sizeof(float4) * 3 * (size_t)c->P; break;   // storage-ordered records
+    case 6:                                                                   // (kept for old callers: same as 7)
+    case 7: src = c->G0; bytes = sizeof(float4) * 3 * (size_t)c->P; break;   // splat records [P][3] float4, storage order
+    case 8: src = c->dv; bytes = sizeof(uint32_t) * DV_WORDS; break;          // device-side scalars (DV_*)
+    case 9: src = c->offg; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_export: unknown item %d", what);
   }
   if ((int64_t)bytes > dst_bytes)
@@ -907,7 +1145,7 @@ int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* strea
   uint32_t* table = v1 + n; uint32_t* sums = table + tbl;
   uint2* cell_range = reinterpret_cast<uint2*>(sums + RS_BINS + (((uintptr_t)(sums + RS_BINS) & 4) ? 1 : 0));
   hipLaunchKernelGGL(k_knn_cells, dim3((n + 255) / 256), dim3(256), 0, st, points, P, g, k0);
-  const int res = radix_sort_pairs(k0, v0, k1, v1, n, 0, ceil_log2(ncells), true, table, sums, st);
+  const int res = radix_sort_pairs(k0, v0, k1, v1, n, nullptr, 0, ceil_log2(ncells), true, table, sums, st);
   const uint32_t* skeys = res ? k1 : k0;
   const uint32_t* sidx = res ? v1 : v0;
   if (ceil_log2(ncells) == 0) {   // a single cell: no pass ran, build the identity permutation by hand
@@ -938,9 +1176,9 @@ int gsr_test_scan(const uint32_t* in, uint32_t* out, uint32_t n, void* stream) {
   if (!in || !out) return set_err(GSR_ERR_INVALID, "gsr_test_scan: null argument");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int dev = cur_dev();
-  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)n / SCAN_CHUNK + 2), st);
+  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)n / 2048 + 2), st);
   if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_test_scan: allocation failed");
-  scan_exclusive_u32(in, out, n, static_cast<uint32_t*>(blk), out + n, st);
+  scan_exclusive_u32(in, out, n, nullptr, static_cast<uint32_t*>(blk), st);
   pool_free(dev, blk);
   LAUNCH_CHECK("test scan");
   return GSR_OK;
@@ -959,7 +1197,7 @@ int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begi
   uint32_t* v1 = k1 + n;
   uint32_t* table = v1 + n;
   uint32_t* sums = table + tbl;
-  const int res = radix_sort_pairs(keys, vals, k1, v1, n, begin_bit, end_bit, iota != 0, table, sums, st);
+  const int res = radix_sort_pairs(keys, vals, k1, v1, n, nullptr, begin_bit, end_bit, iota != 0, table, sums, st);
   if (res) {
     (void)hipMemcpyAsync(keys, k1, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(vals, v1, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st);

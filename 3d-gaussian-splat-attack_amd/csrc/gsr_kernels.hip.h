@@ -4,7 +4,8 @@
 // Data layout in HBM (all float32 / uint32):
 //   G0,G1,G2[REC * g]   per-Gaussian screen geometry written by K1, 3 x float4:
 //                 G0=(px,py,A,B)  G1=(C,opacity,r,g)  G2=(b, depth, rectx_bits, recty_bits)
-//                 rectx_bits = minx | maxx<<12 | clampbits<<24,  recty_bits = miny | maxy<<12   (tile units)
+//                 rectx_bits = minx | maxx<<12,  recty_bits = miny | maxy<<12   (tile units); a colour whose SH sum was
+//                 clamped at 0 is stored as -0.0f (the clamp flag of the backward)
 //   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF when culled
 //   order[r]      Gaussian index of depth rank r (stable radix argsort of dkey)
 //   off[r]        exclusive scan of tiles touched in depth order, off[P] = N (numbers the emitted pairs)
@@ -20,6 +21,7 @@
 #include <stdint.h>
 
 #include "gsr_math.h"
+#include "gsr_sort.hip.h"
 
 namespace gsr {
 
@@ -44,135 +46,102 @@ constexpr int RANK_BITS = 28;                       // pair value = depth rank |
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 
 // ------------------------------------------------------------------------------------------------
-// K1: per-Gaussian preprocess, one thread per Gaussian in storage order.  With the reference's SH layout
-// (16 coefficients x 3 channels = 192 B per Gaussian) each wave first copies its 64 rows into LDS with
-// coalesced float4 loads (rows padded to 13 float4: conflict-free ds_read_b128), then every lane reads its
-// own row from LDS instead of 64 lanes striding through HBM 192 bytes apart.
+// K1 and K8+K9 launch shape.  Their waves never talk to each other about Gaussians (each wave owns 64 of them, wave
+// barriers only); a workgroup is a dispatch granule plus, in K1, the unit that hands the storage-order scan its partial
+// sums: per workgroup the tiles touched by its Gaussians and the smallest / largest live depth key (the depth sort
+// chooses its digit width from that range), so that no separate reduction pass over tcnt / dkey is needed.
 // ------------------------------------------------------------------------------------------------
-constexpr int SHROW_F4 = 13;   // 12 float4 of payload (K = 16) + 1 pad
+constexpr int PRE_WAVES = 1;                 // K8+K9: one wave + its LDS finds room beside other streams' compositing waves
+constexpr int PRE_BLOCK = 64 * PRE_WAVES;
+constexpr int PREF_WAVES = 4;                // K1, colour half
+constexpr int PREF_BLOCK = 64 * PREF_WAVES;
+constexpr int PREG_WAVES = 4;                // K1, geometry half (small workgroups find room beside other streams' compositing waves)
+constexpr int PREG_BLOCK = 64 * PREG_WAVES;
 
-// Copies the SH rows of one wave's Gaussians into LDS rows of SHROW_F4 float4.  RAW: the row is assembled from the
-// reference model's two tensors, _features_dc [P,1,3] and _features_rest [P,15,3] (what get_features concatenates,
-// reference scene/gaussian_model.py:113-116).
-template <bool RAW>
-__device__ __forceinline__ void stage_sh_rows(float4* wrow, const float* sh, const float* sh_dc, int gw0, int nw, int lane,
-                                              uint64_t rowmask) {
-  // rowmask: bit r set = row r is needed (culled Gaussians' coefficients are never read from HBM)
-  if (!RAW) {
-    const float4* src = reinterpret_cast<const float4*>(sh) + (size_t)gw0 * 12;
-    for (int i = lane; i < nw * 12; i += 64) {
-      const int row = i / 12;
-      if ((rowmask >> row) & 1ull) wrow[row * SHROW_F4 + (i - row * 12)] = src[i];
-    }
-  } else {
-    float* wf = reinterpret_cast<float*>(wrow);
-    const float* dc = sh_dc + (size_t)gw0 * 3;
-    for (int i = lane; i < nw * 3; i += 64) {
-      const int row = i / 3;
-      if ((rowmask >> row) & 1ull) wf[row * (4 * SHROW_F4) + (i - row * 3)] = dc[i];
-    }
-    const float* rest = sh + (size_t)gw0 * 45;          // 64*45*4 B per wave: 16-byte aligned
-    const int n4 = (nw * 45) >> 2;
-    const float4* rest4 = reinterpret_cast<const float4*>(rest);
-    for (int i = lane; i < n4; i += 64) {
-      const int ra = (4 * i) / 45, rb = (4 * i + 3) / 45;
-      if (!(((rowmask >> ra) | (rowmask >> rb)) & 1ull)) continue;
-      const float4 v = rest4[i];
-      const float vv[4] = {v.x, v.y, v.z, v.w};
+struct PreBlockOut {
+  uint4* bout;       // [ceil(P / PREG_BLOCK)] per workgroup: (tiles touched, smallest live depth key or 0xFFFFFFFF, largest or 0, -)
+  uint2* ranges;     // [ntiles] set to the empty span (0xFFFFFFFF, 0) here (one tile per thread) when P >= ntiles
+  int ntiles;
+};
+
+// cnt: tiles this thread's Gaussian touches; key: its depth key, 0xFFFFFFFF when it emits nothing
+__device__ __forceinline__ void pre_block_epilogue(const PreBlockOut& o, int g, uint32_t cnt, uint32_t key) {
+  __shared__ uint32_t red[3][PREG_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (o.ranges && g < o.ntiles) o.ranges[g] = make_uint2(0xFFFFFFFFu, 0u);     // (start, end) for atomicMin / atomicMax
+  uint32_t s = cnt, mn = key, mx = key == 0xFFFFFFFFu ? 0u : key;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int e = 4 * i + c, row = e / 45;
-        wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)] = vv[c];
-      }
-    }
-    for (int e = 4 * n4 + lane; e < nw * 45; e += 64) {
-      const int row = e / 45;
-      wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)] = rest[e];
-    }
+  for (int d = 32; d > 0; d >>= 1) {
+    s += (uint32_t)__shfl_xor((int)s, d, 64);
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  }
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = mn; red[2][wave] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ts = 0, tmn = 0xFFFFFFFFu, tmx = 0u;
+#pragma unroll
+    for (int w = 0; w < PREG_WAVES; ++w) { ts += red[0][w]; tmn = min(tmn, red[1][w]); tmx = max(tmx, red[2][w]); }
+    o.bout[blockIdx.x] = make_uint4(ts, tmn, tmx, 0u);
   }
 }
 
-// RAW: scales / rots / opac are the reference model's raw parameters (_scaling = log, _rotation un-normalised,
-// _opacity = logit) and the activation getters (exp, normalize, sigmoid: reference scene/gaussian_model.py:31-39,
-// 97-124) are applied here; `sh` is then _features_rest and `sh_dc` _features_dc.
-// Waves per workgroup of the two per-Gaussian kernels (K1, K8+K9).  Their waves never talk to each other (each stages
-// its own 64 rows in its own LDS slice, wave barriers only), so the workgroup is a dispatch granule, nothing more:
-// one wave + 13 KB of LDS finds room beside another stream's compositing waves far sooner than four + 53 KB.
-constexpr int PRE_WAVES = 1;
-constexpr int PRE_BLOCK = 64 * PRE_WAVES;
-
-template <bool SH_LDS, bool RAW>
-__global__ void __launch_bounds__(PRE_BLOCK) k_preprocess(int P, int K, ViewArgs va, const float* __restrict__ means,
+// ------------------------------------------------------------------------------------------------
+// K1, generic form: one thread per Gaussian in storage order, any SH coefficient count K (the layouts the reference
+// uses -- K = 16, the raw dc | rest pair, precomputed colours -- take k_pre_fwd below).
+// cull != 0: the tile rect is shrunk to the alpha >= 1/255 footprint's bounding box (tighten_rect).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArgs va, int cull, const float* __restrict__ means,
                                                     const float* __restrict__ scales, const float* __restrict__ rots,
                                                     const float* __restrict__ cov3d, const float* __restrict__ opac,
-                                                    const float* __restrict__ sh, const float* __restrict__ sh_dc,
-                                                    const float* __restrict__ colors,
+                                                    const float* __restrict__ sh, const float* __restrict__ colors,
                                                     int32_t* __restrict__ radii, float4* __restrict__ G0,
                                                     float4* __restrict__ G1, float4* __restrict__ G2,
-                                                    uint32_t* __restrict__ dkey, uint32_t* __restrict__ tcnt) {
-  __shared__ float4 srow[SH_LDS ? PRE_WAVES * 64 * SHROW_F4 : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw0 = blockIdx.x * PRE_BLOCK + wave * 64;
-  const int g = gw0 + lane;
-  if (SH_LDS) {
-    // all 64 rows are fetched up front (before the culls are known): issuing the big coalesced loads first and
-    // projecting while they are in flight measured faster than fetching only the survivors' rows afterwards
-    const int nw = min(64, P - gw0);
-    if (nw > 0 && colors == nullptr) stage_sh_rows<RAW>(&srow[wave * 64 * SHROW_F4], sh, sh_dc, gw0, nw, lane, ~0ull);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  const auto one = [&]() -> uint32_t {
-    if (g >= P) return 0u;
+                                                    uint32_t* __restrict__ dkey, uint32_t* __restrict__ tcnt, PreBlockOut bo) {
+  const int g = blockIdx.x * PREG_BLOCK + threadIdx.x;
+  uint32_t cnt = 0, key = 0xFFFFFFFFu;
+  if (g < P) {
     View v;
     load_view(v, va);
     const float p[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float c6[6];
     if (cov3d) {
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < 6; ++i) c6[i] = cov3d[6 * g + i];
     } else {
-      float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+      const float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
       const float4 q4 = reinterpret_cast<const float4*>(rots)[g];
-      float q[4] = {q4.x, q4.y, q4.z, q4.w};
-      if (RAW) {
-        sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
-        float inv_n;
-        act_normalize4(q, q, inv_n);
-      }
+      const float q[4] = {q4.x, q4.y, q4.z, q4.w};
       cov3d_from_scale_rot(sc, va.mod, q, c6);
     }
     Splat s;
     const bool ok = project_splat(v, p, c6, s);
-    if (!ok) {
-      radii[g] = 0;
-      dkey[g] = 0xFFFFFFFFu;
-      tcnt[g] = 0;
-      G2[REC * g] = make_float4(0.f, 0.f, 0.f, 0.f);   // empty rect: emits no pairs
-      return 0u;
+    radii[g] = ok ? s.radius : 0;
+    if (ok) {
+      const float o = opac[g];
+      if (cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, o, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
+      cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
+      if (cnt != 0u) {
+        float rgb[3];
+        uint32_t cl = 0;
+        if (colors) { rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2]; }
+        else cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
+        key = __float_as_uint(s.depth);
+        const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12);
+        const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
+        // a clamped colour is stored as -0.0f: the backward reads the clamp flags off the sign bits
+        if (cl & 1u) rgb[0] = -0.0f;
+        if (cl & 2u) rgb[1] = -0.0f;
+        if (cl & 4u) rgb[2] = -0.0f;
+        G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
+        G1[REC * g] = make_float4(s.C, o, rgb[0], rgb[1]);
+        G2[REC * g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
+      }
     }
-    float rgb[3];
-    uint32_t cl = 0;
-    if (colors) {
-      rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2];
-    } else if (SH_LDS) {
-      cl = sh_to_rgb(va.deg, reinterpret_cast<const float*>(&srow[(wave * 64 + lane) * SHROW_F4]), p, v.cam, rgb);
-    } else {
-      cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
-    }
-    radii[g] = s.radius;
-    dkey[g] = __float_as_uint(s.depth);
-    const uint32_t cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
+    dkey[g] = key;
     tcnt[g] = cnt;
-    const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | (cl << 24);
-    const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
-    G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
-    G1[REC * g] = make_float4(s.C, RAW ? act_sigmoid(opac[g]) : opac[g], rgb[0], rgb[1]);
-  G2[REC * g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
-    return cnt;
-  };
-  (void)one();
+  }
+  pre_block_epilogue(bo, g, cnt, key);
 }
 
 // K10
@@ -185,21 +154,95 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// tiles touched per depth rank (input of the rank-order scan that numbers the emitted pairs).  The splat records stay
-// where K1 wrote them, in storage order: a tile list's consecutive entries are hundreds of ranks apart, so a
-// depth-ordered copy of the records would buy its readers (K6 / K7 gathers) nothing.
+// K2: storage-order numbering of the (tile, Gaussian) pairs + everything the depth sort needs before its first scatter,
+// in ONE launch behind K1.  Block b owns DCHUNK = 2048 Gaussians (= one chunk of the depth sort's first pass):
+//   * its carry is the sum of K1's workgroup sums in front of it (a few thousand L2-resident words, summed redundantly
+//     by every block instead of by a dependent single-block kernel), likewise the global min / max of the live depth keys;
+//   * offg[g] = exclusive scan of tiles touched in storage order (numbers the backward's partial rows; offg[P] = total);
+//   * the digit width w of the depth sort from the key range, and this chunk's histogram of the first digit of the live
+//     keys (culled Gaussians are not counted: the first scatter pass drops them), written to the radix table;
+//   * the last block publishes the device-side scalars: pair count (exact 64-bit, and the 32-bit count the rest of
+//     the forward uses -- 0 with the overflow flag set when it exceeds `cap` or 2^31), kmin, w.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rank_counts(int P, const uint32_t* __restrict__ order,
-                                                     const uint32_t* __restrict__ tcnt, uint32_t* __restrict__ cnt) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < P) cnt[r] = tcnt[order[r]];          // culled Gaussians (all at the tail of the order): 0
+constexpr int DROUNDS = RS_ROUNDS_MIN;               // the depth sort always works in 2048-key chunks (LDS: 2048 bins)
+constexpr int DCHUNK = rs_chunk(DROUNDS);
+constexpr int DITEMS = DCHUNK / 256;
+static_assert(DCHUNK % PREG_BLOCK == 0, "a scan chunk covers whole K1 workgroups");
+
+__global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uint32_t* __restrict__ tcnt,
+                                                           const uint32_t* __restrict__ dkey,
+                                                           const uint4* __restrict__ bout, uint32_t* __restrict__ offg,
+                                                           uint32_t* __restrict__ table, uint32_t nb,
+                                                           uint32_t* __restrict__ dv, unsigned long long cap,
+                                                           uint32_t* host_slot, uint32_t host_token) {
+  __shared__ uint32_t tmp[4];
+  __shared__ unsigned long long tmp64[4];
+  __shared__ uint32_t h[RS_BINS_DEV];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t base = b * DCHUNK + tid * DITEMS;
+  // this chunk's tiles-touched counts and depth keys are requested first: they do not depend on the reduction below
+  uint32_t v[DITEMS], kk[DITEMS];
+#pragma unroll
+  for (int i = 0; i < DITEMS; ++i) {
+    const bool in = base + i < P;
+    v[i] = in ? tcnt[base + i] : 0u;
+    kk[i] = in ? dkey[base + i] : RS_DROP_KEY;
+  }
+  const uint32_t nk1 = (P + PREG_BLOCK - 1) / PREG_BLOCK;
+  const uint32_t front = b * (DCHUNK / PREG_BLOCK);     // K1 workgroups in front of this chunk
+  uint32_t part = 0, mn = 0xFFFFFFFFu, mx = 0u;
+  unsigned long long all = 0;
+  for (uint32_t i = tid; i < nk1; i += 256) {
+    const uint4 bo = bout[i];
+    part += i < front ? bo.x : 0u;
+    all += bo.x;
+    mn = min(mn, bo.y); mx = max(mx, bo.z);
+  }
+  uint32_t carry;
+  block_excl_scan_256(part, tmp, carry);
+  const uint32_t kmin = block_min_u32(mn, tmp), kmax = block_max_u32(mx, tmp);
+  const uint32_t w = depth_digit_width(kmin, kmax), mask = (1u << w) - 1u, nbins = 1u << w;
+  for (uint32_t d = tid; d < nbins; d += 256) h[d] = 0;
+  __syncthreads();
+  uint32_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < DITEMS; ++i) {
+    sum += v[i];
+    if (kk[i] != RS_DROP_KEY) atomicAdd(&h[(kk[i] - kmin) & mask], 1u);
+  }
+  uint32_t total;
+  uint32_t run = block_excl_scan_256(sum, tmp, total) + carry;
+#pragma unroll
+  for (int i = 0; i < DITEMS; ++i) {
+    if (base + i < P) offg[base + i] = run;
+    run += v[i];
+  }
+  __syncthreads();
+  for (uint32_t d = tid; d < nbins; d += 256) table[d * nb + b] = h[d];
+  if (b == nb - 1) {
+    const unsigned long long n64 = block_sum_u64(all, tmp64);
+    if (tid == 0) {
+      offg[P] = carry + total;
+      const bool ovf = n64 > cap;
+      dv[DV_N] = ovf ? 0u : (uint32_t)n64;
+      dv[DV_KMIN] = kmin; dv[DV_W] = w; dv[DV_OVF] = ovf ? 1u : 0u;
+      dv[DV_N64] = (uint32_t)n64; dv[DV_N64 + 1] = (uint32_t)(n64 >> 32);
+      if (host_slot) {
+        // pinned, device-mapped host memory: count and flag first, then -- behind a system-scope fence -- the token the
+        // host is polling for (words: 0,1 = count, 2 = overflow flag, 3 = token)
+        host_slot[0] = (uint32_t)n64; host_slot[1] = (uint32_t)(n64 >> 32); host_slot[2] = ovf ? 1u : 0u;
+        __threadfence_system();
+        __hip_atomic_store(&host_slot[3], host_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: emit (tile, rank) pairs, one thread per OUTPUT slot (perfectly balanced, coalesced writes)
+// K3: emit (tile, Gaussian) pairs, one thread per OUTPUT slot (perfectly balanced, coalesced writes), in depth-rank
+// order.  A block emits one chunk of the tile sort's first pass and leaves that pass's digit histogram of its chunk in
+// the radix table: the sort's first histogram launch (a full read of the keys) disappears.
 // ------------------------------------------------------------------------------------------------
-constexpr int EMIT_SLOTS = 1024;
-
 __device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo, uint32_t hi, uint32_t target) {
   // largest r in [lo,hi) with off[r] <= target   (off is non-decreasing, off[lo] <= target)
   while (hi - lo > 1) {
@@ -209,68 +252,108 @@ __device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo,
   return lo;
 }
 
-// A (tile, Gaussian) pair of the reference's 3-sigma tile rect is kept only if some pixel of the tile can pass
+// A (tile, Gaussian) pair of the Gaussian's tile rect is kept only if some pixel of the tile can pass
 // the reference's own alpha test (alpha >= 1/255); pairs that cannot are given the key `ntiles`, sort to the
 // tail and are never composited.  The same test per 16x4 strip gives a 4-bit mask that rides in the top bits of
-// the pair's value, so K6/K7 skip strips with scalar bit tests instead of evaluating the splat there.  The rendered image, radii and gradients are unchanged by construction
-// (tile_can_contribute is conservative); only the work shrinks.  `cull` = 0 keeps every pair.
-__global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order,
-                                              uint32_t P, uint32_t N,
-                                              const float4* __restrict__ R0, const float4* __restrict__ R1,
-                                              const float4* __restrict__ R2, int gridx, int W, int H,
-                                              uint32_t ntiles, int cull, uint32_t* __restrict__ pair_tile,
-                                              uint32_t* __restrict__ pair_rank) {
-  __shared__ uint32_t s_off[EMIT_SLOTS + 1];
+// the pair's value, so K6/K7 skip strips with scalar bit tests instead of evaluating the splat there.  The rendered
+// image, radii and gradients are unchanged by construction (the test is conservative); only the work shrinks.
+// `cull` = 0 keeps every pair.  dv: device-side counts (DV_N pairs, DV_V ranks).
+// A block = CHUNK / 8 threads emits CHUNK slots, eight per thread with their dependent chains (search -> order[] ->
+// record -> mask) interleaved: the kernel is bound by those chains' latency, not by their arithmetic.
+constexpr int EMIT_PER_THREAD = 8;        // slots per thread, in EMIT_BATCHES rounds of EMIT_ILV interleaved chains
+constexpr int EMIT_ILV = 4;
+constexpr int EMIT_GRAIN = rs_chunk(RS_ROUNDS_MIN);     // slots per chunk_first entry (the smaller of the two chunk sizes)
+template <int ROUNDS>
+__global__ void __launch_bounds__(rs_chunk(ROUNDS) / EMIT_PER_THREAD)
+k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_first,
+       const uint32_t* __restrict__ dv, const float4* __restrict__ R0, const float4* __restrict__ R1, const float4* __restrict__ R2, int gridx, int W, int H,
+       uint32_t ntiles, int cull, uint32_t* __restrict__ pair_tile, uint32_t* __restrict__ pair_rank,
+       uint32_t* __restrict__ table, uint32_t nb, uint32_t digit_mask) {
+  constexpr int CHUNK = rs_chunk(ROUNDS);
+  constexpr int THREADS = CHUNK / EMIT_PER_THREAD;
+  __shared__ uint32_t s_off[CHUNK + 1];
   __shared__ uint32_t s_r[2];
-  const uint32_t e0 = blockIdx.x * EMIT_SLOTS;
-  const uint32_t e1 = min(e0 + (uint32_t)EMIT_SLOTS, N);
-  if (threadIdx.x < 2) s_r[threadIdx.x] = upper_rank(off, 0, P + 1, threadIdx.x == 0 ? e0 : e1 - 1);
+  __shared__ uint32_t h[RS_BINS];
+  const uint32_t N = dv[DV_N], V = dv[DV_V];
+  const uint32_t e0 = blockIdx.x * CHUNK;
+  if (e0 >= N) return;
+  const uint32_t e1 = min(e0 + (uint32_t)CHUNK, N);
+  // first and last rank with slots in this chunk, from the owners of the chunk starts that the rank scan recorded
+  // (chunk_first, one entry per EMIT_GRAIN slots): no search of off[] in global memory
+  if (threadIdx.x == 0) s_r[0] = chunk_first[blockIdx.x * (CHUNK / EMIT_GRAIN)];
+  if (threadIdx.x == 64) {
+    uint32_t rh = V - 1u;
+    if (e1 < N) {                                           // another chunk follows: e1 is its first slot
+      const uint32_t rn = chunk_first[(blockIdx.x + 1u) * (CHUNK / EMIT_GRAIN)];
+      rh = off[rn] == e1 ? rn - 1u : rn;                    // ranks all own at least one slot: off[] is strictly increasing
+    }
+    s_r[1] = rh;
+  }
+  if (threadIdx.x < RS_BINS) h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t r_lo = s_r[0], r_hi = s_r[1];
   const uint32_t span = r_hi - r_lo + 1;
-  const bool in_lds = span <= (uint32_t)(EMIT_SLOTS + 1);
+  const bool in_lds = span <= (uint32_t)(CHUNK + 1);
   if (in_lds)
-    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_off[i] = off[r_lo + i];
+    for (uint32_t i = threadIdx.x; i < span; i += THREADS) s_off[i] = off[r_lo + i];
   __syncthreads();
-  for (uint32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-    uint32_t r, o;
-    if (in_lds) {
-      const uint32_t i = upper_rank(s_off, 0, span, e);
-      r = r_lo + i; o = s_off[i];
-    } else {
-      r = upper_rank(off, r_lo, r_hi + 1, e); o = off[r];
+#pragma unroll 1
+  for (int bt = 0; bt < EMIT_PER_THREAD / EMIT_ILV; ++bt) {
+  uint32_t e[EMIT_ILV], o[EMIT_ILV], g[EMIT_ILV];
+  bool on[EMIT_ILV];
+#pragma unroll
+  for (int k = 0; k < EMIT_ILV; ++k) {
+    e[k] = e0 + threadIdx.x + (bt * EMIT_ILV + k) * THREADS;
+    on[k] = e[k] < e1;
+    uint32_t r = r_lo;
+    o[k] = 0;
+    if (on[k]) {
+      if (in_lds) {
+        const uint32_t i = upper_rank(s_off, 0, span, e[k]);
+        r = r_lo + i; o[k] = s_off[i];
+      } else {
+        r = upper_rank(off, r_lo, r_hi + 1, e[k]); o[k] = off[r];
+      }
     }
-    const uint32_t g = order[r];                           // the pair's value: the Gaussian (storage index)
-    const float4 c = R2[REC * g];
-    const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
+    g[k] = on[k] ? order[r] : 0u;                          // the pair's value: the Gaussian (storage index)
+  }
+  float4 ra[EMIT_ILV], rb[EMIT_ILV], rc[EMIT_ILV];
+#pragma unroll
+  for (int k = 0; k < EMIT_ILV; ++k) {
+    rc[k] = R2[REC * g[k]];
+    if (cull) { ra[k] = R0[REC * g[k]]; rb[k] = R1[REC * g[k]]; }
+  }
+#pragma unroll
+  for (int k = 0; k < EMIT_ILV; ++k) {
+    if (!on[k]) continue;
+    const uint32_t rx = __float_as_uint(rc[k].z), ry = __float_as_uint(rc[k].w);
     const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
-    const uint32_t local = e - o;
-    const uint32_t dy = local / wx, dx = local - dy * wx;
+    const uint32_t local = e[k] - o[k];
+    // local / wx through a float reciprocal (local < 2^24: a rect has at most 4095^2 tiles), corrected by one step
+    uint32_t dy = (uint32_t)((float)local * __builtin_amdgcn_rcpf((float)wx));
+    dy -= (dy * wx > local) ? 1u : 0u;
+    dy += ((dy + 1u) * wx <= local) ? 1u : 0u;
+    const uint32_t dx = local - dy * wx;
     const uint32_t tx = minx + dx, ty = miny + dy;
     uint32_t key = ty * (uint32_t)gridx + tx;
     uint32_t mask = 0xFu;   // one bit per 16x4 strip of the tile that the Gaussian can reach
     if (cull) {
-      const float4 a = R0[REC * g], b = R1[REC * g];
       const float x0 = (float)(tx * TILE);
       const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
-      mask = strip_masks4(a.x, a.y, a.z, a.w, b.x, b.y, x0, x1, (float)(ty * TILE), (float)(H - 1));
+      mask = strip_masks4(ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, x0, x1, (float)(ty * TILE), (float)(H - 1));
       if (mask == 0) key = ntiles;
     }
-    pair_tile[e] = key;
-    pair_rank[e] = g | (mask << RANK_BITS);
+    pair_tile[e[k]] = key;
+    pair_rank[e[k]] = g[k] | (mask << RANK_BITS);
+    atomicAdd(&h[key & digit_mask], 1u);
   }
+  }
+  __syncthreads();
+  if (threadIdx.x <= digit_mask) table[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
-// K5 (keys >= ntiles are culled pairs at the tail of the sorted list)
-__global__ void __launch_bounds__(256) k_ranges(uint32_t N, uint32_t ntiles, const uint32_t* __restrict__ tiles,
-                                                uint2* __restrict__ ranges) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const uint32_t t = tiles[i];
-  if (t >= ntiles) return;
-  if (i == 0 || tiles[i - 1] != t) ranges[t].x = i;
-  if (i == N - 1 || tiles[i + 1] != t) ranges[t].y = i + 1;
-}
+// K5 (tile ranges) has no kernel of its own: the last pass of the tile sort leaves every tile's span of the sorted list
+// in ranges[] (gsr_sort.hip.h, key_ranges), and k_tile_schedule turns the spans of tiles without pairs into (0, 0).
 
 // ------------------------------------------------------------------------------------------------
 // K6 / K7 common: one WAVE (= one 64-thread workgroup) per 16x16 tile, 4 pixels per lane
@@ -301,6 +384,7 @@ struct RenderArgs {
   float4* bnd;            // [records][256] (T, C_r, C_g, C_b) per pixel, pixel = strip * 64 + lane
   const uint32_t* segoff; // [ntiles] first boundary record of the tile, SEG_NONE for tiles that are not split
   uint32_t seg_shift;     // log2 of the segment length
+  const uint32_t* dv;     // device-side scalars of an asynchronous-count forward (dv[DV_OVF] != 0: the image is poisoned), or null
   unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock_fwd): [ntiles * NSUB][2] start/end, 100 MHz
 };
 
@@ -356,7 +440,7 @@ __device__ __forceinline__ uint32_t wave_max_u32_fwd(uint32_t v) {
 }
 // seg_shift = 0: no tile is split.  rec_cap: capacity of the boundary-record buffer (a tile whose records would not
 // fit stays unsplit); nrec_out receives the number of records in use.
-__global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
                                                         uint32_t rec_cap, uint32_t* __restrict__ nrec_out) {
@@ -377,12 +461,28 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, const uint2*
   if (t == 0) smax = 0;
   __syncthreads();
   uint32_t mymax = 0;
-  for (int i = t; i < ntiles; i += 1024) {
-    const uint2 r = ranges[i];
-    const uint32_t len = r.y - r.x;
-    if (in_lds) slen[i] = len;
-    atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
-    mymax = max(mymax, len);
+  for (int i0 = t; i0 < ntiles; i0 += 8 * 1024) {
+    // eight independent loads in flight per thread (the loop used to pay one memory round trip per 1024 tiles)
+    uint2 r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 1024;
+      r[k] = i < ntiles ? ranges[i] : make_uint2(0u, 0u);
+      if (r[k].x > r[k].y) {                 // a tile without pairs still holds the empty span (0xFFFFFFFF, 0)
+        r[k] = make_uint2(0u, 0u);
+        ranges[i] = r[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * 1024;
+      if (i < ntiles) {
+        const uint32_t len = r[k].y - r[k].x;
+        if (in_lds) slen[i] = len;
+        atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
+        mymax = max(mymax, len);
+      }
+    }
   }
   mymax = wave_max_u32_fwd(mymax);
   if (lane == 0) atomicMax(&smax, mymax);
@@ -659,7 +759,13 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
     for (int k = 0; k < NPX; ++k) rec[k * 64] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
   }
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
-  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  if (a.dv != nullptr && a.dv[DV_OVF] != 0u) {
+    // the pair count overflowed the capacity this forward was sized for: nothing was composited -- make that unmissable
+    bg0 = bg1 = bg2 = __uint_as_float(0x7FC00000u);
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) T[k] = 1.f;
+  }
   const size_t HW = (size_t)a.H * a.W;
 #pragma unroll
   for (int k = 0; k < NPX; ++k) {
@@ -1042,9 +1148,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
 // ------------------------------------------------------------------------------------------------
 // K8+K9 fused with the per-Gaussian reduction of the partial rows: one thread per Gaussian, in STORAGE
 // order, so every attribute read and every gradient write of a wave is one contiguous span; the rows of a
-// Gaussian's (tile, Gaussian) pairs are contiguous too (slots are numbered in storage order).  The 192-byte
-// SH rows go through LDS (coalesced float4 copies in and out, rows padded to 13 float4 => conflict-free
-// ds_read_b128) instead of 64 lanes each walking their own row.
+// Gaussian's (tile, Gaussian) pairs are contiguous too (slots are numbered in storage order).
 // ------------------------------------------------------------------------------------------------
 struct PreBwdArgs {
   int P, K;
@@ -1076,211 +1180,97 @@ struct PreBwdArgs {
   float* dcov3d;
 };
 
-// RAW: inputs are the raw parameters as in k_preprocess<.,true>; the gradients written are those of the raw
-// parameters (chain rule of exp / normalize / sigmoid applied here) and a.dsh / a.dsh_dc receive the
-// _features_rest / _features_dc parts of the SH gradient.
+// Generic form (any K): one thread per Gaussian walks its own partial rows and its own SH row.
 // GEOM = false: the rows carry the three colour sums only (K7 without the geometry sums) and only the SH / colour /
 // object-feature gradients are produced.
-template <bool SH_LDS, bool RAW, bool GEOM>
+template <bool GEOM>
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
-  __shared__ float4 srow[SH_LDS ? PRE_WAVES * 64 * SHROW_F4 : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw0 = blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
-  const int g = gw0 + lane;
+  const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int K = a.K;
-  float4* wrow = SH_LDS ? &srow[wave * 64 * SHROW_F4] : nullptr;
-  const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
-  uint32_t o0 = 0, o1 = 0;
-  if (g < a.P) { o0 = a.offg[g] * a.nsub; o1 = a.offg[g + 1] * a.nsub; }
-  // ---- sum this Gaussian's partial rows ---------------------------------------------------------------------
-  // The rows of the wave's 64 Gaussians are one contiguous span: copy it through LDS in chunks of 256 rows with
-  // coalesced float4 loads (48-byte rows read back with ds_read_b128 are bank-conflict free) instead of 64 lanes
-  // each walking their own rows in HBM.  A Gaussian with more than 256 rows is summed by the whole wave.
+  if (g >= a.P) return;
+  const uint32_t o0 = a.offg[g] * a.nsub, o1 = a.offg[g + 1] * a.nsub;
+  if (o1 == o0) {   // no pairs: zero gradients
+    if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
+    if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
+    if (a.dsh) for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] = 0.f;
+    if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
+    if (a.dcolors) { a.dcolors[3 * g] = 0.f; a.dcolors[3 * g + 1] = 0.f; a.dcolors[3 * g + 2] = 0.f; }
+    if (a.dopac) a.dopac[g] = 0.f;
+    if (a.dscales) { a.dscales[3 * g] = 0.f; a.dscales[3 * g + 1] = 0.f; a.dscales[3 * g + 2] = 0.f; }
+    if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
+    if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
+    return;
+  }
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-  if (SH_LDS && nw > 0) {
-    const uint32_t S = a.offg[gw0] * a.nsub, E = a.offg[gw0 + nw] * a.nsub;
-    const bool big = (o1 - o0) > 256u;
-    for (uint32_t c0 = S; c0 < E; c0 += 256u) {
-      const uint32_t rows = min(256u, E - c0);
-      const float4* src = a.part + (size_t)c0 * PART_F4;
-      for (uint32_t i = lane; i < rows * PART_F4; i += 64) wrow[i] = src[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (!big) {
-        const uint32_t lo = max(o0, c0), hi = min(o1, c0 + rows);
-        for (uint32_t e = lo; e < hi; ++e) {
-          const float4* r = &wrow[(e - c0) * PART_F4];
-          const float4 p0 = r[0], p1 = r[1], p2 = r[2];
-          if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-          if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
-          dr += p1.z; dg += p1.w; db += p2.x;
+  for (uint32_t e = o0; e < o1; ++e) {
+    const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+    if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
+    if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
+    dr += p1.z; dg += p1.w; db += p2.x;
+  }
+  if (a.dsh_objs) {
+    float acc[NUM_OBJ];
+#pragma unroll
+    for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
+    if (a.part_obj) {
+      for (uint32_t e = o0; e < o1; ++e) {
+        const float4 tg = a.part[(size_t)e * PART_F4 + 2];
+        if (__float_as_uint(tg.y) != a.tag_lo || __float_as_uint(tg.z) != a.tag_hi) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = a.part_obj[(size_t)e * 4 + q];
+          acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    uint64_t bm = __ballot(big);
-    while (bm) {
-      const int L = __ffsll((unsigned long long)bm) - 1;
-      bm &= bm - 1;
-      const uint32_t b0 = __shfl(o0, L, 64), b1 = __shfl(o1, L, 64);
-      float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (uint32_t e = b0 + lane; e < b1; e += 64) {
-        const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
-        if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-        if (GEOM) { t[0] += p0.x; t[1] += p0.y; t[2] += p0.z; t[3] += p0.w; t[4] += p1.x; t[5] += p1.y; }
-        t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
-      }
 #pragma unroll
-      for (int i = 0; i < 9; ++i) t[i] = __shfl(wave_sum_to_hi(t[i]), 63, 64);
-      if (lane == L) { mx = t[0]; my = t[1]; mxx = t[2]; mxy = t[3]; myy = t[4]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
-    }
+    for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
   }
-  {
-    const uint64_t need = __ballot(o1 > o0);            // culled Gaussians: coefficients not needed, gradient = 0
-    if (SH_LDS && nw > 0 && need) stage_sh_rows<RAW>(wrow, a.sh, a.sh_dc, gw0, nw, lane, need);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (g < a.P) {
-    float* my_sh = SH_LDS ? reinterpret_cast<float*>(&wrow[lane * SHROW_F4]) : nullptr;
-    if (o1 == o0) {   // culled: zero gradients
-      if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
-      if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
-      if (a.dsh) {
-        if (SH_LDS) { for (int i = 0; i < 12; ++i) wrow[lane * SHROW_F4 + i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        else for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] = 0.f;
-      }
-      if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
-      if (a.dcolors) { a.dcolors[3 * g] = 0.f; a.dcolors[3 * g + 1] = 0.f; a.dcolors[3 * g + 2] = 0.f; }
-      if (a.dopac) a.dopac[g] = 0.f;
-      if (a.dscales) { a.dscales[3 * g] = 0.f; a.dscales[3 * g + 1] = 0.f; a.dscales[3 * g + 2] = 0.f; }
-      if (a.drots) { a.drots[4 * g] = 0.f; a.drots[4 * g + 1] = 0.f; a.drots[4 * g + 2] = 0.f; a.drots[4 * g + 3] = 0.f; }
-      if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
+  View v;
+  load_view(v, a.va);
+  const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
+  const float A = e0.z, B = e0.w, C = e1.x;
+  // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
+  const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
+  const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
+  const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
+  if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
+  if (GEOM && a.dopac) a.dopac[g] = dop;
+  const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+  float dp[3] = {0.f, 0.f, 0.f};
+  if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
+  if (a.sh) {
+    const uint32_t cl = (__float_as_uint(e1.z) >> 31) | ((__float_as_uint(e1.w) >> 31) << 1) | ((__float_as_uint(e2.x) >> 31) << 2);
+    const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
+    if (a.dsh) {
+      sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
     } else {
-      if (!SH_LDS) {
-        for (uint32_t e = o0; e < o1; ++e) {
-          const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
-          if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-          if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
-          dr += p1.z; dg += p1.w; db += p2.x;
-        }
-      }
-      if (a.dsh_objs) {
-        float acc[NUM_OBJ];
-#pragma unroll
-        for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
-        if (a.part_obj) {
-          for (uint32_t e = o0; e < o1; ++e) {
-            const float4 tg = a.part[(size_t)e * PART_F4 + 2];
-            if (__float_as_uint(tg.y) != a.tag_lo || __float_as_uint(tg.z) != a.tag_hi) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 v = a.part_obj[(size_t)e * 4 + q];
-              acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
-      }
-      View v;
-      load_view(v, a.va);
-      const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
-      const float A = e0.z, B = e0.w, C = e1.x;
-      // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
-      const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
-      const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
-      const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
-      if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
-      if (GEOM && a.dopac) a.dopac[g] = RAW ? dop * e1.y * (1.f - e1.y) : dop;   // e1.y = sigmoid(raw opacity)
-      const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
-      float dp[3] = {0.f, 0.f, 0.f};
-      if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
-      if (a.sh) {
-        const uint32_t cl = __float_as_uint(e2.z) >> 24;
-        const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
-        if (SH_LDS) {
-          // in place on the staged row: sh_to_rgb_bwd reads coefficient k before it writes gradient k
-          sh_to_rgb_bwd(v.sh_degree, 16, my_sh, p, v.cam, drgb, my_sh, dp);
-        } else if (a.dsh) {
-          sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
-        } else {
-          float scratch[48];
-          sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
-        }
-      }
-      if (GEOM) {
-      float c6[6];
-      float s[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-      float inv_qn = 1.f;
-      if (a.cov3d) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
-      } else {
-        s[0] = a.scales[3 * g]; s[1] = a.scales[3 * g + 1]; s[2] = a.scales[3 * g + 2];
-        const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
-        q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
-        if (RAW) {
-          s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
-          act_normalize4(q, q, inv_qn);
-        }
-        cov3d_from_scale_rot(s, a.va.mod, q, c6);
-      }
-      float dc6[6];
-      project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
-      if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
-      if (a.cov3d) {
-        if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
-      } else if (a.dscales || a.drots) {
-        float ds[3], dq[4];
-        cov3d_bwd(s, a.va.mod, q, dc6, ds, dq);
-        if (RAW) {
-          ds[0] *= s[0]; ds[1] *= s[1]; ds[2] *= s[2];     // d exp(x) = exp(x)
-          act_normalize4_bwd(q, inv_qn, dq, dq);
-        }
-        if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
-        if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
-      }
-      }
+      float scratch[48];
+      sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
     }
   }
-  if (SH_LDS && a.dsh && nw > 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (!RAW) {
-      float4* dst = reinterpret_cast<float4*>(a.dsh) + (size_t)gw0 * 12;
-      for (int i = lane; i < nw * 12; i += 64) {
-        const int row = i / 12;
-        dst[i] = wrow[row * SHROW_F4 + (i - row * 12)];
-      }
-    } else {
-      const float* wf = reinterpret_cast<const float*>(wrow);
-      float* dc = a.dsh_dc + (size_t)gw0 * 3;
-      for (int i = lane; i < nw * 3; i += 64) {
-        const int row = i / 3;
-        dc[i] = wf[row * (4 * SHROW_F4) + (i - row * 3)];
-      }
-      float* rest = a.dsh + (size_t)gw0 * 45;
-      const int n4 = (nw * 45) >> 2;
-      float4* rest4 = reinterpret_cast<float4*>(rest);
-      for (int i = lane; i < n4; i += 64) {
-        float vv[4];
+  if (GEOM) {
+    float c6[6];
+    float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.cov3d) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int e = 4 * i + c, row = e / 45;
-          vv[c] = wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)];
-        }
-        rest4[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      }
-      for (int e = 4 * n4 + lane; e < nw * 45; e += 64) {
-        const int row = e / 45;
-        rest[e] = wf[row * (4 * SHROW_F4) + 3 + (e - row * 45)];
-      }
+      for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
+    } else {
+      sc[0] = a.scales[3 * g]; sc[1] = a.scales[3 * g + 1]; sc[2] = a.scales[3 * g + 2];
+      const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+      cov3d_from_scale_rot(sc, a.va.mod, q, c6);
+    }
+    float dc6[6];
+    project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+    if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
+    if (a.cov3d) {
+      if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
+    } else if (a.dscales || a.drots) {
+      float ds[3], dq[4];
+      cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
+      if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
+      if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
     }
   }
 }
@@ -1376,23 +1366,30 @@ struct PreArgs {
   float4* G1;
   float4* G2;
   float* D;               // [P,9] d rgb_c / d dir_axis (before the clamp), or null: not wanted (no backward follows)
-  uint32_t* dkey;
-  uint32_t* tcnt;
+  uint32_t* dkey;         // float bits of the view depth; 0xFFFFFFFF for a Gaussian that emits no pair
+  uint32_t* tcnt;         // tiles of the (tightened) rect
+  int cull;               // != 0: shrink the rect to the alpha >= 1/255 footprint (tighten_rect)
+  PreBlockOut bo;
 };
 
+// A colour c >= 0 whose pre-clamp value was negative is stored as -0.0f: the compositors see 0 either way (x + -0 = x,
+// w * -0 adds nothing), and the backward reads the clamp flag off the sign bit instead of from a separate word -- so
+// the colour words of a record belong to the colour kernel alone and the geometry kernel never touches them.
+__device__ __forceinline__ float clamp_flagged(float c) { return c > 0.f ? c : (c < 0.f ? -0.0f : 0.0f); }
+__device__ __forceinline__ uint32_t clamp_bits_of(float r, float g, float b) {
+  return (__float_as_uint(r) >> 31) | ((__float_as_uint(g) >> 31) << 1) | ((__float_as_uint(b) >> 31) << 2);
+}
+
+// K1, geometry half: one thread per Gaussian -- projection, culls, tile rect, depth key, tiles touched, the geometric
+// words of the 48-byte record ((px,py,A,B) (C,opacity,.,.) (.,depth,rect x,rect y)) -- and the workgroup sums the storage
+// scan starts from.  Reads 44 bytes per Gaussian.  With precomputed colours it writes those too (nothing else to do).
 template <bool RAW>
-__global__ void __launch_bounds__(PRE_BLOCK) k_pre_fwd(PreArgs a) {
-  __shared__ float slots[PRE_WAVES * 64 * SLOT_W];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* ws = &slots[wave * 64 * SLOT_W];
-  const int g = blockIdx.x * PRE_BLOCK + wave * 64 + lane;
-  View v;
-  load_view(v, a.va);
-  // ---- phase A: one thread per Gaussian -- projection, culls, per-Gaussian scalars ---------------------------------
-  bool ok = false;
-  Splat s;
-  float aux0 = 0.f, aux1 = 0.f, aux2 = 0.f, op = 0.f;
+__global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
+  const int g = blockIdx.x * PREG_BLOCK + threadIdx.x;
+  uint32_t cnt = 0, key = 0xFFFFFFFFu;
   if (g < a.P) {
+    View v;
+    load_view(v, a.va);
     const bool second = g >= a.Pa;                       // which attribute segment this Gaussian lives in
     const int gl = second ? g - a.Pa : g;
     const float* means = second ? a.means_b : a.means;
@@ -1413,94 +1410,112 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_fwd(PreArgs a) {
       }
       cov3d_from_scale_rot(sc, a.va.mod, q, c6);
     }
-    ok = project_splat(v, p, c6, s);
-    if (ok) {
+    Splat s;
+    const bool vis = project_splat(v, p, c6, s);
+    a.radii[g] = vis ? s.radius : 0;                     // the reference's radius, whatever the footprint test says
+    if (vis) {
       const float oraw = second ? a.opac_b[gl] : a.opac[gl];
-      op = RAW ? act_sigmoid(oraw) : oraw;
-      if (a.colors) {
-        aux0 = a.colors[3 * g]; aux1 = a.colors[3 * g + 1]; aux2 = a.colors[3 * g + 2];
-      } else {
-        const float dx = p[0] - v.cam[0], dy = p[1] - v.cam[1], dz = p[2] - v.cam[2];
-        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        aux0 = dx * inv; aux1 = dy * inv; aux2 = dz * inv;
+      const float op = RAW ? act_sigmoid(oraw) : oraw;
+      if (a.cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, op, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
+      cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
+      if (cnt != 0u) {
+        key = __float_as_uint(s.depth);
+        const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12);
+        const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
+        a.G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
+        float* g1 = reinterpret_cast<float*>(&a.G1[REC * g]);
+        float* g2 = reinterpret_cast<float*>(&a.G2[REC * g]);
+        if (a.colors) {
+          a.G1[REC * g] = make_float4(s.C, op, a.colors[3 * g], a.colors[3 * g + 1]);
+          a.G2[REC * g] = make_float4(a.colors[3 * g + 2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
+        } else {
+          *reinterpret_cast<float2*>(g1) = make_float2(s.C, op);
+          g2[1] = s.depth;
+          *reinterpret_cast<float2*>(g2 + 2) = make_float2(__uint_as_float(rx), __uint_as_float(ry));
+        }
       }
     }
-    a.radii[g] = ok ? s.radius : 0;
-    a.dkey[g] = ok ? __float_as_uint(s.depth) : 0xFFFFFFFFu;
-    a.tcnt[g] = ok ? (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy)) : 0u;
+    a.dkey[g] = key;
+    a.tcnt[g] = cnt;
   }
+  pre_block_epilogue(a.bo, g, cnt, key);
+}
+
+// K1, colour half: SH -> RGB for the Gaussians that emit pairs, by FOUR LANES per Gaussian (see above), + d colour /
+// d view direction for the backward.  Reads the 192-byte SH rows of the survivors only, writes the three colour words of
+// their records.  It depends on the geometry half only through tcnt[] and is needed by nobody before the forward
+// compositor: the library runs it on a side stream, beside the binning chain (which leaves most of the chip idle).
+template <bool RAW>
+__global__ void __launch_bounds__(PREF_BLOCK) k_pre_color(PreArgs a) {
+  __shared__ float slots[PREF_WAVES * 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ws = &slots[wave * 64 * 4];
+  const int g = blockIdx.x * PREF_BLOCK + wave * 64 + lane;
+  const bool ok = g < a.P && a.tcnt[g] != 0u;
   const uint64_t live = __ballot(ok);
   const int nlive = __popcll(live);
+  if (nlive == 0) return;
   if (ok) {
-    float* sl = ws + SLOT_W * __popcll(live & ((1ull << lane) - 1ull));
-    sl[0] = s.px; sl[1] = s.py; sl[2] = s.A; sl[3] = s.B; sl[4] = s.C; sl[5] = op; sl[6] = s.depth;
-    sl[7] = __uint_as_float((uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12));
-    sl[8] = __uint_as_float((uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12));
-    sl[9] = aux0; sl[10] = aux1; sl[11] = aux2;
-    sl[12] = __uint_as_float((uint32_t)g);
+    const bool second = g >= a.Pa;
+    const int gl = second ? g - a.Pa : g;
+    const float* means = second ? a.means_b : a.means;
+    const float* cam = a.va.cam;
+    const float dx = means[3 * gl] - cam[0], dy = means[3 * gl + 1] - cam[1], dz = means[3 * gl + 2] - cam[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float* sl = ws + 4 * __popcll(live & ((1ull << lane) - 1ull));
+    sl[0] = dx * inv; sl[1] = dy * inv; sl[2] = dz * inv; sl[3] = __uint_as_float((uint32_t)g);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // ---- phase B: four lanes per SURVIVOR -- SH -> colour, d colour / d direction, the 48-byte record ----------------
   const int q = lane & 3, grp = lane >> 2;
   const int deg = a.va.deg;
   for (int r0 = 0; r0 < nlive; r0 += 16) {
     const int si = r0 + grp;
     if (si < nlive) {
-      const float* sl = ws + SLOT_W * si;
-      const uint32_t gg = __float_as_uint(sl[12]);
-      float rgb0, rgb1, rgb2;
-      uint32_t cl = 0;
-      if (a.colors) {
-        rgb0 = sl[9]; rgb1 = sl[10]; rgb2 = sl[11];
-      } else {
-        const float x = sl[9], y = sl[10], z = sl[11];
-        float sv[12];
-        if (gg >= (uint32_t)a.Pa) load_sh12<RAW>(a.sh_b, a.sh_dc_b, gg - (uint32_t)a.Pa, q, sv);
-        else load_sh12<RAW>(a.sh, a.sh_dc, gg, q, sv);
-        float b[16], gx[16], gy[16], gz[16];
+      const float4 slv = *reinterpret_cast<const float4*>(ws + 4 * si);
+      const float x = slv.x, y = slv.y, z = slv.z;
+      const uint32_t gg = __float_as_uint(slv.w);
+      float sv[12];
+      if (gg >= (uint32_t)a.Pa) load_sh12<RAW>(a.sh_b, a.sh_dc_b, gg - (uint32_t)a.Pa, q, sv);
+      else load_sh12<RAW>(a.sh, a.sh_dc, gg, q, sv);
+      float b[16], gx[16], gy[16], gz[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) b[k] = 0.f;
-        sh_basis(deg, x, y, z, b);
-        float bs[4];
+      for (int k = 0; k < 16; ++k) b[k] = 0.f;
+      sh_basis(deg, x, y, z, b);
+      float bs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bs[j] = pick4(q, b[j], b[4 + j], b[8 + j], b[12 + j]);
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      for (int j = 0; j < 4; ++j) bs[j] = pick4(q, b[j], b[4 + j], b[8 + j], b[12 + j]);
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { c0 = fmaf(bs[j], sv[3 * j], c0); c1 = fmaf(bs[j], sv[3 * j + 1], c1); c2 = fmaf(bs[j], sv[3 * j + 2], c2); }
-        c0 = quad_sum(c0) + 0.5f; c1 = quad_sum(c1) + 0.5f; c2 = quad_sum(c2) + 0.5f;
-        cl = (c0 < 0.f ? 1u : 0u) | (c1 < 0.f ? 2u : 0u) | (c2 < 0.f ? 4u : 0u);
-        rgb0 = fmaxf(c0, 0.f); rgb1 = fmaxf(c1, 0.f); rgb2 = fmaxf(c2, 0.f);
-        if (a.D) {
-          sh_basis_grad(deg, x, y, z, gx, gy, gz);
-          float d[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // d[3c + axis]
+      for (int j = 0; j < 4; ++j) { c0 = fmaf(bs[j], sv[3 * j], c0); c1 = fmaf(bs[j], sv[3 * j + 1], c1); c2 = fmaf(bs[j], sv[3 * j + 2], c2); }
+      c0 = quad_sum(c0) + 0.5f; c1 = quad_sum(c1) + 0.5f; c2 = quad_sum(c2) + 0.5f;
+      if (a.D) {
+        sh_basis_grad(deg, x, y, z, gx, gy, gz);
+        float d[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // d[3c + axis]
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float ex = pick4(q, gx[j], gx[4 + j], gx[8 + j], gx[12 + j]);
-            const float ey = pick4(q, gy[j], gy[4 + j], gy[8 + j], gy[12 + j]);
-            const float ez = pick4(q, gz[j], gz[4 + j], gz[8 + j], gz[12 + j]);
+        for (int j = 0; j < 4; ++j) {
+          const float ex = pick4(q, gx[j], gx[4 + j], gx[8 + j], gx[12 + j]);
+          const float ey = pick4(q, gy[j], gy[4 + j], gy[8 + j], gy[12 + j]);
+          const float ez = pick4(q, gz[j], gz[4 + j], gz[8 + j], gz[12 + j]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              d[3 * c] = fmaf(ex, sv[3 * j + c], d[3 * c]);
-              d[3 * c + 1] = fmaf(ey, sv[3 * j + c], d[3 * c + 1]);
-              d[3 * c + 2] = fmaf(ez, sv[3 * j + c], d[3 * c + 2]);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 9; ++i) d[i] = quad_sum(d[i]);
-          if (q < 3) {
-            const float dx_ = pick4(q, d[0], d[3], d[6], 0.f), dy_ = pick4(q, d[1], d[4], d[7], 0.f),
-                        dz_ = pick4(q, d[2], d[5], d[8], 0.f);
-            *reinterpret_cast<F3u*>(a.D + (size_t)gg * 9 + 3 * q) = F3u{dx_, dy_, dz_};
+          for (int c = 0; c < 3; ++c) {
+            d[3 * c] = fmaf(ex, sv[3 * j + c], d[3 * c]);
+            d[3 * c + 1] = fmaf(ey, sv[3 * j + c], d[3 * c + 1]);
+            d[3 * c + 2] = fmaf(ez, sv[3 * j + c], d[3 * c + 2]);
           }
         }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] = quad_sum(d[i]);
+        if (q < 3) {
+          const float dx_ = pick4(q, d[0], d[3], d[6], 0.f), dy_ = pick4(q, d[1], d[4], d[7], 0.f),
+                      dz_ = pick4(q, d[2], d[5], d[8], 0.f);
+          *reinterpret_cast<F3u*>(a.D + (size_t)gg * 9 + 3 * q) = F3u{dx_, dy_, dz_};
+        }
       }
-      // lanes 0..2 of the group store one float4 of the record each: 48 contiguous bytes per Gaussian
-      const uint32_t rx = __float_as_uint(sl[7]) | (cl << 24);
-      if (q == 0) a.G0[REC * gg] = make_float4(sl[0], sl[1], sl[2], sl[3]);
-      else if (q == 1) a.G1[REC * gg] = make_float4(sl[4], sl[5], rgb0, rgb1);
-      else if (q == 2) a.G2[REC * gg] = make_float4(rgb2, sl[6], __uint_as_float(rx), sl[8]);
+      // the colour words of the record: (., ., r, g) of its second float4 and (b, ., ., .) of its third
+      if (q == 0) *reinterpret_cast<float2*>(reinterpret_cast<float*>(&a.G1[REC * gg]) + 2) = make_float2(clamp_flagged(c0), clamp_flagged(c1));
+      else if (q == 1) *reinterpret_cast<float*>(&a.G2[REC * gg]) = clamp_flagged(c2);
     }
   }
 }
@@ -1614,7 +1629,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       float dp[3] = {0.f, 0.f, 0.f};
       if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
       if (a.sh) {
-        const uint32_t cl = __float_as_uint(e2.z) >> 24;
+        const uint32_t cl = clamp_bits_of(e1.z, e1.w, e2.x);
         hrgb[0] = (cl & 1u) ? 0.f : dr; hrgb[1] = (cl & 2u) ? 0.f : dg; hrgb[2] = (cl & 4u) ? 0.f : db;
         const float vx = p[0] - v.cam[0], vy = p[1] - v.cam[1], vz = p[2] - v.cam[2];
         const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);

@@ -16,8 +16,10 @@
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GSR_EXP(x) __expf(x)
+#define GSR_LOG_FAST(x) __logf(x)     // v_log_f32 (1 ulp of log2) x ln 2: callers widen their bound by 1e-4 relative + 1e-3
 #else
 #define GSR_EXP(x) expf(x)
+#define GSR_LOG_FAST(x) logf(x)
 #endif
 
 namespace gsr {
@@ -404,6 +406,31 @@ GSR_HD bool tile_can_contribute(float cx, float cy, float A, float B, float C, f
   return qmin <= bound;
 }
 
+// Shrinks a splat's tile rect [rmin, rmax) -- the reference's square of ceil(3 sigma) around the centre -- to the tiles
+// that the axis-aligned bounding box of its alpha >= 1/255 footprint touches: Q(d) <= tau bounds |dx| by
+// sqrt(tau C / (A C - B^2)) and |dy| by sqrt(tau A / (A C - B^2)) (the extents of the ellipse Q = tau), with the same
+// widened tau as the per-tile tests above plus a relative and an absolute margin on the extents.  Every (tile, Gaussian)
+// pair this drops would have been dropped by strip_masks4 at emission anyway (its mask is 0): the pair list, the image and
+// the gradients are unchanged, only fewer slots are emitted, sorted and numbered.  An opacity below 1/255 empties the rect.
+GSR_HD void tighten_rect(float px, float py, float A, float B, float C, float o, int gridx, int gridy, int& rminx,
+                         int& rminy, int& rmaxx, int& rmaxy) {
+  const float tau = 2.0f * logf(255.0f * o);
+  const float bound = tau + 1e-4f * fabsf(tau) + 1e-3f;
+  if (!(bound >= 0.f)) { rmaxx = rminx; rmaxy = rminy; return; }    // alpha never reaches the floor (also NaN opacity)
+  const float det = A * C - B * B;
+  if (!(A > 0.f) || !(C > 0.f) || !(det > 0.f)) return;            // not a proper conic: leave the rect alone
+  const float ex = sqrtf(bound * C / det) * 1.001f + 0.01f, ey = sqrtf(bound * A / det) * 1.001f + 0.01f;
+  if (!(ex < 1.0e9f) || !(ey < 1.0e9f)) return;
+  const float inv = 1.0f / (float)TILE;
+  const int x0 = trunc_clamp((px - ex) * inv, gridx), y0 = trunc_clamp((py - ey) * inv, gridy);
+  const int x1 = (px + ex < 0.f) ? 0 : trunc_clamp((px + ex) * inv + 1.0f, gridx);
+  const int y1 = (py + ey < 0.f) ? 0 : trunc_clamp((py + ey) * inv + 1.0f, gridy);
+  rminx = x0 > rminx ? x0 : rminx; rminy = y0 > rminy ? y0 : rminy;
+  rmaxx = x1 < rmaxx ? x1 : rmaxx; rmaxy = y1 < rmaxy ? y1 : rmaxy;
+  if (rmaxx < rminx) rmaxx = rminx;
+  if (rmaxy < rminy) rmaxy = rminy;
+}
+
 // The same test for the four 16x4 strips of a tile at once (strip k = pixel rows y0 + 4k .. y0 + 4k + 3, clipped to
 // the image height): bit k of the result is set when strip k can be reached.  What is shared between the strips --
 // the threshold, the two column offsets, the two reciprocals that place the minimum on an edge -- is computed once
@@ -415,7 +442,7 @@ GSR_HD uint32_t strip_masks4(float cx, float cy, float A, float B, float C, floa
     for (int k = 0; k < 4; ++k) if (y0 + 4.f * (float)k <= ymax) m |= 1u << k;
     return m;
   }
-  const float tau = 2.0f * logf(255.0f * o);
+  const float tau = 2.0f * GSR_LOG_FAST(255.0f * o);
   const float bound = tau + 1e-4f * fabsf(tau) + 1e-3f;
   if (!(bound >= 0.f)) return 0u;
   const float dxl = x0 - cx, dxh = x1 - cx;

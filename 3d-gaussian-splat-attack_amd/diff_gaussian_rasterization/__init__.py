@@ -12,6 +12,7 @@ There is NO fallback: without the compiled library or without a HIP device every
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import weakref
 import os
@@ -27,6 +28,8 @@ _lib = None
 FLAG_NO_CULL = 1          # GSR_FLAG_NO_CULL (include/gsraster.h)
 FLAG_NO_SEGMENTS = 1 << 16
 FLAG_FWD_SHARED = 1 << 17   # the forward waves of a tile share one staging of the list (opt-in; include/gsraster.h)
+FLAG_ASYNC_COUNT = 1 << 18  # GSR_FLAG_ASYNC_COUNT: never wait for the pair count (capacity guess + overflow flag)
+FLAG_NO_SIDE_STREAM = 1 << 19   # GSR_FLAG_NO_SIDE_STREAM: SH -> RGB on the caller's stream instead of the side stream
 _FLAGS = int(os.environ.get("GSR_FLAGS", "0"), 0)
 
 
@@ -49,6 +52,20 @@ def set_flags(flags: int) -> None:
     """Extension flags passed in GsrSettings.flags by every later call (0 = default behaviour)."""
     global _FLAGS
     _FLAGS = int(flags)
+
+
+
+@contextlib.contextmanager
+def extra_flags(flags: int):
+    """`with extra_flags(FLAG_NO_CULL): ...` -- the given bits are OR-ed into every call's flags inside the block."""
+    global _FLAGS
+    old = _FLAGS
+    _FLAGS = old | int(flags)
+    try:
+        yield
+    finally:
+        _FLAGS = old
+
 
 GSR_STAGES = ("preprocess", "depth_sort", "bin", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
@@ -128,6 +145,11 @@ def _load():
     lib.gsr_last_error.argtypes = []
     _lib = lib
     return lib
+
+
+class PairCapacityExceeded(RuntimeError):
+    """FLAG_ASYNC_COUNT only: a forward emitted more (tile, Gaussian) pairs than the capacity guessed from earlier views;
+    its image is NaN.  Render again (the library counts synchronously on the next forward of that size)."""
 
 
 def _err(lib) -> str:
@@ -266,7 +288,7 @@ def _zero_scalar(device):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, keep=True):
         lib = _load()
         if not means3D.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
@@ -295,9 +317,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
-        # no input wants a gradient (torch.no_grad(), or plain tensors): a forward-only call -- the library then keeps
-        # no backward state (segment boundaries, d colour / d direction)
-        keep = any(ctx.needs_input_grad)
+        # `keep` was decided by the caller of apply() (inside forward grad mode is always off and needs_input_grad is
+        # True for a requires_grad tensor even under torch.no_grad()): a forward-only call keeps no backward state
+        # (segment boundaries, d colour / d direction)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             rc = lib.gsr_forward(ctypes.byref(pack.c), P, K, _ptr(m3), _ptr(shc), _ptr(shoc), _ptr(colc), _ptr(opc),
@@ -316,7 +338,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError(msg)
         ctx.holder = _CtxHolder(lib, handle) if keep else None
         ctx.pack = pack
-        ctx.num_rendered = nren.value
+        ctx._nren = nren.value
         ctx.shapes = (means3D.shape, means2D.shape if means2D is not None else None,
                       None if sh is None else sh.shape, None if sh_objs is None else sh_objs.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape,
@@ -364,7 +386,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if ctx.pack.c.debug:
                 torch.save({"grad_color": gcol, "grad_objects": gobj}, "snapshot_bw.dump")
                 msg += " (gradients saved to snapshot_bw.dump)"
-            raise RuntimeError(msg)
+            raise (PairCapacityExceeded if rc == 5 else RuntimeError)(msg)
         if P == 0:
             for t in (d_m3, d_m2, d_sh, d_obj, d_col, d_op, d_sc, d_ro, d_cov):
                 if t is not None:
@@ -374,7 +396,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         def shaped(t, shape):
             return None if t is None else t.reshape(shape)
         return (shaped(d_m3, s[0]), shaped(d_m2, s[1]), shaped(d_sh, s[2]), shaped(d_obj, s[3]), shaped(d_col, s[4]),
-                shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None)
+                shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None, None)
 
 
 class _RasterizeGaussiansRaw(torch.autograd.Function):
@@ -382,7 +404,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     RAW parameter tensors of a reference-style GaussianModel."""
 
     @staticmethod
-    def forward(ctx, xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation, raster_settings):
+    def forward(ctx, xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation, raster_settings,
+                keep=True):
         lib = _load()
         if not xyz.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
@@ -406,7 +429,6 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
-        keep = any(ctx.needs_input_grad)           # forward-only call: no backward state is kept (see above)
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
@@ -422,7 +444,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             raise Exception(msg) if rc == 1 else RuntimeError(msg)
         ctx.holder = _CtxHolder(lib, handle) if keep else None
         ctx.pack = pack
-        ctx.num_rendered = nren.value
+        ctx._nren = nren.value
         ctx.shapes = (xyz.shape, means2D.shape, features_dc.shape, features_rest.shape,
                       None if objects_dc is None else objects_dc.shape, opacity.shape, scaling.shape, rotation.shape)
         ctx.kept = (x, dc, rest, obj, op, sc, ro)
@@ -471,13 +493,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 rc = lib.gsr_backward_raw(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
                                           _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), stream)
             if rc != 0:
-                raise RuntimeError(_err(lib))
+                raise (PairCapacityExceeded if rc == 5 else RuntimeError)(_err(lib))
         s = ctx.shapes
 
         def shaped(t, shape, wanted=True):
             return None if (t is None or not wanted) else t.reshape(shape)
         return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
-                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None)
+                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None)
+
+
+def _wants_backward(*tensors) -> bool:
+    """A forward keeps backward state only if autograd can reach it: grad mode on and an input that requires grad.
+    Decided here, before Function.apply (inside forward() grad mode is off and needs_input_grad ignores no_grad())."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
@@ -485,8 +513,9 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc
     """(color[3,H,W], radii[P], objects[16,H,W]) from the RAW parameters of a reference-style GaussianModel
     (_xyz, _features_dc, _features_rest, _objects_dc or None, _opacity, _scaling, _rotation): equal to the
     getters (scene/gaussian_model.py:97-124) followed by GaussianRasterizer.forward, in one fused pass."""
+    keep = _wants_backward(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation)
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
-                                        raster_settings)
+                                        raster_settings, keep)
 
 
 @torch.no_grad()
@@ -531,8 +560,9 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
 
 def rasterize_gaussians(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    keep = _wants_backward(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
     return _RasterizeGaussians.apply(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, keep)
 
 
 class GaussianRasterizer(nn.Module):
@@ -570,14 +600,20 @@ class GaussianRasterizer(nn.Module):
 
 # ---- introspection used by the benchmark / tests -----------------------------------------------------------
 def last_num_rendered(output: torch.Tensor) -> int:
-    """Number of (tile, Gaussian) pairs of the forward that produced `output` (its grad_fn's context)."""
+    """Number of (tile, Gaussian) pairs of the forward that produced `output` (its grad_fn's context).  An
+    asynchronous-count forward (FLAG_ASYNC_COUNT) learns it here, from the context (waits for the early device copy)."""
     fn = output.grad_fn
-    return int(getattr(fn, "num_rendered", -1)) if fn is not None else -1
+    if fn is None:
+        return -1
+    n = int(getattr(fn, "_nren", -1))
+    if n < 0 and getattr(fn, "holder", None) is not None:
+        n = fn.holder.info(0)
+    return n
 
 
 _EXPORTS = {"ranges": (0, torch.int32), "pair_rank": (1, torch.int32), "n_contrib": (2, torch.int32),
             "final_T": (3, torch.float32), "order": (4, torch.int32), "off": (5, torch.int32),
-            "R": (6, torch.float32), "G": (7, torch.float32)}
+            "R": (7, torch.float32), "G": (7, torch.float32), "dv": (8, torch.int32), "offg": (9, torch.int32)}
 
 
 def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
@@ -589,12 +625,16 @@ def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
     H, W = fn.pack.c.image_height, fn.pack.c.image_width
     T = ((W + 15) // 16) * ((H + 15) // 16)
     n = {"ranges": 2 * T, "pair_rank": holder.info(0), "n_contrib": H * W, "final_T": H * W, "order": P,
-         "off": P + 1, "R": 12 * P, "G": 12 * P}[name]
+         "off": P + 1, "R": 12 * P, "G": 12 * P, "dv": 16, "offg": P + 1}[name]
+    live = None
+    if name in ("order", "off") and P > 0:
+        # only the Gaussians that emit pairs are ranked: dv[1] = V of them (order[:V], off[:V + 1] are meaningful)
+        live = int(export_state(output, "dv")[1].item()) + (1 if name == "off" else 0)
     dst = torch.empty(max(n, 1), dtype=dt, device=output.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(output.device).cuda_stream)
     if holder.lib.gsr_ctx_export(holder.handle, what, dst.data_ptr(), dst.numel() * 4, stream) != 0:
         raise RuntimeError(_err(holder.lib))
-    return dst[:n]
+    return dst[:n if live is None else live]
 
 
 def profile(enable, stages=None) -> None:
@@ -629,6 +669,6 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "rasterize_gaussians_raw2",
+           "rasterize_gaussians_raw2", "PairCapacityExceeded",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

@@ -56,10 +56,52 @@ def _settings(cam, pc, pipe, bg_color, scaling_modifier) -> GaussianRasterizatio
                                          pc.active_sh_degree, cam.camera_center, False, pipe.debug)
 
 
+class RenderResult(dict):
+    """The dict of reference gaussian_renderer/__init__.py:99-103, with one entry made on demand: `visibility_filter`
+    (= radii > 0) costs a compare kernel per view that the attack never looks at (training code does), so it is
+    computed -- on the stream current at that moment -- the first time it is read.  The key is present from the start
+    (`in`, keys(), len() see it); items() / values() / get() / [] / pop() resolve it."""
+    _LAZY = "visibility_filter"
+
+    def _resolve(self):
+        v = dict.__getitem__(self, self._LAZY)
+        if v is None:
+            v = dict.__getitem__(self, "radii") > 0
+            dict.__setitem__(self, self._LAZY, v)
+        return v
+
+    def __getitem__(self, key):
+        return self._resolve() if key == self._LAZY else dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        if key == self._LAZY and key in self:
+            self._resolve()
+        return dict.pop(self, key, *default)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def copy(self):
+        self._resolve()
+        return dict(self)
+
+    def __repr__(self):
+        self._resolve()
+        return dict.__repr__(self)
+
+
 def _result(image, screenspace_points, radii, objects) -> dict:
     """The dict of reference gaussian_renderer/__init__.py:99-103 (the image is NOT clamped)."""
-    return dict(render=image, viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii,
-                render_object=objects)
+    return RenderResult(render=image, viewspace_points=screenspace_points, visibility_filter=None, radii=radii,
+                        render_object=objects)
 
 
 def _python_colours(cam, pc):
@@ -71,10 +113,31 @@ def _python_colours(cam, pc):
     return torch.clamp_min(eval_sh(pc.active_sh_degree, coeffs, rays) + 0.5, 0.0)
 
 
+_ZEROS = {}      # (device, shape, dtype) -> (zero tensor, its _version): the storage every view's screenspace_points aliases
+
+
+def _zero_points(like: torch.Tensor, requires_grad: bool) -> torch.Tensor:
+    """A fresh LEAF of zeros shaped like `like` without a fill kernel per view: the values are never written by the
+    rasteriser (only .grad is), so all views alias one zero buffer per (device, shape).  Should a caller write into
+    one of them in place, the buffer's version changes and it is replaced."""
+    if not like.is_cuda:
+        return torch.zeros_like(like, requires_grad=requires_grad)
+    key = (like.device, tuple(like.shape), like.dtype)
+    hit = _ZEROS.get(key)
+    if hit is None or hit[0]._version != hit[1]:
+        z = torch.zeros(like.shape, dtype=like.dtype, device=like.device)
+        if len(_ZEROS) > 64:
+            _ZEROS.clear()
+        hit = _ZEROS[key] = (z, z._version)
+        # the fill runs on the current stream; views rendered on other streams must not read ahead of it
+        torch.cuda.current_stream(like.device).synchronize()
+    return hit[0].detach().requires_grad_(requires_grad)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     # The reference builds `zeros_like(...) + 0` and calls retain_grad() on that non-leaf (:25-29); a zero LEAF gives
     # callers the same thing (values 0, .grad filled by backward) without an add kernel and a gradient copy per view.
-    screenspace_points = torch.zeros_like(pc.get_xyz, requires_grad=bool(getattr(pipe, "viewspace_grad", True)))
+    screenspace_points = _zero_points(pc.get_xyz, bool(getattr(pipe, "viewspace_grad", True)))
     st = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     no_objects = bool(getattr(pipe, "skip_objects", False))
 

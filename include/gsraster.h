@@ -36,7 +36,8 @@ enum {
   GSR_ERR_INVALID = 1,  /* bad argument combination / sizes */
   GSR_ERR_DEVICE = 2,   /* a HIP call failed (message names the stage) */
   GSR_ERR_NOMEM = 3,
-  GSR_ERR_STATE = 4     /* e.g. backward called twice on a released context */
+  GSR_ERR_STATE = 4,    /* e.g. backward called twice on a released context */
+  GSR_ERR_OVERFLOW = 5  /* GSR_FLAG_ASYNC_COUNT only: the forward emitted more pairs than the guessed capacity */
 };
 
 /* flags */
@@ -61,6 +62,18 @@ enum {
 #define GSR_FLAG_TILE_MAP(m) ((uint32_t)(((m) & 3u) + 1u) << 12)
 #define GSR_FLAG_NO_SEGMENTS (1u << 16)
 #define GSR_FLAG_FWD_SHARED (1u << 17)
+/* Asynchronous pair count.  By default gsr_forward waits (once, early, behind work it has already enqueued) for the
+ * number of (tile, Gaussian) pairs before it sizes the pair buffers -- the only host synchronisation of the path.
+ * With this flag a forward whose (P, H, W) has been rendered before on this device sizes them from the count that
+ * earlier forward saw, plus 25 % + 64 K pairs of head-room, and never waits: *num_rendered is then -1 (ask
+ * gsr_ctx_info(ctx, 0) later).  If the scene emits more pairs than that capacity, nothing is composited, out_color is
+ * filled with NaN, gsr_backward on the context returns GSR_ERR_OVERFLOW, and the next forward counts synchronously
+ * again.  Opt-in: a caller that never looks at the image or calls gsr_backward would not notice an overflow. */
+#define GSR_FLAG_ASYNC_COUNT (1u << 18)
+/* gsr_forward runs the colour half of its per-Gaussian stage (SH -> RGB) on a library-owned side stream, beside the
+ * binning chain of the same view, and joins it before compositing (events; the caller's stream semantics are
+ * unchanged).  This flag keeps everything on the caller's stream. */
+#define GSR_FLAG_NO_SIDE_STREAM (1u << 19)
 
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the

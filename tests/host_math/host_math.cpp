@@ -78,4 +78,14 @@ void hm_strip_masks4(int n, const float* geo, float x0, float x1, float y0, floa
   }
 }
 
+// geo [n,6] as above; rect_in [4] = rminx, rminy, rmaxx, rmaxy (tiles); out [n,4] = the tightened rect
+void hm_tighten_rect(int n, const float* geo, int gridx, int gridy, const int* rect_in, int* out) {
+  for (int i = 0; i < n; ++i) {
+    const float* g = geo + 6 * i;
+    int x0 = rect_in[0], y0 = rect_in[1], x1 = rect_in[2], y1 = rect_in[3];
+    tighten_rect(g[0], g[1], g[2], g[3], g[4], g[5], gridx, gridy, x0, y0, x1, y1);
+    out[4 * i] = x0; out[4 * i + 1] = y0; out[4 * i + 2] = x1; out[4 * i + 3] = y1;
+  }
+}
+
 }  // extern "C"

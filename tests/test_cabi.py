@@ -119,3 +119,21 @@ def test_patch_reference_rebinds_render_everywhere():
     finally:
         for m in (gr, user, other):
             sys.modules.pop(m.__name__, None)
+
+
+def test_render_result_makes_the_visibility_filter_on_demand():
+    """render()'s dict (reference gaussian_renderer/__init__.py:99-103) has the `visibility_filter` key from the start;
+    the tensor (radii > 0) is made the first time it is read."""
+    import torch
+    from gsplat_attack.renderer import RenderResult
+    radii = torch.tensor([0, 3, 0, 7], dtype=torch.int32)
+    r = RenderResult(render=torch.zeros(3, 2, 2), viewspace_points=None, visibility_filter=None, radii=radii,
+                     render_object=None)
+    assert "visibility_filter" in r and len(r) == 5 and list(r.keys())[2] == "visibility_filter"
+    assert dict.__getitem__(r, "visibility_filter") is None            # not made yet
+    assert r["visibility_filter"].tolist() == [False, True, False, True]
+    assert r.get("visibility_filter") is r["visibility_filter"]
+    r2 = RenderResult(render=None, viewspace_points=None, visibility_filter=None, radii=radii, render_object=None)
+    assert dict(r2.items())["visibility_filter"].tolist() == [False, True, False, True]
+    r3 = RenderResult(render=None, viewspace_points=None, visibility_filter=None, radii=radii, render_object=None)
+    assert r3.pop("visibility_filter").tolist() == [False, True, False, True] and "visibility_filter" not in r3

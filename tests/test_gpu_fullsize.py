@@ -81,8 +81,8 @@ def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
     img = render(cam, model, PipelineParams(skip_objects=True), torch.zeros(3, device=dev))["render"]
     ranges = D.export_state(img, "ranges").view(-1, 2).long()
     pairs = D.export_state(img, "pair_rank").long()
-    order0 = D.export_state(img, "order").long()
-    inv = torch.empty_like(order0)
+    order0 = D.export_state(img, "order").long()           # the V Gaussians that emit pairs, by depth rank
+    inv = torch.full((model.get_xyz.shape[0],), -1, dtype=torch.long, device=dev)
     inv[order0] = torch.arange(order0.numel(), device=dev)
     ranks = inv[pairs & ((1 << 28) - 1)]                 # a pair's value is its Gaussian; its depth rank through `order`
     assert int((pairs >> 28).max()) <= 15
@@ -102,10 +102,10 @@ def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
     # ranks map to depths in non-decreasing order
     order = D.export_state(img, "order").long()
     recs = D.export_state(img, "G").view(-1, 12)
-    depth_by_rank = recs[order, 9]
-    vis = (model_radii(model, cam, dev) > 0)[order]          # records of culled Gaussians are not written
-    d = depth_by_rank[vis]
+    d = recs[order, 9]                                       # every ranked Gaussian's record was written
     assert bool((d[1:] >= d[:-1]).all())
+    assert bool((model_radii(model, cam, dev)[order] > 0).all())
+    assert int(inv[pairs & ((1 << 28) - 1)].min()) >= 0      # every listed Gaussian is a ranked one
 
 
 def test_nyc_cull_and_fused_paths_agree_at_full_size(nyc):
@@ -122,7 +122,11 @@ def test_nyc_cull_and_fused_paths_agree_at_full_size(nyc):
         D.set_flags(0)
     assert torch.equal(img0, out1["render"])
     for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
+        # the same partial rows are summed per Gaussian; only a Gaussian whose full rect has more rows than K9 stages at
+        # once (summed by the whole wave) and whose tightened rect has fewer (summed by one lane) adds them in another order
+        scale = g0[k].abs().max().clamp_min(1e-30)
+        assert ((g0[k] - g1[k]).abs().max() / scale).item() <= 2e-6, k
+        assert (g0[k] != g1[k]).float().mean().item() <= 1e-3, k
     # Default (long lists walked as segments by the backward): the forward is the same bits; the backward starts each
     # segment from the forward's stored (T, C) instead of dividing T back through the whole list -- same numbers
     # within float32 rounding, and the segment boundaries move with the culled pairs.

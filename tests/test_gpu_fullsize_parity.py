@@ -156,7 +156,12 @@ def _windows_for(D, model, cam, bg, scale=1.0, extra=0):
     ranges = D.export_state(img, "ranges").view(-1, 2).long()
     wins, longest = pick_windows(ranges, gx, gy, extra=extra, seed=gx * gy)
     radii = out["radii"].cpu()
-    depth = D.export_state(img, "G").view(-1, 12)[:, 9].cpu()
+    # depth keys from a forward over the full 3-sigma rects: every Gaussian with radius > 0 then has its record written
+    with D.extra_flags(D.FLAG_NO_CULL):
+        full = render(cam, model, PipelineParams(skip_objects=True), bg, scale)
+    depth = D.export_state(full["render"], "G").view(-1, 12)[:, 9].cpu()
+    assert torch.equal(full["radii"].cpu(), radii)
+    del full
     depth = torch.where(radii > 0, depth, torch.zeros_like(depth))       # records of culled Gaussians are not written
     return wins, longest, gx, gy, (depth, radii)
 

@@ -62,10 +62,13 @@ def hip_depth_keys(inp, cam, bg, sh_degree=3, scale_modifier=1.0):
     t = {k: (None if v is None else v.detach().to(dev).float()) for k, v in inp.items()}
     P = t["means3D"].shape[0]
     st = settings_for(cam, bg, sh_degree, scale_modifier, cls=D.GaussianRasterizationSettings, device=dev)
-    color, radii, _ = D.GaussianRasterizer(raster_settings=st)(
-        means3D=t["means3D"].requires_grad_(True), means2D=torch.zeros(P, 3, device=dev), opacities=t["opacities"],
-        shs=t.get("shs"), sh_objs=t.get("sh_objs"), colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
-        rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
+    # full 3-sigma rects: then every Gaussian with radius > 0 has its record (and depth) written; with the default flags
+    # a Gaussian whose alpha >= 1/255 footprint misses the image emits nothing and leaves no record
+    with D.extra_flags(D.FLAG_NO_CULL):
+        color, radii, _ = D.GaussianRasterizer(raster_settings=st)(
+            means3D=t["means3D"].requires_grad_(True), means2D=torch.zeros(P, 3, device=dev), opacities=t["opacities"],
+            shs=t.get("shs"), sh_objs=t.get("sh_objs"), colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
+            rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
     if P == 0:
         return torch.zeros(0)
     keys = D.export_state(color, "G").view(-1, 12)[:, 9].cpu()

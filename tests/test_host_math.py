@@ -195,3 +195,48 @@ def test_strip_masks_are_conservative_and_tight(lib):
             same += int((ref.astype(bool) == bit).sum())
             assert (~touches & bit).sum() < 0.35 * max((~touches).sum(), 1)
         assert same >= 0.999 * n * (int(ymax) // 4 + 1)
+
+
+def test_tightened_rect_keeps_every_contributing_tile(lib):
+    """tighten_rect (K1, default flags) shrinks a splat's 3-sigma tile rect to the bounding box of its alpha >= 1/255
+    footprint.  No tile in which some pixel passes the reference's alpha test may fall outside the shrunk rect (brute
+    force over an 8x8-tile image), an opacity below 1/255 must empty it, and it must actually shrink most rects."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    th = rng.uniform(0, math.pi, n)
+    s1, s2 = np.exp(rng.uniform(-1.5, 3.0, n)), np.exp(rng.uniform(-1.5, 3.0, n))
+    c, s = np.cos(th), np.sin(th)
+    a = (c * c) * s1 * s1 + (s * s) * s2 * s2 + 0.3
+    b = c * s * (s1 * s1 - s2 * s2)
+    cc = (s * s) * s1 * s1 + (c * c) * s2 * s2 + 0.3
+    det = a * cc - b * b
+    A, B, C = cc / det, -b / det, a / det
+    G = 8                                                    # 8x8 tiles = 128x128 pixels
+    cx, cy = rng.uniform(-40, 168, n), rng.uniform(-40, 168, n)
+    o = np.concatenate([rng.uniform(0, 1, n // 2), rng.uniform(0, 0.02, n - n // 2)])
+    geo = np.ascontiguousarray(np.stack([cx, cy, A, B, C, o], 1).astype(np.float32))
+    rect = np.array([0, 0, G, G], np.int32)
+    out = np.zeros((n, 4), np.int32)
+    lib.hm_tighten_rect.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.hm_tighten_rect(n, ptr(geo), G, G, ptr(rect), ptr(out))
+    xs, ys = np.meshgrid(np.arange(16.0 * G), np.arange(16.0 * G))
+    g64 = geo.astype(np.float64)
+    shrunk = 0
+    for i0 in range(0, n, 250):
+        gi = g64[i0:i0 + 250]
+        dx = gi[:, 0, None, None] - xs[None]
+        dy = gi[:, 1, None, None] - ys[None]
+        power = -0.5 * (gi[:, 2, None, None] * dx * dx + gi[:, 4, None, None] * dy * dy) - gi[:, 3, None, None] * dx * dy
+        alpha = np.minimum(0.99, gi[:, 5, None, None] * np.exp(np.minimum(power, 0)))
+        ok = (power <= 0) & (alpha >= 1.0 / 255.0)
+        tiles = ok.reshape(len(gi), G, 16, G, 16).any(axis=(2, 4))              # [i, ty, tx]
+        for j in range(len(gi)):
+            x0, y0, x1, y1 = out[i0 + j]
+            assert 0 <= x0 <= x1 <= G and 0 <= y0 <= y1 <= G
+            inside = np.zeros((G, G), bool)
+            inside[y0:y1, x0:x1] = True
+            assert not (tiles[j] & ~inside).any(), f"splat {i0 + j}: a contributing tile lies outside the tightened rect"
+            if g64[i0 + j, 5] < 0.99 / 255.0:
+                assert (x1 - x0) * (y1 - y0) == 0
+            shrunk += int((x1 - x0) * (y1 - y0) < G * G)
+    assert shrunk > 0.5 * n
