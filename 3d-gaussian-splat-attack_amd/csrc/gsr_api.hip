@@ -850,7 +850,7 @@ int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const flo
 
 static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
                          float* dshs, float* dsh_dc, float* dsh_objs, float* dcolors_precomp, float* dopacities,
-                         float* dscales, float* drotations, float* dcov3D, void* stream) {
+                         float* dscales, float* drotations, float* dcov3D, void* stream, bool accumulate = false) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_backward: null context");
   if (!grad_color) return set_err(GSR_ERR_INVALID, "gsr_backward: grad_color is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -950,6 +950,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
+    pa.accumulate = accumulate ? 1 : 0;
     const dim3 gridK9((unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK));
     if (c->raw && ((pa.dsh == nullptr) != (pa.dsh_dc == nullptr)))
       return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
@@ -989,6 +990,14 @@ int gsr_backward_raw(GsrCtx* c, const float* grad_color, const float* grad_objec
   if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw: context came from gsr_forward; use gsr_backward");
   return backward_impl(c, grad_color, grad_objects, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, dobjects_dc, nullptr,
                        dopacity_logit, dlog_scaling, drotation_raw, nullptr, stream);
+}
+
+int gsr_backward_raw_into(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dxyz, float* dmeans2D,
+                          float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
+                          float* dlog_scaling, float* drotation_raw, int32_t accumulate, void* stream) {
+  if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw_into: context came from gsr_forward; use gsr_backward");
+  return backward_impl(c, grad_color, grad_objects, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, dobjects_dc, nullptr,
+                       dopacity_logit, dlog_scaling, drotation_raw, nullptr, stream, accumulate != 0);
 }
 
 int gsr_mark_visible(const GsrSettings* s, int32_t P, const float* means3D, uint8_t* present, void* stream) {

@@ -1178,6 +1178,7 @@ struct PreBwdArgs {
   float* dscales;
   float* drots;
   float* dcov3d;
+  int accumulate;         // != 0: every output is ADDED to (read-modify-write) and Gaussians without pairs are left alone
 };
 
 // Generic form (any K): one thread per Gaussian walks its own partial rows and its own SH row.
@@ -1189,6 +1190,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   const int K = a.K;
   if (g >= a.P) return;
   const uint32_t o0 = a.offg[g] * a.nsub, o1 = a.offg[g + 1] * a.nsub;
+  if (o1 == o0 && a.accumulate) return;   // no pairs: nothing to add
   if (o1 == o0) {   // no pairs: zero gradients
     if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
     if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
@@ -1201,6 +1203,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
     return;
   }
+  const bool acc = a.accumulate != 0;
+  auto put = [acc](float* p, float v) { *p = acc ? *p + v : v; };
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
   for (uint32_t e = o0; e < o1; ++e) {
     const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
@@ -1209,9 +1213,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     dr += p1.z; dg += p1.w; db += p2.x;
   }
   if (a.dsh_objs) {
-    float acc[NUM_OBJ];
+    float acc_o[NUM_OBJ];
 #pragma unroll
-    for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
+    for (int c = 0; c < NUM_OBJ; ++c) acc_o[c] = 0.f;
     if (a.part_obj) {
       for (uint32_t e = o0; e < o1; ++e) {
         const float4 tg = a.part[(size_t)e * PART_F4 + 2];
@@ -1219,12 +1223,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 v = a.part_obj[(size_t)e * 4 + q];
-          acc[4 * q] += v.x; acc[4 * q + 1] += v.y; acc[4 * q + 2] += v.z; acc[4 * q + 3] += v.w;
+          acc_o[4 * q] += v.x; acc_o[4 * q + 1] += v.y; acc_o[4 * q + 2] += v.z; acc_o[4 * q + 3] += v.w;
         }
       }
     }
 #pragma unroll
-    for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
+    for (int c = 0; c < NUM_OBJ; ++c) put(&a.dsh_objs[(size_t)g * NUM_OBJ + c], acc_o[c]);
   }
   View v;
   load_view(v, a.va);
@@ -1234,16 +1238,20 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
   const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
   const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
-  if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
-  if (GEOM && a.dopac) a.dopac[g] = dop;
+  if (GEOM && a.dmeans2D) { put(&a.dmeans2D[3 * g], dndcx); put(&a.dmeans2D[3 * g + 1], dndcy); put(&a.dmeans2D[3 * g + 2], 0.f); }
+  if (GEOM && a.dopac) put(&a.dopac[g], dop);
   const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
   float dp[3] = {0.f, 0.f, 0.f};
-  if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
+  if (a.dcolors) { put(&a.dcolors[3 * g], dr); put(&a.dcolors[3 * g + 1], dg); put(&a.dcolors[3 * g + 2], db); }
   if (a.sh) {
     const uint32_t cl = (__float_as_uint(e1.z) >> 31) | ((__float_as_uint(e1.w) >> 31) << 1) | ((__float_as_uint(e2.x) >> 31) << 2);
     const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
-    if (a.dsh) {
+    if (a.dsh && !acc) {
       sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
+    } else if (a.dsh && K <= 16) {
+      float scratch[48];
+      sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
+      for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] += scratch[i];
     } else {
       float scratch[48];
       sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
@@ -1263,14 +1271,14 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     }
     float dc6[6];
     project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
-    if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
+    if (a.dmeans3D) { put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]); }
     if (a.cov3d) {
-      if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
+      if (a.dcov3d) for (int i = 0; i < 6; ++i) put(&a.dcov3d[6 * g + i], dc6[i]);
     } else if (a.dscales || a.drots) {
       float ds[3], dq[4];
       cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
-      if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
-      if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+      if (a.dscales) { put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]); }
+      if (a.drots) { put(&a.drots[4 * g], dq[0]); put(&a.drots[4 * g + 1], dq[1]); put(&a.drots[4 * g + 2], dq[2]); put(&a.drots[4 * g + 3], dq[3]); }
     }
   }
 }
@@ -1541,6 +1549,16 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   if (nw <= 0) return;
   uint32_t o0 = 0, o1 = 0;
   if (g < a.P) { o0 = a.offg[g] * a.nsub; o1 = a.offg[g + 1] * a.nsub; }
+  const bool acc = a.accumulate != 0;
+  auto put = [acc](float* p, float v) { *p = acc ? *p + v : v; };
+  // the record and the position of a Gaussian with rows are requested now, ahead of the row summation that does not
+  // depend on them (the kernel is a chain of dependent memory phases per wave: every phase started early is time won)
+  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e2 = e0;
+  float p[3] = {0.f, 0.f, 0.f};
+  if (o1 != o0) {
+    e0 = a.G0[REC * g]; e1 = a.G1[REC * g]; e2 = a.G2[REC * g];
+    p[0] = a.means[3 * g]; p[1] = a.means[3 * g + 1]; p[2] = a.means[3 * g + 2];
+  }
   // ---- sum this Gaussian's partial rows (the wave's rows are one contiguous span) ------------------------------------
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
   {
@@ -1587,7 +1605,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   // ---- phase A: chain rule per Gaussian ------------------------------------------------------------------------------
   float hdir[3] = {0.f, 0.f, 0.f}, hrgb[3] = {0.f, 0.f, 0.f};
   if (g < a.P) {
-    if (o1 == o0) {   // culled: zero gradients (dL/dSH: phase B writes the zeros)
+    if (o1 == o0 && acc) {
+      // nothing to add for a Gaussian without pairs
+    } else if (o1 == o0) {   // culled: zero gradients (dL/dSH: phase B writes the zeros)
       if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
       if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
       if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
@@ -1598,9 +1618,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
     } else {
       if (a.dsh_objs) {
-        float acc[NUM_OBJ];
+        float acc_o[NUM_OBJ];
 #pragma unroll
-        for (int c = 0; c < NUM_OBJ; ++c) acc[c] = 0.f;
+        for (int c = 0; c < NUM_OBJ; ++c) acc_o[c] = 0.f;
         if (a.part_obj) {
           for (uint32_t e = o0; e < o1; ++e) {
             const float4 tg = a.part[(size_t)e * PART_F4 + 2];
@@ -1608,26 +1628,24 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float4 v4 = a.part_obj[(size_t)e * 4 + q];
-              acc[4 * q] += v4.x; acc[4 * q + 1] += v4.y; acc[4 * q + 2] += v4.z; acc[4 * q + 3] += v4.w;
+              acc_o[4 * q] += v4.x; acc_o[4 * q + 1] += v4.y; acc_o[4 * q + 2] += v4.z; acc_o[4 * q + 3] += v4.w;
             }
           }
         }
 #pragma unroll
-        for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc[c];
+        for (int c = 0; c < NUM_OBJ; ++c) put(&a.dsh_objs[(size_t)g * NUM_OBJ + c], acc_o[c]);
       }
       View v;
       load_view(v, a.va);
-      const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
       const float A = e0.z, B = e0.w, C = e1.x;
       // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
       const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
       const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
       const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
-      if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }
-      if (GEOM && a.dopac) a.dopac[g] = RAW ? dop * e1.y * (1.f - e1.y) : dop;   // e1.y = sigmoid(raw opacity)
-      const float p[3] = {a.means[3 * g], a.means[3 * g + 1], a.means[3 * g + 2]};
+      if (GEOM && a.dmeans2D) { put(&a.dmeans2D[3 * g], dndcx); put(&a.dmeans2D[3 * g + 1], dndcy); put(&a.dmeans2D[3 * g + 2], 0.f); }
+      if (GEOM && a.dopac) put(&a.dopac[g], RAW ? dop * e1.y * (1.f - e1.y) : dop);   // e1.y = sigmoid(raw opacity)
       float dp[3] = {0.f, 0.f, 0.f};
-      if (a.dcolors) { a.dcolors[3 * g] = dr; a.dcolors[3 * g + 1] = dg; a.dcolors[3 * g + 2] = db; }
+      if (a.dcolors) { put(&a.dcolors[3 * g], dr); put(&a.dcolors[3 * g + 1], dg); put(&a.dcolors[3 * g + 2], db); }
       if (a.sh) {
         const uint32_t cl = clamp_bits_of(e1.z, e1.w, e2.x);
         hrgb[0] = (cl & 1u) ? 0.f : dr; hrgb[1] = (cl & 2u) ? 0.f : dg; hrgb[2] = (cl & 4u) ? 0.f : db;
@@ -1665,9 +1683,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         }
         float dc6[6];
         project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
-        if (a.dmeans3D) { a.dmeans3D[3 * g] = dp[0]; a.dmeans3D[3 * g + 1] = dp[1]; a.dmeans3D[3 * g + 2] = dp[2]; }
+        if (a.dmeans3D) { put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]); }
         if (a.cov3d) {
-          if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = dc6[i];
+          if (a.dcov3d) for (int i = 0; i < 6; ++i) put(&a.dcov3d[6 * g + i], dc6[i]);
         } else if (a.dscales || a.drots) {
           float ds[3], dq[4];
           cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
@@ -1675,8 +1693,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
             ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2];     // d exp(x) = exp(x)
             act_normalize4_bwd(q, inv_qn, dq, dq);
           }
-          if (a.dscales) { a.dscales[3 * g] = ds[0]; a.dscales[3 * g + 1] = ds[1]; a.dscales[3 * g + 2] = ds[2]; }
-          if (a.drots) { a.drots[4 * g] = dq[0]; a.drots[4 * g + 1] = dq[1]; a.drots[4 * g + 2] = dq[2]; a.drots[4 * g + 3] = dq[3]; }
+          if (a.dscales) { put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]); }
+          if (a.drots) { put(&a.drots[4 * g], dq[0]); put(&a.drots[4 * g + 1], dq[1]); put(&a.drots[4 * g + 2], dq[2]); put(&a.drots[4 * g + 3], dq[3]); }
         }
       }
     }
@@ -1686,6 +1704,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   {
     float* h = hand + HAND_W * lane;
     h[0] = hdir[0]; h[1] = hdir[1]; h[2] = hdir[2]; h[3] = hrgb[0]; h[4] = hrgb[1]; h[5] = hrgb[2];
+    h[6] = (o1 != o0) ? 1.f : 0.f;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1708,7 +1727,17 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         const float bj = pick4(q, b[j], b[4 + j], b[8 + j], b[12 + j]);
         out[3 * j] = bj * g0; out[3 * j + 1] = bj * g1; out[3 * j + 2] = bj * g2;
       }
-      store_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, out);
+      if (acc) {
+        if (h[6] != 0.f) {
+          float cur[12];
+          load_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, cur);
+#pragma unroll
+          for (int j = 0; j < 12; ++j) out[j] += cur[j];
+          store_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, out);
+        }
+      } else {
+        store_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, out);
+      }
     }
   }
 }

@@ -116,6 +116,8 @@ def _load():
     lib.gsr_forward_raw.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [vp, vp, vp, ctypes.POINTER(vp), i64p, vp]
     lib.gsr_backward_raw.restype = ctypes.c_int
     lib.gsr_backward_raw.argtypes = [vp] * 12
+    lib.gsr_backward_raw_into.restype = ctypes.c_int
+    lib.gsr_backward_raw_into.argtypes = [vp] * 11 + [i32, vp]
     lib.gsr_forward_raw2.restype = ctypes.c_int
     lib.gsr_forward_raw2.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [i32] + [vp] * 7 + [vp, vp, vp, i64p, vp]
     lib.gsr_ctx_free.restype = None
@@ -399,14 +401,65 @@ class _RasterizeGaussians(torch.autograd.Function):
                 shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None, None)
 
 
+class GradBucket:
+    """Caller-owned gradient bucket of a reference-style GaussianModel: ONE flat float32 buffer of 59 floats per Gaussian
+    in the order xyz | f_dc | f_rest | opacity | scaling | rotation (the layout of the flat buffer the fused backward
+    hands to autograd, and of the all-reduce bucket of gsplat_attack.dist).  A rasterise call that is given a bucket
+    writes its attribute gradients straight into it -- the first backward after reset() overwrites, later ones add
+    (gsr_backward_raw_into) -- and returns no gradient for those inputs to autograd: the per-view 236-byte-per-Gaussian
+    gradient buffer and the framework's read-modify-write accumulation into .grad both disappear (reference
+    attack.py:476-494 accumulates B views' gradients in .grad).  One bucket per stream: concurrent backwards must not
+    share one."""
+    CUTS = (0, 3, 6, 51, 52, 55, 59)
+    NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    SHAPES = ((3,), (1, 3), (15, 3), (1,), (3,), (4,))
+
+    def __init__(self, P: int, device):
+        self.P = int(P)
+        self.flat = torch.empty(59 * self.P, dtype=torch.float32, device=device)
+        self.fresh = True          # the next backward overwrites instead of adding
+        self.used = False          # some backward has written since reset()
+
+    def reset(self):
+        self.fresh, self.used = True, False
+
+    def slices(self):
+        P = self.P
+        return [self.flat[c0 * P:c1 * P] for c0, c1 in zip(self.CUTS[:-1], self.CUTS[1:])]
+
+    def views(self) -> dict:
+        """name -> tensor view shaped like the model's parameter (e.g. _features_rest: [P,15,3])."""
+        return {n: sl.view(self.P, *shp) for n, sl, shp in zip(self.NAMES, self.slices(), self.SHAPES)}
+
+    def add_(self, other: "GradBucket"):
+        """Fold another (stream's) bucket into this one.  Buckets no backward wrote to hold nothing."""
+        if other.used:
+            if self.used:
+                self.flat.add_(other.flat)
+            else:
+                self.flat.copy_(other.flat)
+                self.used, self.fresh = True, False
+        return self
+
+    def assign_to(self, model):
+        """model.<param>.grad = the bucket's view of it (no copy).  An unused bucket means zero gradients."""
+        if not self.used:
+            self.flat.zero_()
+            self.used, self.fresh = True, False
+        for n, v in self.views().items():
+            p = getattr(model, n)
+            p.grad = v.view(p.shape)
+
+
 class _RasterizeGaussiansRaw(torch.autograd.Function):
     """Same path with the activation getters fused into the kernels (gsr_forward_raw / gsr_backward_raw): takes the
     RAW parameter tensors of a reference-style GaussianModel."""
 
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation, raster_settings,
-                keep=True):
+                keep=True, bucket=None):
         lib = _load()
+        ctx.bucket = bucket
         if not xyz.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
                                f"{xyz.device}); there is no CPU path")
@@ -470,7 +523,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         def out(cond, *shape):
             return torch.empty(*shape, dtype=torch.float32, device=device) if cond else None
         want_sh = need[2] or need[3]
-        if need[0] and want_sh and need[5] and need[6] and need[7]:
+        all59 = need[0] and want_sh and need[5] and need[6] and need[7]
+        bucket = ctx.bucket if all59 else None
+        if bucket is not None:
+            # the caller's bucket receives the 59 attribute gradients directly (overwritten by the first backward after
+            # reset(), added to by the others); autograd gets no gradient for those inputs
+            if bucket.P != P or bucket.flat.device != device:
+                raise ValueError("grad bucket does not match the model (P or device)")
+            d_x, d_dc, d_rest, d_op, d_sc, d_ro = bucket.slices()
+        elif all59:
             # All 59 attack-relevant floats per Gaussian are wanted (the normal case): carve them out of ONE flat
             # buffer, in the order xyz | f_dc | f_rest | opacity | scaling | rotation.  autograd hands these views to
             # .grad as they are, so a data-parallel caller can sum the whole gradient with a single collective
@@ -490,16 +551,26 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if P > 0:
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-                rc = lib.gsr_backward_raw(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
-                                          _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), stream)
+                if bucket is not None:
+                    rc = lib.gsr_backward_raw_into(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
+                                                   _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro),
+                                                   0 if bucket.fresh else 1, stream)
+                else:
+                    rc = lib.gsr_backward_raw(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
+                                              _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), stream)
             if rc != 0:
                 raise (PairCapacityExceeded if rc == 5 else RuntimeError)(_err(lib))
+        if bucket is not None:
+            bucket.fresh, bucket.used = False, True
+            s = ctx.shapes
+            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None,
+                    None if d_obj is None else d_obj.reshape(s[4]), None, None, None, None, None, None)
         s = ctx.shapes
 
         def shaped(t, shape, wanted=True):
             return None if (t is None or not wanted) else t.reshape(shape)
         return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
-                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None)
+                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None, None)
 
 
 def _wants_backward(*tensors) -> bool:
@@ -509,13 +580,13 @@ def _wants_backward(*tensors) -> bool:
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
-                            raster_settings):
+                            raster_settings, grad_bucket: Optional["GradBucket"] = None):
     """(color[3,H,W], radii[P], objects[16,H,W]) from the RAW parameters of a reference-style GaussianModel
     (_xyz, _features_dc, _features_rest, _objects_dc or None, _opacity, _scaling, _rotation): equal to the
     getters (scene/gaussian_model.py:97-124) followed by GaussianRasterizer.forward, in one fused pass."""
     keep = _wants_backward(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation)
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
-                                        raster_settings, keep)
+                                        raster_settings, keep, grad_bucket)
 
 
 @torch.no_grad()
@@ -669,6 +740,6 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "rasterize_gaussians_raw2", "PairCapacityExceeded",
+           "rasterize_gaussians_raw2", "PairCapacityExceeded", "GradBucket",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

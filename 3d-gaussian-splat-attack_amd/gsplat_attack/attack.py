@@ -32,7 +32,7 @@ from torch import nn
 from . import dist as gdist
 from . import pgd
 from .streams import StreamRing
-from .renderer import PipelineParams, render, render_pair
+from .renderer import PipelineParams, _has_raw_layout, render, render_pair
 
 GROUPS = ("color", "position", "scaling", "rotation", "opacity")
 
@@ -76,6 +76,35 @@ def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsi
             getattr(pgd, f"gaussian_{name}_{norm}_attack")(model, alpha, epsilon, originals[attr])
 
 
+class PhaseTimer:
+    """Optional per-phase GPU timing of pgd_attack (bench.py's `pgd` block): HIP events on the current stream at the
+    phase boundaries of every iteration, read back once at the end.  Meaningful with streams=1 (one stream, phases do
+    not overlap).  Phases: render (rasteriser forward), loss (detector forward), backward (detector backward +
+    rasteriser backward), reduce (bucket fold / all-reduce / .grad assignment), step, rerender."""
+    PHASES = ("render", "loss", "backward", "reduce", "step", "rerender")
+
+    def __init__(self):
+        self.marks = []          # (phase, start event, end event)
+        self._t = None
+
+    def start(self):
+        self._t = torch.cuda.Event(enable_timing=True)
+        self._t.record()
+
+    def lap(self, phase: str):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((phase, self._t, e))
+        self._t = e
+
+    def totals_ms(self) -> dict:
+        torch.cuda.synchronize()
+        out = {p: 0.0 for p in self.PHASES}
+        for ph, a, b in self.marks:
+            out[ph] += a.elapsed_time(b)
+        return out
+
+
 def _world():
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         return torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -102,7 +131,8 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                log: Optional[Callable[[dict], None]] = None, streams: int = 4, accumulate_grads: bool = False,
                batch_loss: bool = False, loss_reduction: str = "sum", background=None,
                success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
-               originals: Optional[dict] = None) -> List[float]:
+               originals: Optional[dict] = None, use_buckets: bool = True,
+               timer: Optional["PhaseTimer"] = None) -> List[float]:
     """Runs up to `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
     initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
     pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order.
@@ -123,7 +153,10 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         says whether the detector was fooled on that view, the B flags are gathered over the ranks, and
                         when at least B-1 views succeed (attack.py:560) the loop stops and the attacked model is written
                         to save_path (attack.py:566-568).  The flags of the last iteration are in log records
-                        ("successes") and in pgd_attack.last_successes."""
+                        ("successes") and in pgd_attack.last_successes.
+      use_buckets       (default on) the fused backward adds each view's attribute gradients into a per-stream
+                        GradBucket instead of handing autograd a fresh 59-float-per-Gaussian buffer per view; off =
+                        round-2 behaviour (A/B, tests)."""
     groups = tuple(groups)
     assert all(g in GROUPS for g in groups) and norm in ("l2", "linf") and loss_reduction in ("sum", "mean")
     dev = model.get_xyz.device
@@ -153,9 +186,28 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
     try:
         history = []
         ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" and not batch_loss else None
+        # Gradient buckets (fused path, all five groups differentiated): the rasteriser's backward writes a view's 59
+        # attribute gradients per Gaussian straight into a caller-owned flat buffer -- the first view of the iteration
+        # overwrites it, the others add -- instead of allocating 236 bytes per Gaussian per view and leaving the
+        # accumulation into .grad to autograd's read-modify-write.  One bucket per stream, folded once per iteration;
+        # the folded bucket IS the all-reduce buffer and becomes .grad without a copy.
+        buckets = None
+        if (use_buckets and dev.type == "cuda" and not frozen and getattr(pipe, "fused_activations", True)
+                and _has_raw_layout(model) and all(getattr(model, n).requires_grad for n in gdist.ATTACK_PARAMS)):
+            from diff_gaussian_rasterization import GradBucket
+            P = int(model.get_xyz.shape[0])
+            buckets = [GradBucket(P, dev) for _ in range(ring.n if ring is not None else 1)]
+            pipe = copy.copy(pipe)
+            pipe.grad_bucket = (lambda: buckets[ring.current]) if ring is not None else buckets[0]
+        run_flat = None                                    # accumulate_grads with buckets: the running sum
         for it in range(iters):
             t0 = time.perf_counter()
-            if not accumulate_grads or world > 1:
+            if timer is not None:
+                timer.start()
+            if buckets is not None:
+                for b in buckets:
+                    b.reset()
+            elif not accumulate_grads or world > 1:
                 model.zero_grad()                          # multi-GPU: .grad holds THIS step's gradient until reduced
             losses = []
             if batch_loss:
@@ -170,15 +222,45 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                 for cam in mine:                           # one forward+backward per view: peak memory = one view per stream
                     with (ring.next() if ring is not None else contextlib.nullcontext()):
                         img = render(cam, model, pipe, bg)["render"]
+                        if timer is not None:
+                            timer.lap("render")
                         loss = loss_fn(img[None])
                         if loss_reduction == "mean":
                             loss = loss / len(cameras)
+                        if timer is not None:
+                            timer.lap("loss")
                         loss.backward()
+                        if timer is not None:
+                            timer.lap("backward")
                         losses.append(loss.detach())
                 if ring is not None:
                     ring.join()
             total = torch.stack(losses).sum() if losses else torch.zeros((), device=dev)
-            if world > 1:
+            if buckets is not None:
+                tot = buckets[0]
+                for b in buckets[1:]:
+                    tot.add_(b)
+                if not tot.used:                           # a rank without views contributes zeros
+                    tot.flat.zero_()
+                    tot.used, tot.fresh = True, False
+                if world > 1:
+                    flat = tot.flat
+                    if flat.is_cuda and torch.distributed.get_backend() == "gloo":
+                        host = flat.cpu()                  # rehearsal on one GPU: gloo reduces host tensors
+                        torch.distributed.all_reduce(host)
+                        flat.copy_(host)
+                    else:
+                        torch.distributed.all_reduce(flat)     # ONE collective over 59 floats per Gaussian
+                    torch.distributed.all_reduce(total)
+                if accumulate_grads:
+                    run_flat = tot.flat.clone() if run_flat is None else run_flat.add_(tot.flat)
+                    keep = tot.flat
+                    tot.flat = run_flat
+                    tot.assign_to(model)
+                    tot.flat = keep
+                else:
+                    tot.assign_to(model)
+            elif world > 1:
                 gdist.allreduce_attribute_grads(model, names=reduce_names)     # one bucket: 236 MB, or 192 MB colour-only
                 torch.distributed.all_reduce(total)
                 if accumulate_grads:
@@ -186,16 +268,24 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         p = getattr(model, n)
                         running[n] = p.grad.clone() if n not in running else running[n].add_(p.grad)
                         p.grad = running[n]
+            if timer is not None:
+                timer.lap("reduce")
             _step(model, originals, groups, norm, alpha, epsilon)
+            if timer is not None:
+                timer.lap("step")
             history.append(float(total))
             rec = {"iter": it, "loss": history[-1], "views": len(cameras)}
             done = False
             if success_fn is not None:
                 imgs = render_combined(model, background, mine, bg, pipe)
+                if timer is not None:
+                    timer.lap("rerender")
                 flags = gather_success([success_fn(im, i) for im, i in zip(imgs, my_idx)], len(cameras), rank, world, dev)
                 pgd_attack.last_successes = flags
                 rec["successes"] = flags
-                done = sum(flags) >= len(cameras) - 1      # attack.py:560: all views, or all but one
+                # attack.py:560: all views of the batch, or all but one; a single view (batch_mode false,
+                # attack.py:590-598) has to succeed itself
+                done = sum(flags) >= max(len(cameras) - 1, 1)
             if log is not None:
                 if dev.type == "cuda":
                     torch.cuda.synchronize()
@@ -215,30 +305,52 @@ pgd_attack.last_successes = None
 
 
 def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5, max_iters: int = 20,
-               success_fn: Callable[[torch.Tensor, int], bool], save_path: Optional[str] = None, **kw) -> dict:
-    """The batch schedule of the reference's run() (attack.py:463-475, 560-569): the pending views are attacked
-    `batch_size` at a time; a batch that reaches B-1 successes is retired, one that exhausts `max_iters` iterations is
-    dropped, and when no view is pending the attacked model is saved.  Perturbations accumulate across batches: every
-    batch projects onto the eps-ball around the ORIGINAL attributes (attack.py:397-403 captures them once).
-    -> {"batches": [{"views", "iters", "success", "loss"}], "all_succeeded"}."""
+               success_fn: Callable[[torch.Tensor, int], bool], save_path: Optional[str] = None,
+               truncate: bool = True, **kw) -> dict:
+    """The batch schedule of the reference's run() (attack.py:463-475, 556-569), iteration for iteration: ONE global
+    counter `it` runs over range(max_iters * num_batches); the pending views are attacked `batch_size` at a time; an
+    iteration with (it + 1) % max_iters == 0 attacks nothing and DROPS the current batch (:470-475) -- so a batch that
+    starts after an early success only gets what is left of the current max_iters window; a batch that reaches B-1
+    successes is retired (:560-563), and the attacked model is saved when the retired batch was the last pending one
+    (:564-569), whether or not earlier batches were dropped.  truncate=False keeps the views beyond a multiple of
+    batch_size as a smaller last batch instead of dropping them.  Perturbations accumulate across batches: every batch
+    projects onto the eps-ball around the ORIGINAL attributes (attack.py:389-394 captures them once).
+    -> {"batches": [{"views", "iters", "success", "loss"}], "all_succeeded", "saved", "iterations"}."""
     pending = list(range(len(cameras)))
+    if truncate and len(pending) % batch_size:             # the reference drops the views beyond a multiple of B (:417-423)
+        pending = pending[:len(pending) - len(pending) % batch_size]
+    num_batches = max(1, -(-len(pending) // batch_size))   # ceil (:428); truncate=False keeps a smaller last batch
     originals = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
-    report = []
-    while pending:
+    report, saved = [], False
+    it, budget = 0, max_iters * num_batches
+    rank, _ = _world()
+    while pending and it < budget:
+        if (it + 1) % max_iters == 0:                      # the window's last slot: the batch is dropped, nothing is attacked
+            it += 1
+            if report and report[-1]["views"] == pending[:batch_size] and not report[-1]["success"]:
+                report[-1]["dropped"] = True
+            else:
+                report.append({"views": pending[:batch_size], "iters": 0, "success": False, "loss": None, "dropped": True})
+            pending = pending[batch_size:]
+            continue
         cur = pending[:batch_size]
         batch = [cameras[i] for i in cur]
-        hist = pgd_attack(model, batch, iters=max_iters - 1, background=background,      # attack.py:470: the iteration
-                          success_fn=lambda im, j: success_fn(im, cur[j]),                # budget's last slot drops the batch
-                          originals=originals, **kw)
+        left = min(max_iters - 1 - (it % max_iters), budget - it)     # attack iterations before the window's last slot
+        hist = pgd_attack(model, batch, iters=left, background=background,
+                          success_fn=lambda im, j: success_fn(im, cur[j]), originals=originals, **kw)
+        it += len(hist)
         flags = pgd_attack.last_successes or []
-        ok = sum(flags) >= len(cur) - 1
+        ok = bool(hist) and sum(flags) >= len(cur) - 1
         report.append({"views": cur, "iters": len(hist), "success": bool(ok), "loss": hist[-1] if hist else None})
-        pending = pending[len(cur):]
-    done = all(b["success"] for b in report)
-    rank, _ = _world()
-    if done and save_path is not None and rank == 0:
-        model.save_ply(save_path)
-    return {"batches": report, "all_succeeded": done}
+        if ok:
+            pending = pending[len(cur):]
+            if not pending:                                # attack.py:564-569
+                if save_path is not None and rank == 0:
+                    model.save_ply(save_path)
+                saved = True
+        # not ok: the window is exhausted; the next loop turn is its last slot and drops the batch
+    return {"batches": report, "all_succeeded": all(b["success"] for b in report) and not pending, "saved": saved,
+            "iterations": it}
 
 
 def combine_with_background(attacked, background):

@@ -15,10 +15,15 @@ from __future__ import annotations
 import torch
 
 
+_WARNED = set()
+
+
 def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Tensor, l2: bool) -> bool:
-    """Device tensors take the fused HIP update (libgsraster.so: gsr_pgd_step, two launches per tensor).  Returns
-    False for host tensors (the formulation below is then used as written: that is the CPU statement the golden
-    fixtures pin).  A device tensor the kernel cannot take raises instead of silently running tensor ops."""
+    """Device tensors the fused HIP update can take -- contiguous float32 [rows, <= 48 columns], which is every tensor
+    the reference attacks -- take it (libgsraster.so: gsr_pgd_step, two launches per tensor) and True is returned.
+    False = the caller runs the tensor formulation below: host tensors (the CPU statement the golden fixtures pin),
+    and device tensors in another layout (float64, non-contiguous, wider rows, 0-dim), with one warning per layout --
+    the same arithmetic through tensor ops, slower.  Mismatched shapes or devices raise."""
     if not x.is_cuda:
         return False
     if grad is None:
@@ -27,13 +32,19 @@ def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Ten
     if not (grad.is_cuda and x0.is_cuda) or x.shape != grad.shape or x.shape != x0.shape:
         raise ValueError(f"pgd step: x {tuple(x.shape)} on {x.device}, grad {tuple(grad.shape)} on {grad.device}, "
                          f"x0 {tuple(x0.shape)} on {x0.device} must agree")
-    if x.dim() < 1 or x.shape[0] == 0:
+    if x.numel() == 0:
         return True
-    rows = x.shape[0]
-    cols = x.numel() // rows
-    if x.dtype != torch.float32 or not x.is_contiguous() or cols > 48:
-        raise NotImplementedError("gsr_pgd_step updates contiguous float32 [rows, <=48] tensors in place "
-                                  f"(got {x.dtype}, contiguous={x.is_contiguous()}, {cols} columns)")
+    rows = x.shape[0] if x.dim() >= 1 else 0
+    cols = x.numel() // rows if rows else 0
+    if x.dim() < 1 or x.dtype != torch.float32 or not x.is_contiguous() or cols > 48:
+        key = (x.dtype, x.is_contiguous(), x.dim() < 1, cols > 48)
+        if key not in _WARNED:
+            _WARNED.add(key)
+            import warnings
+            warnings.warn("gsplat_attack.pgd: gsr_pgd_step updates contiguous float32 [rows, <=48] tensors; this one "
+                          f"({x.dtype}, contiguous={x.is_contiguous()}, shape {tuple(x.shape)}) takes the tensor-op "
+                          "formulation instead", stacklevel=3)
+        return False
     grad = grad.to(torch.float32).contiguous()
     x0 = x0.to(torch.float32).contiguous()
     import ctypes
@@ -72,7 +83,8 @@ def l2_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, 
         # branch-free form of "if norm > 0 ... else zero step" (no host sync on the device path)
         step = torch.where(norm > 0, grad / norm.clamp_min(torch.finfo(grad.dtype).tiny), torch.zeros_like(grad))
         x.add_(step, alpha=-alpha)
-        delta = (x - x0).renorm(p=2, dim=0, maxnorm=epsilon)
+        d = x - x0
+        delta = d.renorm(p=2, dim=0, maxnorm=epsilon) if d.dim() >= 2 else d.reshape(-1, 1).renorm(p=2, dim=0, maxnorm=epsilon).reshape(d.shape)
         x.copy_(x0 + delta)
 
 

@@ -21,7 +21,8 @@ class PipelineParams:
     """The three switches render() reads (reference attack.py:254-256, configs/config.yaml:61-63)."""
 
     def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False,
-                 skip_objects: bool = False, fused_activations: bool = True, viewspace_grad: bool = True):
+                 skip_objects: bool = False, fused_activations: bool = True, viewspace_grad: bool = True,
+                 grad_bucket=None):
         self.convert_SHs_python = convert_SHs_python
         self.compute_cov3D_python = compute_cov3D_python
         self.debug = debug
@@ -35,6 +36,10 @@ class PipelineParams:
         # colour-only attack turns it off (and freezes the geometry parameters): the backward then runs without the
         # geometry sums and the projection chain rule (BASELINE configs 2 and 3)
         self.viewspace_grad = viewspace_grad
+        # extension (default None = autograd fills .grad): a diff_gaussian_rasterization.GradBucket -- or a callable
+        # returning the bucket to use for this call (one per stream) -- that receives the 59 attribute gradients of the
+        # fused path directly; see GradBucket
+        self.grad_bucket = grad_bucket
 
 
 def _has_raw_layout(pc) -> bool:
@@ -144,9 +149,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     fused = (getattr(pipe, "fused_activations", True) and override_color is None and not pipe.convert_SHs_python
              and not pipe.compute_cov3D_python and _has_raw_layout(pc))
     if fused:
+        bucket = getattr(pipe, "grad_bucket", None)
+        if callable(bucket):
+            bucket = bucket()
         image, radii, objects = rasterize_gaussians_raw(
             pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, None if no_objects else pc._objects_dc,
-            pc._opacity, pc._scaling, pc._rotation, st)
+            pc._opacity, pc._scaling, pc._rotation, st, grad_bucket=bucket)
         return _result(image, screenspace_points, radii, objects)
 
     # classic surface: activated tensors through the keyword call of reference :86-95

@@ -31,6 +31,7 @@ class StreamRing:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)] if self.n > 1 else []
         self._i = 0
         self._forked = False
+        self.current = 0            # index of the stream the innermost `with ring.next()` block runs on
         if self.streams:
             # leaf gradients are accumulated on the stream their AccumulateGrad node was first made on, whatever
             # stream a view's backward runs on: intended here, and ordered by autograd
@@ -47,11 +48,13 @@ class StreamRing:
     @contextlib.contextmanager
     def next(self):
         if not self.streams:
+            self.current = 0
             yield None
             return
         if not self._forked:
             self._fork()
-        s = self.streams[self._i % self.n]
+        self.current = self._i % self.n
+        s = self.streams[self.current]
         self._i += 1
         with torch.cuda.stream(s):
             yield s

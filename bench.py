@@ -4,11 +4,18 @@
 One "step" = one view: ``render()`` forward of the S-nyc-1M synthetic scene (1,000,000 Gaussians, SH degree 3,
 1920x1080) through the drop-in ``diff_gaussian_rasterization`` package (libgsraster.so,
 hand-written HIP) + one backward from a fixed dL/dC[3,H,W] down to .grad on all seven raw attribute tensors
-(59 attack-relevant floats per Gaussian), object channels off.  With N > 1 every rank renders its own view of
-the ring (weak scaling) and the attribute gradients are sum-all-reduced over RCCL each step, inside the timed
-region.  Inputs are resident in HBM before the timed region starts.  Consecutive views are dealt round-robin over
---streams HIP streams (default 4; gsplat_attack.streams) so one view's sort/scan kernels run beside another's
-compositing kernels -- exactly K views are still rendered and differentiated inside the timed region.
+(59 attack-relevant floats per Gaussian), object channels off.  Inputs are resident in HBM before a timed region
+starts.  A timed region is EXACTLY --steps steps between barrier + synchronise on both sides; --regions of them are
+run back to back and the MEDIAN region is reported (every region's time is listed).
+
+N = 1 (the BASELINE metric): `value` = independent views dealt round-robin over --streams HIP streams (default 4; what a
+batch of views allows: reference attack.py:476-485), `sequential` = the same views strictly one after another on
+one stream (what the reference's default loop, batch_mode false, and config 4's one view per rank see), `pgd` = whole PGD
+iterations (config 3 and config 4 on one GPU) split into their phases.
+N > 1 (config 4): a step is one PGD iteration's worth of rasterisation per rank -- --views-per-rank forward+backward
+passes into the rank's gradient bucket, ONE sum all-reduce of the bucket (59 floats per Gaussian) over RCCL, the fused
+projected-gradient step on all six attribute tensors -- strictly in that order, as a PGD loop needs it; `allreduce_ms`
+is the collective alone.  --independent-views restores round 2's behaviour (views pipelined across steps, no update).
 
     python bench.py                       # N=1, defaults finish in ~2 minutes incl. the CPU baseline
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
@@ -39,7 +46,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "r02_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r02.sh)
+PMC_FILE = "r03_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r03.sh)
 
 
 def log(msg: str) -> None:
@@ -136,8 +143,9 @@ def parity_and_cfg1(dev) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--scene", default="nyc-1M")
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (parity-size runs)")
     ap.add_argument("--width", type=int, default=None)
@@ -150,14 +158,16 @@ def main():
                          "the fused raw-parameter path")
     ap.add_argument("--no-cull", action="store_true", help="keep the full 3-sigma tile rects (A/B of the footprint cull)")
     ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the views are dealt over (view i runs on stream i %% S): the small sort/scan "
-                         "kernels of one view overlap the compositing kernels of the next")
+                    help="HIP streams independent views are dealt over (view i runs on stream i %% S)")
+    ap.add_argument("--views-per-rank", type=int, default=1, help="N > 1: views each rank renders per PGD step")
+    ap.add_argument("--independent-views", action="store_true",
+                    help="N > 1: round-2 behaviour (views pipelined across steps, all-reduce but no parameter update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed forward-only / PGD-iteration extras")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (dense point, forward-only, PGD blocks)")
     ap.add_argument("--scale-modifier", type=float, default=1.0,
                     help="render()'s scaling_modifier for the main timed region (diagnostic: 2.43 = the dense data point)")
     ap.add_argument("--one-camera", action="store_true",
-                    help="render the same camera every step (round-1 behaviour) instead of cycling the 8 ring cameras")
+                    help="render the same camera every step instead of cycling the 8 ring cameras")
     ap.add_argument("--dense-pairs", type=float, default=10e6,
                     help="target pair count of the second, denser data point (scale_modifier is searched for it); 0 = skip")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
@@ -166,6 +176,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the raster path has no CPU fallback")
     from gsplat_attack import dist as gdist
+    from gsplat_attack import pgd as gpgd
     from gsplat_attack.renderer import PipelineParams, render
     from gsplat_attack.scenes import make_scene
     import diff_gaussian_rasterization as D
@@ -184,23 +195,13 @@ def main():
     if args.no_cull:
         D.set_flags(D.FLAG_NO_CULL)
 
-    n_views = max(8, world)
+    n_views = max(8, world * max(args.views_per_rank, 1))
     if rank == 0:
         log(f"building scene {args.scene} on {dev}")
     model, cams, spec = make_scene(args.scene, device=dev, P=args.P, width=args.width, height=args.height,
                                    n_views=n_views)
     cam = cams[rank % n_views]
     H, W = cam.image_height, cam.image_width
-    # every timed step renders the NEXT camera of the 8-view ring (rank r, step i: view (i * world + r) mod 8), so that
-    # no step re-renders what the previous one left in the caches
-    step_no = [0]
-
-    def next_cam():
-        if args.one_camera:
-            return cam
-        c = cams[(step_no[0] * world + rank) % n_views]
-        step_no[0] += 1
-        return c
     P = model.get_xyz.shape[0]
     pipe = PipelineParams(skip_objects=not args.objects, viewspace_grad=not args.color_only,
                           fused_activations=not args.classic)
@@ -209,10 +210,19 @@ def main():
             getattr(model, n_).requires_grad_(False)
     bg = torch.zeros(3, device=dev)
     gc = torch.randn(3, H, W, generator=torch.Generator().manual_seed(99)).to(dev)
-
-    info = {}
-
     scale_mod = [args.scale_modifier]
+    step_no = [0]
+    pgd_loop = world > 1 and not args.independent_views
+    B = max(args.views_per_rank, 1) if pgd_loop else 1
+
+    def next_cam():
+        # every step renders the NEXT camera of the ring (rank r: views (i * world + r) mod 8): no step re-renders what
+        # the previous one left in the caches
+        if args.one_camera:
+            return cam
+        c = cams[(step_no[0] * world + rank) % n_views]
+        step_no[0] += 1
+        return c
 
     def step():
         model.zero_grad()
@@ -224,100 +234,162 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
 
-    def run_steps(n):
-        if streams is None:
+    def run_steps(n, use_streams=True):
+        sts = streams if use_streams else None
+        if sts is None:
             for _ in range(n):
                 step()
             return
-        for s_ in streams:
+        for s_ in sts:
             s_.wait_stream(torch.cuda.current_stream(dev))
         for i in range(n):
-            with torch.cuda.stream(streams[i % len(streams)]):
+            with torch.cuda.stream(sts[i % len(sts)]):
                 step()
-        for s_ in streams:
+        for s_ in sts:
             torch.cuda.current_stream(dev).wait_stream(s_)
+
+    # ---- N > 1: one PGD iteration per step (config 4) ---------------------------------------------------------------
+    ar_events = []
+    bytes_reduced = [0]
+    if pgd_loop:
+        from gsplat_attack.streams import StreamRing
+        ring = StreamRing(min(args.streams, B), dev)
+        buckets = [D.GradBucket(P, dev) for _ in range(ring.n)]
+        pipe_b = PipelineParams(skip_objects=not args.objects, grad_bucket=lambda: buckets[ring.current])
+        originals = {n_: getattr(model, n_).detach().clone() for n_ in gdist.ATTACK_PARAMS}
+        rank_cams = [cams[(rank * B + v) % n_views] for v in range(B)]
+
+        def pgd_step():
+            for b_ in buckets:
+                b_.reset()
+            for c_ in rank_cams:
+                with ring.next():
+                    render(c_, model, pipe_b, bg, scale_mod[0])["render"].backward(gc)
+            ring.join()
+            tot = buckets[0]
+            for b_ in buckets[1:]:
+                tot.add_(b_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if rehearse:
+                host = tot.flat.cpu()
+                dist.all_reduce(host)
+                tot.flat.copy_(host)
+            else:
+                dist.all_reduce(tot.flat)                  # ONE collective: 59 floats per Gaussian
+            e1.record()
+            ar_events.append((e0, e1))
+            bytes_reduced[0] = tot.flat.numel() * 4
+            tot.assign_to(model)
+            for n_ in gdist.ATTACK_PARAMS:                 # the identical projected step on every rank (attack.py:53-173)
+                p_ = getattr(model, n_)
+                gpgd.l2_step_(p_, p_.grad, 0.5, 5.0, originals[n_])
+
+        def run_steps(n, use_streams=True):                # noqa: F811 -- the N > 1 definition of a step
+            for _ in range(n):
+                pgd_step()
 
     if rank == 0:
         log(f"scene ready: P={P}, {W}x{H}; warmup x{args.warmup}")
     for i in range(args.warmup):
-        out = step()
+        if pgd_loop:
+            pgd_step()
+        else:
+            out = step()
         torch.cuda.synchronize()
-        if rank == 0:
+        if rank == 0 and not pgd_loop:
             log(f"warmup step {i} done, N={D.last_num_rendered(out['render'])}")
-    del out
+    ar_events.clear()
+    info = {}
     # pair / visible counts of every camera of the ring (the roofline figures use their means)
-    per_cam = []
-    with torch.no_grad():
-        for c_ in (cams[:n_views] if not args.one_camera else [cam]):
-            o_ = render(c_, model, pipe, bg, scale_mod[0])
-            per_cam.append((int((o_["radii"] > 0).sum().item()), o_))
-    # num_rendered of a forward-only call: read it from a grad-enabled render's context
-    Ns = []
+    Ns, Vs = [], []
     for c_ in (cams[:n_views] if not args.one_camera else [cam]):
         o_ = render(c_, model, pipe, bg, scale_mod[0])
         Ns.append(D.last_num_rendered(o_["render"]))
+        Vs.append(int(D.export_state(o_["render"], "dv")[1].item()))
         del o_
-    info["N_per_camera"] = Ns
-    info["V_per_camera"] = [v for v, _ in per_cam]
-    info["N"] = int(round(sum(Ns) / len(Ns)))
-    info["V"] = int(round(sum(info["V_per_camera"]) / len(per_cam)))
-    del per_cam
+    info["N_per_camera"], info["V_per_camera"] = Ns, Vs
+    info["N"], info["V"] = int(round(sum(Ns) / len(Ns))), int(round(sum(Vs) / len(Vs)))
     step_no[0] = 0
 
-    # Timed region: only the dominant kernel (K7, the backward composite) is timed, by two HIP events that
-    # hipExtLaunchKernelGGL stamps with the dispatch's own start and end on its launch stream (events recorded around
-    # the launch would also count the time the dispatch waits behind the other streams' kernels); bracketing all
-    # seven stages costs ~10 us of queue gap each.
+    def timed_regions(n_regions, use_streams=True, profile_stage=None):
+        """n_regions x exactly --steps steps, each between barrier + synchronise; per-region seconds (max over ranks)."""
+        secs = []
+        for _ in range(n_regions):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(args.steps, use_streams)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                if rehearse:
+                    t = t.cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            secs.append(dt)
+        return secs
+
+    # Timed regions: only the dominant kernel (K7, the backward composite) is timed inside them, by two HIP events that
+    # hipExtLaunchKernelGGL stamps with the dispatch's own start and end on its launch stream.
     DOMINANT = "render_bwd"
-    if streams is not None:
-        run_steps(2 * len(streams))          # untimed: lets every stream build its own workspace blocks
-        torch.cuda.synchronize()
+    run_steps(2 * max(args.streams, 1))                    # untimed: lets every stream build its own workspace blocks
+    torch.cuda.synchronize()
     D.profile(True, stages=[DOMINANT])
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    secs = timed_regions(args.regions)
+    dom_calls = D.profile_read()[DOMINANT]
+    dom_ms_timed = dom_calls[0] / max(dom_calls[1], 1)
+    med = sorted(secs)[len(secs) // 2]
     if rank == 0:
-        log(f"timed region done: {args.steps} steps in {elapsed:.3f} s (host enqueue {t_enq:.3f} s)")
-        if elapsed < 0.1:
-            log(f"WARNING: the timed region lasted {elapsed * 1e3:.1f} ms; use --steps >= 300 for a stable number")
-    dom_ms_timed = D.profile_read()[DOMINANT][0] / args.steps
+        log(f"timed regions ({args.steps} steps each): " + ", ".join(f"{x * 1e3:.1f} ms" for x in secs))
+    ar_ms = None
+    if ar_events:
+        torch.cuda.synchronize()
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+    # the same views strictly one after another on one stream
+    seq = None
+    if world == 1 and streams is not None:
+        D.profile(False)
+        secs1 = timed_regions(args.regions, use_streams=False)
+        m1 = sorted(secs1)[len(secs1) // 2]
+        seq = {"value": round(args.steps / m1, 2), "unit": "views/s", "ms_per_step": round(m1 / args.steps * 1e3, 4),
+               "regions_ms": [round(x * 1e3, 2) for x in secs1], "streams": 1,
+               "what": "the same fwd+bwd views strictly one after another on ONE stream: what the reference's default "
+                       "loop (configs/config.yaml:56 batch_mode false, attack.py:486-494) and config 4's one view per "
+                       "rank per step see"}
     # Untimed extra pass with every stage bracketed: the per-stage breakdown reported under "stages".
     D.profile(True)
     nb = max(3, min(args.steps, 10))
-    for _ in range(nb):
-        step()
+    if pgd_loop:
+        for _ in range(nb):
+            pgd_step()
+        nb_views = nb * B
+    else:
+        for _ in range(nb):
+            step()
+        nb_views = nb
     torch.cuda.synchronize()
-    stages = {k: (ms * args.steps / nb, calls) for k, (ms, calls) in D.profile_read().items()}
+    stages = {k: (ms / max(nb_views, 1), calls) for k, (ms, calls) in D.profile_read().items()}
     D.profile(False)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         N, V, HW = info["N"], info["V"], H * W
         sb = stage_bytes(P, V, N, HW)
         per = {}
-        for name, (ms, calls) in stages.items():
-            launches = args.steps
-            avg_ms = ms / max(launches, 1)
+        for name, (avg_ms, calls) in stages.items():
             per[name] = {"avg_ms": round(avg_ms, 4),
                          "GBps": round(sb[name] / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and sb[name] else None}
         dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd", "tile_sort", "bin"),
                   key=lambda n: per[n]["avg_ms"])
         dom_ms = per[dom]["avg_ms"]
         if dom == DOMINANT:
-            dom_ms = round(dom_ms_timed, 4)      # the duration measured inside the timed region itself
+            dom_ms = round(dom_ms_timed, 4)      # the duration measured inside the timed regions themselves
         achieved = sb[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes of the dominant kernel from the committed PMC passes (profiles/collect_r01.sh: FETCH_SIZE and
+        # HBM bytes of the dominant kernel from the committed PMC passes (profiles/collect_r03.sh: FETCH_SIZE and
         # WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only when they
         # were taken on this very workload
         traffic = None
@@ -326,14 +398,11 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2, 1>",
                     "preprocess_bwd": "void gsr::k_pre_bwd<true, true>",
-                    "preprocess": "void gsr::k_pre_fwd<true>"}.get(dom)
+                    "preprocess": "void gsr::k_pre_color<true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
                 n_valu = pmc["per_kernel"][kern].get("SQ_INSTS_VALU")
                 if n_valu:
-                    # secondary roofline of the dominant kernel: a SIMD issues one plain wave64 VALU instruction per
-                    # 2 cycles (MI355X_MICROARCH.md; tests/ubench/valu_rate.hip measures 2.5 for v_add_f32, 2.8 for
-                    # v_fma_f32, 4.1 for DPP forms, ~9.5 for v_exp_f32 at 8 waves/SIMD), 1024 SIMDs, 2.4 GHz
                     peak = 1024 * 2.4e9 / 2 / 1e9
                     ach = n_valu / (per[dom]["avg_ms"] * 1e-3) / 1e9
                     valu = {"bound": "fp32 VALU issue", "wave_instr_per_launch": round(n_valu),
@@ -342,33 +411,41 @@ def main():
         except Exception:
             traffic = None
         B_total = 304 * P + 548 * V + 116 * N + 40 * HW
-        t_view = elapsed / args.steps
+        views_per_step = world * B
+        t_view = med / (args.steps * B)
+        workload = (f"{spec.name}: {P} Gaussians (SH degree 3), {W}x{H}, "
+                    + (f"one PGD iteration per step: {B} view(s) per GPU fwd+bwd into a gradient bucket, one all-reduce of "
+                       "59 floats/Gaussian, fused L2 step on all six attribute tensors" if pgd_loop else
+                       "one view per step per GPU, render() fwd + bwd to all attribute grads")
+                    + (", 16 object channels on" if args.objects else ", object channels off")
+                    + (", gradients on SH coefficients only" if args.color_only else "")
+                    + (", classic activated-tensor surface" if args.classic else ""))
         result = {
             "metric": "fwd+bwd views/sec @1080p, 1M Gaussians",
-            "value": round(world * args.steps / elapsed, 3),
+            "value": round(views_per_step * args.steps / med, 3),
             "unit": "views/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(t_view * 1e3, 4),
+            "ms_per_step": round(med / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{spec.name}: {P} Gaussians (SH degree 3), {W}x{H}, one view per step per GPU, "
-                                   "render() fwd + bwd to all attribute grads"
-                                   + (", 16 object channels on" if args.objects else ", object channels off")
-                                   + (", gradients on SH coefficients only" if args.color_only else "")
-                                   + (", classic activated-tensor surface" if args.classic else ""),
+            "regions_ms": [round(x * 1e3, 2) for x in secs],
+            "timing": f"median of {args.regions} regions of exactly {args.steps} steps, each between barrier + synchronise",
+            "config": {"workload": workload,
                        "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
+                       "loop": "pgd" if pgd_loop else "independent views",
+                       "views_per_rank": B,
                        "cameras": "one fixed camera" if args.one_camera else
                                   f"the {n_views} ring cameras in turn (V and N are means over them)",
                        "N_pairs_per_camera": info["N_per_camera"], "V_visible_per_camera": info["V_per_camera"],
                        "streams": args.streams,
-                       "parallelism": f"views sharded 1/GPU, dp{world}"
-                                      + (f", consecutive views pipelined over {args.streams} HIP streams per GPU"
-                                         if args.streams > 1 else "")
+                       "parallelism": f"views sharded {B}/GPU, dp{world}"
+                                      + (f", independent views pipelined over {args.streams} HIP streams per GPU"
+                                         if args.streams > 1 and not pgd_loop else "")
                                       + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -376,7 +453,7 @@ def main():
                          f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
                          "this workload (not measured inside this run; FETCH_SIZE doubled per MI355X_MICROARCH.md)",
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
-                         # the same kernel with nothing beside it (untimed one-stream pass): in the timed region its
+                         # the same kernel with nothing beside it (untimed one-stream pass): in the timed regions its
                          # launches share the chip with the other streams' kernels
                          "avg_launch_ms_alone": per[dom]["avg_ms"],
                          "note": "K6/K7 are bound by VALU instruction issue (256*N alpha evaluations), not by HBM; "
@@ -387,9 +464,18 @@ def main():
         }
         if valu is not None:
             result["roofline"]["valu"] = valu
+        if seq is not None:
+            result["sequential"] = seq
+        if world > 1:
+            result["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
+            result["bytes_reduced"] = bytes_reduced[0] or 59 * 4 * P
+            result["views_per_rank"] = B
+            result["scaling_note"] = ("N > 1 lines time whole PGD iterations (serialised render -> backward -> all-reduce -> "
+                                      "step); compare them with `pgd.cfg4_one_gpu` of the N = 1 line, not with its `value` "
+                                      "(independent views, no update)")
         if world == 1 and not args.no_extras and args.dense_pairs > 0:
             # Second data point: the same scene with the splats scaled up until a view emits ~10 M pairs (BASELINE.md's
-            # nominal N; the SURVEY section 8d distributions give 3 M).  scale_modifier is render()'s own argument.
+            # nominal N; the SURVEY section 8d distributions give 2.5 M).  scale_modifier is render()'s own argument.
             log("dense data point: searching scale_modifier ...")
             lo, hi = 1.0, 6.0
             for _ in range(7):
@@ -405,75 +491,22 @@ def main():
             step_no[0] = 0
             run_steps(12)
             torch.cuda.synchronize()
-            nd = max(40, min(args.steps, 150))
-            t0 = time.perf_counter()
-            run_steps(nd)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            sd = timed_regions(3)
+            sd1 = timed_regions(3, use_streams=False)
+            dt, dt1 = sorted(sd)[1], sorted(sd1)[1]
             Nd = sum(n_dense) / len(n_dense)
             Bd = 304 * P + 548 * V + 116 * Nd + 40 * HW            # V of the unscaled scene: a lower bound
-            result["dense"] = {"value": round(nd / dt, 2), "unit": "views/s", "ms_per_step": round(dt / nd * 1e3, 4),
-                               "steps": nd, "scale_modifier": round(scale_mod[0], 4), "N_pairs": int(round(Nd)),
+            result["dense"] = {"value": round(args.steps / dt, 2), "unit": "views/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+                               "sequential_views_per_s": round(args.steps / dt1, 2),
+                               "steps": args.steps, "scale_modifier": round(scale_mod[0], 4), "N_pairs": int(round(Nd)),
                                "N_pairs_per_camera": n_dense,
-                               "pipeline_GBps": round(Bd / (dt / nd) / 1e9, 1),
+                               "pipeline_GBps": round(Bd / (dt / args.steps) / 1e9, 1),
                                "workload": "same scene and cameras, every splat scaled by scale_modifier so that a view "
                                            "emits ~10 M (tile, Gaussian) pairs (BASELINE.md section 3 nominal)"}
             scale_mod[0] = args.scale_modifier
             step_no[0] = 0
         if world == 1 and not args.no_extras:
-            # SURVEY.md section 8d "also report": forward-only rate and one PGD iteration (untimed extras)
-            log("extras: forward-only views, PGD iterations ...")
-            from gsplat_attack.attack import pgd_attack
-            with torch.no_grad():
-                run_fwd = min(args.steps, 100)
-                for s_ in (streams or []):
-                    s_.wait_stream(torch.cuda.current_stream(dev))
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(run_fwd):
-                    if streams is None:
-                        render(cam, model, pipe, bg)
-                    else:
-                        with torch.cuda.stream(streams[i % len(streams)]):
-                            render(cam, model, pipe, bg)
-                torch.cuda.synchronize()
-                fwd_rate = run_fwd / (time.perf_counter() - t0)
-            col_rate = None
-            if not args.color_only:
-                # gradients on the SH coefficients only (BASELINE configs 2/3): geometry frozen, lighter K7 / K8+K9
-                frozen = [getattr(model, n_) for n_ in ("_xyz", "_scaling", "_rotation", "_opacity")]
-                for p_ in frozen:
-                    p_.requires_grad_(False)
-                pipe_c = PipelineParams(skip_objects=not args.objects, viewspace_grad=False)
-                n_col = min(args.steps, 150)
-
-                def col_steps(n):
-                    for i in range(n):
-                        ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
-                        with ctx_:
-                            model.zero_grad()
-                            render(cam, model, pipe_c, bg)["render"].backward(gc)
-                for s_ in (streams or []):
-                    s_.wait_stream(torch.cuda.current_stream(dev))
-                col_steps(6)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                col_steps(n_col)
-                torch.cuda.synchronize()
-                col_rate = n_col / (time.perf_counter() - t0)
-                for p_ in frozen:
-                    p_.requires_grad_(True)
-            recs = []
-            pgd_model = model.clone()
-            pgd_attack(pgd_model, cams[:8], iters=6, groups=("color", "position", "scaling", "rotation", "opacity"),
-                       log=recs.append, streams=max(args.streams, 1))
-            pgd_ms = 1e3 * sorted(r["seconds"] for r in recs[2:])[len(recs[2:]) // 2]
-            del pgd_model
-            result["extras"] = {"fwd_only_views_per_s": round(fwd_rate, 1),
-                                "sh_grads_only_views_per_s": None if col_rate is None else round(col_rate, 1),
-                                "pgd_iteration_ms": round(pgd_ms, 3),
-                                "pgd_iteration": "8 views x (fwd+bwd) + surrogate detector loss + step on "
-                                                 "{colour, position, scaling, rotation, opacity}, one GPU"}
+            result["extras"], result["pgd"] = extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams)
         if world == 1 and not args.no_cpu_baseline:
             sp, sw, sh = (int(x) for x in args.cpu_sample.split(","))
             log(f"cpu baseline (oracle-R) on a {sp}-Gaussian {sw}x{sh} sample ...")
@@ -487,6 +520,110 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
+    """Untimed extras of the N = 1 line (SURVEY.md section 8d "also report"): forward-only and SH-only rates, and whole
+    PGD iterations split into phases."""
+    from gsplat_attack.attack import PhaseTimer, SurrogateDetector, pgd_attack
+    from gsplat_attack.renderer import PipelineParams, render
+    cam = cams[0]
+    log("extras: forward-only views, SH-only gradients ...")
+    with torch.no_grad():
+        run_fwd = min(args.steps, 100)
+        for s_ in (streams or []):
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(run_fwd):
+            if streams is None:
+                render(cam, model, pipe, bg)
+            else:
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    render(cam, model, pipe, bg)
+        torch.cuda.synchronize()
+        fwd_rate = run_fwd / (time.perf_counter() - t0)
+    col_rate = None
+    if not args.color_only:
+        # gradients on the SH coefficients only (BASELINE configs 2/3): geometry frozen, lighter K7 / K8+K9
+        frozen = [getattr(model, n_) for n_ in ("_xyz", "_scaling", "_rotation", "_opacity")]
+        for p_ in frozen:
+            p_.requires_grad_(False)
+        pipe_c = PipelineParams(skip_objects=not args.objects, viewspace_grad=False)
+        n_col = min(args.steps, 150)
+
+        def col_steps(n):
+            for i in range(n):
+                ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
+                with ctx_:
+                    model.zero_grad()
+                    render(cam, model, pipe_c, bg)["render"].backward(gc)
+        for s_ in (streams or []):
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        col_steps(6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        col_steps(n_col)
+        torch.cuda.synchronize()
+        col_rate = n_col / (time.perf_counter() - t0)
+        for p_ in frozen:
+            p_.requires_grad_(True)
+    extras = {"fwd_only_views_per_s": round(fwd_rate, 1),
+              "sh_grads_only_views_per_s": None if col_rate is None else round(col_rate, 1)}
+
+    log("pgd: config 3 (colour L2, PGD-20, B = 1) and config 4 on one GPU (8 views, five groups) ...")
+    det = SurrogateDetector().to(dev)
+    never = lambda im, i: False                            # noqa: E731 -- the success check runs, the loop never stops on it
+
+    def measure(name, views, groups, iters, n_streams, rerender):
+        m = model.clone()
+        kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0)
+        if rerender:
+            kw.update(success_fn=never, background=None)
+        pgd_attack(m, views, iters=3, **kw)                # warm-up
+        torch.cuda.synchronize()
+        recs = []
+        t0 = time.perf_counter()
+        pgd_attack(m, views, iters=iters, log=recs.append, **kw)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters * 1e3
+        out = {"iteration_ms": round(wall, 3), "views": len(views), "groups": list(groups), "streams": n_streams,
+               "what": name}
+        if n_streams == 1:
+            # phase split on one stream: HIP events at the phase boundaries + the library's own stage events
+            tm = PhaseTimer()
+            D.profile(True)
+            pgd_attack(m, views, iters=iters, timer=tm, **kw)
+            ph = {k: v / iters for k, v in tm.totals_ms().items()}
+            st = {k: ms / iters for k, (ms, _) in D.profile_read().items()}
+            D.profile(False)
+            r_bwd = st["render_bwd"] + st["preprocess_bwd"]
+            out["phases_ms"] = {
+                "raster_forward": round(ph["render"], 3),
+                "raster_backward": round(r_bwd, 3),
+                "detector": round(ph["loss"] + max(ph["backward"] - r_bwd, 0.0), 3),
+                "gradient_accumulation": round(ph["reduce"], 3),
+                "step": round(ph["step"], 3),
+                "rerender": round(ph["rerender"], 3),
+            }
+            tot = sum(out["phases_ms"].values())
+            in_scope_overhead = out["phases_ms"]["gradient_accumulation"] + out["phases_ms"]["step"]
+            out["overhead_frac"] = round(in_scope_overhead / max(tot, 1e-9), 4)
+            out["phases_note"] = ("HIP events on the one stream (with the library's per-stage events on, which add a few "
+                                  "microseconds per stage); detector = surrogate forward + its share of backward; "
+                                  "overhead_frac = (gradient_accumulation + step) / sum of phases")
+        del m
+        return out
+    pgd = {
+        "cfg3": measure("BASELINE config 3: DAGGER PGD-20, L2 on the SH colour only, ONE view per iteration, forward-only "
+                        "re-render after every step (attack.py:522-530), surrogate detector", cams[:1], ("color",), 20, 1, True),
+        "cfg4_one_gpu": measure("BASELINE config 4 on one GPU: 8 views per iteration, L2 on {colour, position, scaling, "
+                                "rotation, opacity}, one stream", cams[:8],
+                                ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False),
+        "cfg4_one_gpu_pipelined": measure("the same with the 8 views dealt over 4 streams", cams[:8],
+                                          ("color", "position", "scaling", "rotation", "opacity"), 6, max(args.streams, 1), False),
+    }
+    return extras, pgd
 
 
 if __name__ == "__main__":

@@ -11,7 +11,8 @@
  *   - plain C, no torch types: raw DEVICE pointers (float32 / int32, contiguous) + sizes + a hipStream_t
  *     passed as void*;
  *   - every call enqueues on the given stream of the CURRENT hip device; the only host synchronisation is
- *     inside gsr_forward (one 4-byte read of the number of tile/Gaussian pairs, to size the sort buffers);
+ *     inside gsr_forward: the host polls a pinned word for the number of (tile, Gaussian) pairs, which a kernel early
+ *     in the forward writes there, to size the sort buffers (GSR_FLAG_ASYNC_COUNT removes even that);
  *   - return value 0 = success, otherwise a GSR_ERR_* code and gsr_last_error() describes it
  *     (thread-local string);
  *   - the caller owns all inputs / outputs / gradient buffers and must keep the INPUT tensors of
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 100 /* 0.1.0 */
+#define GSR_VERSION 300 /* 0.3.0 */
 #define GSR_NUM_OBJECTS 16 /* object-feature channels, reference scene/gaussian_model.py:52 */
 
 enum {
@@ -150,6 +151,17 @@ int gsr_backward_raw(GsrCtx* ctx, const float* grad_color, const float* grad_obj
                      float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
                      float* dlog_scaling, float* drotation_raw, void* stream);
 
+/* gsr_backward_raw with a choice of what happens to the output buffers.  accumulate == 0: they are overwritten (zeros
+ * for Gaussians without pairs), exactly gsr_backward_raw.  accumulate != 0: the gradients are ADDED to what the buffers
+ * hold and Gaussians without pairs are not touched at all.  That is what a batch of views needs (reference
+ * attack.py:476-494: the B renders' gradients add up in .grad): the first view of a PGD iteration overwrites a
+ * caller-owned [P,59] bucket, the others add to it, and the per-view gradient buffer plus the framework's
+ * read-modify-write accumulation of 236 bytes per Gaussian and view disappear.  Concurrent calls (views on different
+ * streams) must use different buckets. */
+int gsr_backward_raw_into(GsrCtx* ctx, const float* grad_color, const float* grad_objects, float* dxyz, float* dmeans2D,
+                          float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
+                          float* dlog_scaling, float* drotation_raw, int32_t accumulate, void* stream);
+
 /* Forward-only render of TWO parameter sets as one scene: the attacked target (a) followed by the frozen background (b),
  * Gaussians numbered a then b (radii [Pa+Pb]).  Replaces what the reference does after every PGD step to check the
  * attack: deep-copy the attacked model, append the background to each of its seven tensors (seven concat_setup calls,
@@ -189,14 +201,23 @@ int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* strea
  * 2 number of pairs of a context (ctx as int64 handle in *out on input is NOT used; see gsr_ctx_info). */
 int gsr_query(int32_t what, int64_t* out);
 
-/* Per-context numbers for roofline accounting: what 0 = num_rendered (N), 1 = visible Gaussians (V; -1 if not
- * counted), 2 = workspace bytes of this context. */
+/* Per-context numbers for roofline accounting: what 0 = num_rendered (N; waits for the forward's count if it was
+ * asynchronous), 1 = visible Gaussians (V; -1: not counted on the host), 2 = workspace bytes of this context,
+ * 3 = the pair capacity the forward's buffers were sized for (= N unless GSR_FLAG_ASYNC_COUNT).
+ * A context kept for backward holds, besides 100 bytes per Gaussian and 16 per pixel, 4 bytes per pair and -- unless
+ * object channels are composited or GSR_FLAG_NO_SEGMENTS is set -- (N/256 + min(tiles, N/256) + 1) boundary records of
+ * 4 KB: 50-190 MB at N = 3-10 M pairs.  num_rendered counts the pairs of the TIGHTENED tile rects (the tiles the
+ * alpha >= 1/255 footprint's bounding box touches); under GSR_FLAG_NO_CULL it is the reference's count. */
 int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
 
 /* Copies one internal array of a context into a caller DEVICE buffer (tests / diagnostics):
- * what 0 = tile ranges [T][2] u32, 1 = sorted pair list (depth ranks) [N] u32, 2 = n_contrib [H*W] u32,
- * 3 = final_T [H*W] f32, 4 = order (rank -> Gaussian) [P] u32, 5 = off [P+1] u32,
- * 6 = depth-ordered splat records [P][3] float4, 7 = storage-ordered records (layout: csrc/gsr_kernels.hip.h). */
+ * what 0 = tile ranges [T][2] u32, 1 = sorted pair list [N] u32 (Gaussian index | strip mask << 28, tile by tile, depth
+ * order inside a tile), 2 = n_contrib [H*W] u32, 3 = final_T [H*W] f32, 4 = order (depth rank -> Gaussian; the first
+ * V = scalars[1] entries are meaningful: only Gaussians that emit pairs are ranked) [P] u32, 5 = off [P+1] u32 (pairs
+ * emitted in front of rank r; V+1 entries), 7 (and, for old callers, 6) = splat records [P][3] float4 in storage order
+ * (layout: csrc/gsr_kernels.hip.h; written for Gaussians that emit pairs), 8 = the forward's device-side scalars [16]
+ * u32 (0 pairs, 1 V, 2 smallest depth key, 3 depth digit width, 4 overflow flag, 5 boundary records, 6-7 64-bit pair
+ * count), 9 = offg [P+1] u32 (storage-order scan of tiles touched). */
 int gsr_ctx_export(const GsrCtx* ctx, int32_t what, void* dst, int64_t dst_bytes, void* stream);
 
 /* Frees every cached workspace block of the current device (blocks in use by live contexts are kept). */

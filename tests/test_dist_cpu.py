@@ -114,3 +114,50 @@ def test_flat_bucket_detection():
     assert float(shaped[5][-1, -1]) == 2.0 * (59 * P - 1)
     assert gdist._flat_view_of([torch.zeros(3), torch.zeros(3)]) is None
     assert gdist._flat_view_of([flat[0:3], flat[4:8]]) is None            # a hole
+
+
+def test_run_attack_follows_the_references_global_iteration_budget(monkeypatch):
+    """run_attack is the reference's batch schedule (attack.py:463-475, 556-569): one global iteration counter, the slot
+    (it + 1) % max_iters == 0 drops the current batch without attacking, a batch that starts late only gets the rest of
+    the window, and the model is saved when the LAST pending batch succeeds even if an earlier one was dropped."""
+    import torch
+    from gsplat_attack import attack as A
+
+    class M:
+        def __init__(self):
+            for n in A.gdist.ATTACK_PARAMS:
+                setattr(self, n, torch.zeros(2, 3))
+            self.saved = []
+
+        def save_ply(self, path):
+            self.saved.append(path)
+
+    plan = {}      # views of the batch -> (iterations it needs to succeed, or None = never)
+    calls = []
+
+    def fake_pgd(model, batch, *, iters, **kw):
+        need = plan[tuple(batch)]
+        n = iters if need is None or need > iters else need
+        calls.append((tuple(batch), iters, n))
+        ok = need is not None and need <= iters
+        fake_pgd.last_successes = [ok] * len(batch)
+        return [0.0] * n
+    fake_pgd.last_successes = None
+    monkeypatch.setattr(A, "pgd_attack", fake_pgd)
+
+    cams = list(range(7))                                  # 7 views, B = 2: the reference truncates to 6 = 3 batches
+    plan.update({(0, 1): 3, (2, 3): None, (4, 5): 2})
+    m = M()
+    rep = A.run_attack(m, cams, batch_size=2, max_iters=10, success_fn=lambda im, i: True, save_path="x.ply")
+    # batch (0,1): 9 slots left in window 0, succeeds after 3 (it = 3); batch (2,3) gets the REST of window 0 (6 attack
+    # iterations, it = 9), fails; slot it = 9 drops it (it = 10); batch (4,5) starts window 1 with 9, succeeds after 2
+    assert calls == [((0, 1), 9, 3), ((2, 3), 6, 6), ((4, 5), 9, 2)]
+    assert [b["views"] for b in rep["batches"]] == [[0, 1], [2, 3], [4, 5]]
+    assert [b["success"] for b in rep["batches"]] == [True, False, True] and rep["batches"][1].get("dropped")
+    assert rep["iterations"] == 12 and m.saved == ["x.ply"] and rep["saved"] and not rep["all_succeeded"]
+    # a last batch that never succeeds: nothing is saved
+    calls.clear()
+    plan.update({(0, 1): 1, (2, 3): 1, (4, 5): None})
+    m2 = M()
+    rep = A.run_attack(m2, cams, batch_size=2, max_iters=4, success_fn=lambda im, i: True, save_path="y.ply")
+    assert m2.saved == [] and not rep["saved"] and rep["batches"][-1]["views"] == [4, 5] and not rep["batches"][-1]["success"]

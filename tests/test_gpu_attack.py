@@ -248,5 +248,9 @@ def test_success_bookkeeping_stops_the_loop_and_saves_the_model(tmp_path):
     assert torch.allclose(back._features_dc, target._features_dc.detach(), atol=1e-6)
     # the batch schedule around it: 3 views in batches of 2
     first.clear()
+    rep = run_attack(target.clone(), cams, background=background, batch_size=2, max_iters=10, success_fn=success, streams=1,
+                     truncate=False)
+    assert [b["views"] for b in rep["batches"]] == [[0, 1], [2]] and rep["all_succeeded"] and rep["saved"]
+    first.clear()
     rep = run_attack(target.clone(), cams, background=background, batch_size=2, max_iters=10, success_fn=success, streams=1)
-    assert [b["views"] for b in rep["batches"]] == [[0, 1], [2]] and rep["all_succeeded"]
+    assert [b["views"] for b in rep["batches"]] == [[0, 1]] and rep["all_succeeded"]      # the third view is truncated

@@ -1,0 +1,325 @@
+"""Round-3 GPU tests: closed-form pins that do not go through oracle-R, integer parity of the tile lists with the
+oracle, the accumulate-into-bucket backward, the asynchronous pair count, forward-only calls keeping no backward state."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle_r as O  # noqa: E402
+
+SH_C0 = 0.28209479177387814
+
+
+def _hip():
+    import diff_gaussian_rasterization as D
+    D._load()
+    return D
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Closed-form cases.  Derived by hand from SURVEY.md section 8(a), independently of oracle/oracle_r.py:
+# camera at the origin looking down +z, view matrix = identity, tan(fov/2) = 1, 32x32 image => focal = W / (2 tan) = 16,
+# projection (row-vector convention, reference utils/graphics_utils.py:51-71 transposed) h = (x, y, z f/(f-n) - f n/(f-n), z).
+# A Gaussian at (0, 0, z) with isotropic scale s and identity rotation has Sigma_2D = (16 s / z)^2 I + 0.3 I and its
+# centre at pixel ((0 + 1) 32 - 1) / 2 = 15.5.  With 16 s / z = 2:  a = c = 4.3, conic A = C = 1 / 4.3, B = 0,
+# lambda = 4.3 + sqrt(max(0.1, 0)) => radius = ceil(3 sqrt(4.6162)) = ceil(6.4456) = 7.
+# SH degree 0: rgb = C0 sh + 0.5.  Pixel (15, 15): dx = dy = 0.5, power = -(0.25 + 0.25) / (2 * 4.3) = -0.0581395,
+# G = exp(power) = 0.9435183, alpha = o G.
+# ---------------------------------------------------------------------------------------------------------------------
+def _closed_form_settings(D, dev, bg):
+    n, f = 0.01, 100.0
+    P = torch.zeros(4, 4)
+    P[0, 0] = 1.0
+    P[1, 1] = 1.0
+    P[2, 2] = f / (f - n)
+    P[2, 3] = -(f * n) / (f - n)
+    P[3, 2] = 1.0
+    view = torch.eye(4)
+    full = view @ P.t()                                    # p_hom = [p, 1] . full
+    return D.GaussianRasterizationSettings(32, 32, 1.0, 1.0, torch.tensor(bg, device=dev), 1.0, view.to(dev), full.to(dev), 0,
+                                           torch.zeros(3, device=dev), False, False)
+
+
+def _render_closed(D, dev, xyz, scale, opac, rgb, bg):
+    n = len(xyz)
+    means = torch.tensor(xyz, dtype=torch.float32, device=dev, requires_grad=True)
+    sh = torch.tensor([[[(c - 0.5) / SH_C0 for c in col]] for col in rgb], dtype=torch.float32, device=dev, requires_grad=True)
+    op = torch.tensor(opac, dtype=torch.float32, device=dev).view(n, 1).requires_grad_(True)
+    sc = torch.tensor([[s, s, s] for s in scale], dtype=torch.float32, device=dev, requires_grad=True)
+    rot = torch.tensor([[1.0, 0.0, 0.0, 0.0]] * n, dtype=torch.float32, device=dev, requires_grad=True)
+    st = _closed_form_settings(D, dev, bg)
+    color, radii, _ = D.GaussianRasterizer(raster_settings=st)(
+        means3D=means, means2D=torch.zeros(n, 3, device=dev), opacities=op, shs=sh, scales=sc, rotations=rot)
+    return color, radii, dict(means=means, sh=sh, op=op, sc=sc, rot=rot)
+
+
+def test_closed_form_one_gaussian_pixel_values_and_gradients():
+    D = _hip()
+    dev = torch.device("cuda:0")
+    bg = [0.1, 0.2, 0.3]
+    color, radii, leaf = _render_closed(D, dev, [[0.0, 0.0, 4.0]], [0.5], [0.6], [[0.8, 0.4, 0.2]], bg)
+    assert radii.tolist() == [7]
+    # literals (see the derivation above): alpha = 0.6 * 0.943518284537 = 0.566110970722
+    px = color[:, 15, 15].detach().cpu().double()
+    want = torch.tensor([0.49627767950558, 0.31322219414445, 0.24338890292777], dtype=torch.float64)
+    assert (px - want).abs().max().item() <= 2e-6
+    # the whole image from the same formula, pixel by pixel: alpha >= 1/255 <=> dx^2 + dy^2 <= 2 * 4.3 * ln(255 * 0.6) = 43.26
+    ys, xs = torch.meshgrid(torch.arange(32.0, dtype=torch.float64), torch.arange(32.0, dtype=torch.float64), indexing="ij")
+    r2 = (15.5 - xs) ** 2 + (15.5 - ys) ** 2
+    alpha = 0.6 * torch.exp(-0.5 * r2 / 4.3)
+    alpha = torch.where(alpha >= 1.0 / 255.0, alpha, torch.zeros_like(alpha))
+    assert int((alpha > 0).sum()) == int((r2 <= 43.261766).sum())
+    rgb = torch.tensor([0.8, 0.4, 0.2], dtype=torch.float64)
+    bgt = torch.tensor(bg, dtype=torch.float64)
+    img = rgb[:, None, None] * alpha[None] + bgt[:, None, None] * (1.0 - alpha[None])
+    assert (color.detach().cpu().double() - img).abs().max().item() <= 3e-6
+    # gradients of L = red channel of pixel (15, 15):  dL/do = G (r - bg_r),  dL/dsh_r = C0 alpha,
+    # dL/dX = (r - bg_r) o G (-dx / 4.3) dpx/dX with dpx/dX = W / (2 z tan) = 4;  by symmetry dL/dY is the same number
+    color[0, 15, 15].backward()
+    assert abs(leaf["op"].grad.item() - 0.660462799176) <= 2e-6
+    assert abs(leaf["sh"].grad[0, 0, 0].item() - 0.159696956407) <= 1e-6
+    assert leaf["sh"].grad[0, 0, 1:].abs().max().item() == 0.0
+    assert abs(leaf["means"].grad[0, 0].item() - (-0.184315199770)) <= 2e-6
+    assert abs(leaf["means"].grad[0, 1].item() - (-0.184315199770)) <= 2e-6
+
+
+def test_closed_form_two_overlapping_gaussians_blend_front_to_back():
+    """Front splat (z = 4, o = 0.6, rgb (.8,.4,.2)) over a back splat with the same screen footprint (z = 8, s = 1:
+    16 * 1 / 8 = 2, o = 0.5, rgb (.2,.9,.5)), STORED back first: the depth sort must put the z = 4 one in front.
+    Pixel (15,15): a1 = 0.566111, a2 = 0.5 * 0.943518 = 0.471759;  C = c1 a1 + c2 a2 (1 - a1) + bg (1 - a1)(1 - a2)."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    bg = [0.1, 0.2, 0.3]
+    color, radii, leaf = _render_closed(D, dev, [[0.0, 0.0, 8.0], [0.0, 0.0, 4.0]], [1.0, 0.5], [0.5, 0.6],
+                                        [[0.2, 0.9, 0.5], [0.8, 0.4, 0.2]], bg)
+    assert radii.tolist() == [7, 7]
+    px = color[:, 15, 15].detach().cpu().double()
+    want = torch.tensor([0.516746791134765, 0.4565059755487128, 0.2843271261861336], dtype=torch.float64)
+    assert (px - want).abs().max().item() <= 3e-6
+    # dL/d(o_back) for L = red of that pixel: G (1 - a1) (r2 - bg_r) = 0.943518 * 0.433889 * 0.1
+    color[0, 15, 15].backward()
+    assert abs(leaf["op"].grad[0].item() - 0.943518284537 * (1 - 0.566110970722) * (0.2 - 0.1)) <= 2e-6
+    # dL/d(o_front) = G (r1 - [c2 a2 + bg (1 - a2)]) = 0.943518 * (0.8 - (0.2 * 0.471759 + 0.1 * 0.528241))
+    a2 = 0.5 * 0.943518284537
+    assert abs(leaf["op"].grad[1].item() - 0.943518284537 * (0.8 - (0.2 * a2 + 0.1 * (1 - a2)))) <= 2e-6
+
+
+def test_closed_form_near_plane_keeps_z_above_0p2_only():
+    """View-space z <= 0.2 is culled (radius 0, no contribution, zero gradients); z slightly above is kept.  The kept
+    splat: z = 0.21, s = 0.02625 => 16 s / z = 2, the footprint of the cases above."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    bg = [0.1, 0.2, 0.3]
+    color, radii, leaf = _render_closed(D, dev, [[0.0, 0.0, 0.2], [0.0, 0.0, 0.21], [0.0, 0.0, -3.0]],
+                                        [0.025, 0.02625, 0.5], [0.9, 0.6, 0.9], [[1.0, 1.0, 1.0], [0.8, 0.4, 0.2], [1.0, 0.0, 1.0]], bg)
+    assert radii.tolist() == [0, 7, 0]
+    px = color[:, 15, 15].detach().cpu().double()
+    want = torch.tensor([0.49627767950558, 0.31322219414445, 0.24338890292777], dtype=torch.float64)
+    assert (px - want).abs().max().item() <= 5e-6
+    color.sum().backward()
+    for k in ("means", "sh", "op", "sc", "rot"):
+        g = leaf[k].grad
+        assert g[0].abs().max().item() == 0.0 and g[2].abs().max().item() == 0.0, k
+    assert leaf["op"].grad[1].abs().item() > 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Integer parity of the binning with the oracle: under GSR_FLAG_NO_CULL the sorted pair list, the
+# tile ranges and num_rendered are the reference's by construction -- compared bit for bit with oracle_r.build_tile_lists
+# after removing, from BOTH sides, the Gaussians whose integer decisions the oracle flags as fragile.
+# ---------------------------------------------------------------------------------------------------------------------
+def _tile_list_parity(scene, n_views=1, windows=None, **kw):
+    D = _hip()
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.scenes import make_scene
+    dev = torch.device("cuda:0")
+    model, cams, _ = make_scene(scene, device=dev, n_views=n_views, **kw)
+    cam = cams[-1]
+    H, W = cam.image_height, cam.image_width
+    gx = (W + 15) // 16
+    bg = torch.zeros(3, device=dev)
+    with D.extra_flags(D.FLAG_NO_CULL):
+        out = render(cam, model, PipelineParams(skip_objects=True), bg)
+    img = out["render"]
+    ranges = D.export_state(img, "ranges").view(-1, 2).long().cpu()
+    pairs = D.export_state(img, "pair_rank").long().cpu() & 0xFFFFFFFF   # exported as int32
+    gids = pairs & ((1 << 28) - 1)
+    assert int((pairs >> 28).min()) == 15                  # no cull: every strip bit set
+    N = D.last_num_rendered(img)
+    depth = D.export_state(img, "G").view(-1, 12)[:, 9].cpu()
+    radii = out["radii"].cpu()
+    depth = torch.where(radii > 0, depth, torch.zeros_like(depth))
+    cpu = lambda t: t.detach().cpu()
+    st = O.Settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3), 1.0,
+                    cpu(cam.world_view_transform), cpu(cam.full_proj_transform), 3, cpu(cam.camera_center), False, False)
+    xyz, sc, ro = cpu(model.get_xyz).double(), cpu(model.get_scaling).double(), cpu(model.get_rotation).double()
+    O.check_depth_keys(depth, xyz, st, radii)
+    g = O.preprocess(xyz, sc, ro, None, st)
+    frag = g.fragile
+    bad_r = (radii != g.radii) & ~frag
+    assert int(bad_r.sum()) == 0
+    gid_o, ranges_o, _ = O.build_tile_lists(g, H, W, tile_windows=windows, depth_key=depth)
+    if windows is None:
+        tiles = torch.arange(ranges.shape[0])
+    else:
+        tiles = torch.tensor([ty * gx + tx for (x0, y0, x1, y1) in windows for ty in range(y0, y1) for tx in range(x0, x1)])
+    n_frag_h = n_frag_o = 0
+    for t in tiles.tolist():
+        lh = gids[ranges[t, 0]:ranges[t, 1]]
+        lo = gid_o[ranges_o[t, 0]:ranges_o[t, 1]]
+        kh, ko = ~frag[lh], ~frag[lo]
+        n_frag_h += int((~kh).sum())
+        n_frag_o += int((~ko).sum())
+        assert torch.equal(lh[kh], lo[ko]), f"tile {t}: list differs ({lh[kh][:8].tolist()} vs {lo[ko][:8].tolist()})"
+    if windows is None:
+        assert int((ranges[:, 1] - ranges[:, 0]).sum()) == N == int(pairs.numel())
+        assert N - n_frag_h == int(gid_o.numel()) - n_frag_o
+        if int(frag.sum()) == 0:
+            assert torch.equal(ranges, ranges_o) and torch.equal(gids, gid_o) and N == int(gid_o.numel())
+    return int(frag.sum()), N
+
+
+def test_tile_lists_equal_the_oracles_hydrant_1k():
+    nfrag, N = _tile_list_parity("hydrant-1k")
+    print(f"hydrant-1k: N={N}, fragile Gaussians {nfrag}")
+    assert N > 1000
+
+
+def test_tile_lists_equal_the_oracles_60k_at_640x360():
+    nfrag, N = _tile_list_parity("nyc-1M", P=60000, width=640, height=360)
+    print(f"nyc 60k @640x360: N={N}, fragile Gaussians {nfrag}")
+    assert N > 50000
+
+
+def test_tile_lists_equal_the_oracles_nyc_1m_on_windows():
+    # full size (1 M Gaussians, 1080p): the oracle builds the lists of three 6x4-tile windows
+    windows = [(10, 10, 16, 14), (57, 30, 63, 34), (114, 64, 120, 68)]
+    nfrag, N = _tile_list_parity("nyc-1M", n_views=3, windows=windows)
+    print(f"nyc-1M @1080p: N={N}, fragile Gaussians {nfrag}")
+    assert N > 3_000_000
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gsr_backward_raw_into / GradBucket
+# ---------------------------------------------------------------------------------------------------------------------
+def _small_scene(n_views=3, P=20000, w=320, h=192):
+    from gsplat_attack.scenes import make_scene
+    dev = torch.device("cuda:0")
+    model, cams, _ = make_scene("nyc-1M", device=dev, P=P, width=w, height=h, n_views=n_views)
+    return dev, model, cams
+
+
+def test_backward_into_a_bucket_adds_views_like_autograd_does():
+    D = _hip()
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams = _small_scene()
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    gcs = [torch.randn(3, 192, 320, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(3)]
+    pipe = PipelineParams(skip_objects=True)
+    model.zero_grad()
+    per_view = []
+    for cam, gc in zip(cams, gcs):                         # reference behaviour: autograd accumulates in .grad
+        model.zero_grad()
+        render(cam, model, pipe, bg)["render"].backward(gc)
+        per_view.append({n: getattr(model, n).grad.clone() for n in D.GradBucket.NAMES})
+    want = {n: sum(v[n] for v in per_view) for n in D.GradBucket.NAMES}
+    model.zero_grad()
+    bucket = D.GradBucket(model.get_xyz.shape[0], dev)
+    bucket.flat.fill_(float("nan"))                        # the first backward must overwrite, not add
+    pipe_b = PipelineParams(skip_objects=True, grad_bucket=bucket)
+    for cam, gc in zip(cams, gcs):
+        render(cam, model, pipe_b, bg)["render"].backward(gc)
+    assert all(getattr(model, n).grad is None for n in D.GradBucket.NAMES)       # autograd got nothing for them
+    got = bucket.views()
+    for n in D.GradBucket.NAMES:
+        scale = want[n].abs().max().clamp_min(1e-30)
+        assert torch.isfinite(got[n]).all(), n
+        assert ((got[n].view(want[n].shape) - want[n]).abs().max() / scale).item() <= 2e-6, n
+    # first view alone: bitwise what the plain backward writes
+    bucket.reset()
+    render(cams[0], model, pipe_b, bg)["render"].backward(gcs[0])
+    for n in D.GradBucket.NAMES:
+        assert torch.equal(bucket.views()[n].view(per_view[0][n].shape), per_view[0][n]), n
+    bucket.assign_to(model)
+    assert model._features_rest.grad.data_ptr() == bucket.views()["_features_rest"].data_ptr()
+
+
+def test_pgd_attack_with_buckets_takes_the_same_steps():
+    from gsplat_attack.attack import pgd_attack
+    dev, model, cams = _small_scene(n_views=4)
+    a, b = model.clone(), model.clone()
+    kw = dict(iters=3, groups=("color", "position", "scaling", "rotation", "opacity"), alpha=0.05, epsilon=0.5)
+    ha = pgd_attack(a, cams, use_buckets=False, streams=1, **kw)
+    hb = pgd_attack(b, cams, use_buckets=True, streams=1, **kw)
+    hc_model = model.clone()
+    hc = pgd_attack(hc_model, cams, use_buckets=True, streams=3, **kw)
+    assert max(abs(x - y) for x, y in zip(ha, hb)) <= 1e-5 * max(1.0, max(abs(x) for x in ha))
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        ref = getattr(a, n).detach()
+        for other in (b, hc_model):
+            d = (getattr(other, n).detach() - ref).abs().max().item()
+            assert d <= 2e-5 * max(1.0, ref.abs().max().item()), (n, d)
+    assert len(hc) == 3
+
+
+def test_forward_without_grad_keeps_no_backward_state():
+    """a torch.no_grad() render of a model whose parameters require grad must not keep the rasteriser's
+    backward state (segment boundary records, d colour / d direction)."""
+    D = _hip()
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams = _small_scene(n_views=1, P=200000, w=960, h=544)
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams(skip_objects=True)
+    with torch.no_grad():
+        out = render(cams[0], model, pipe, bg)
+    assert out["render"].grad_fn is None and not out["render"].requires_grad
+    out_g = render(cams[0], model, pipe, bg)
+    assert out_g["render"].grad_fn is not None and out_g["render"].grad_fn.holder is not None
+    assert torch.equal(out["render"], out_g["render"].detach())
+    # plain tensors without requires_grad: no context either
+    frozen = model.clone()
+    for p in frozen.parameters():
+        p.requires_grad_(False)
+    out_f = render(cams[0], frozen, PipelineParams(skip_objects=True, viewspace_grad=False), bg)
+    assert out_f["render"].grad_fn is None
+
+
+def test_asynchronous_pair_count_matches_and_reports_overflow():
+    """GSR_FLAG_ASYNC_COUNT: same bits as the synchronous forward when the capacity guess holds; a scene that emits more
+    pairs than the guess gets a NaN image and a PairCapacityExceeded from backward; the next forward recovers."""
+    D = _hip()
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams = _small_scene(n_views=2, P=50000, w=640, h=360)
+    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    gc = torch.randn(3, 360, 640, generator=torch.Generator().manual_seed(5)).to(dev)
+    pipe = PipelineParams(skip_objects=True)
+
+    def run(scale=1.0):
+        model.zero_grad()
+        out = render(cams[0], model, pipe, bg, scale)
+        out["render"].backward(gc)
+        return out["render"].detach().clone(), {n: getattr(model, n).grad.clone() for n in D.GradBucket.NAMES}, D.last_num_rendered(out["render"])
+    img0, g0, n0 = run()                                   # synchronous: seeds the capacity table for this (P, H, W)
+    try:
+        D.set_flags(D.FLAG_ASYNC_COUNT)
+        img1, g1, n1 = run()
+        assert n1 == n0 and torch.equal(img0, img1)
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n
+        # three times larger splats: far more pairs than 1.25 x n0 + 64K
+        model.zero_grad()
+        out = render(cams[0], model, pipe, bg, 4.0)
+        assert torch.isnan(out["render"]).all()
+        with pytest.raises(D.PairCapacityExceeded):
+            out["render"].backward(gc)
+        img2, g2, n2 = run(4.0)                            # counted synchronously again: correct
+        assert n2 > 1.25 * n0 + 65536 and torch.isfinite(img2).all()
+        img3, _, n3 = run(4.0)                             # and asynchronously with the new capacity
+        assert n3 == n2 and torch.equal(img2, img3)
+    finally:
+        D.set_flags(0)
