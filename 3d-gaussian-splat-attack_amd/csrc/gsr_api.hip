@@ -531,7 +531,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   }
   // ---- kept slab ---------------------------------------------------------------------------
   SlabPlan kp;
-  kp.add<float4>(3 * Pp);   // G records (storage order)
+  kp.add<float4>(REC * Pp);   // G records (storage order)
   kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<uint32_t>(DV_WORDS); kp.add<uint32_t>(ntiles);
   // the SH layouts the reference uses (and precomputed colours) take the lane-group kernels
@@ -555,7 +555,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     return set_err(GSR_ERR_NOMEM, "gsr_forward: workspace allocation failed (P=%d, %dx%d)", P, W, H);
   }
   Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
-  c->G0 = ks.take<float4>(3 * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;   // interleaved 48-byte records
+  c->G0 = ks.take<float4>(REC * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;   // interleaved records, REC float4 apart
   c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   c->dv = ks.take<uint32_t>(DV_WORDS);
@@ -630,8 +630,11 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
             cs = side.side;
             side_used = true;
           }
-          if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridCol, blkCol, 0, cs, pa);
-          else hipLaunchKernelGGL((k_pre_color<false>), gridCol, blkCol, 0, cs, pa);
+          // beside the chain: a thin grid (GSR_COLOR_BLOCKS workgroups looping over the chunks); alone: one per chunk
+          static const int col_blocks = [] { const char* e = getenv("GSR_COLOR_BLOCKS"); int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
+          const dim3 gridC(side_used ? std::min<unsigned>(gridCol.x, (unsigned)col_blocks) : gridCol.x);
+          if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, pa);
+          else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, pa);
           if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
         }
       } else
@@ -639,7 +642,14 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                            opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
       // storage-order numbering of the pairs (where the backward puts its partial rows), the depth sort's digit width
       // and first histogram, the device-side pair count -- published to the host slot by the kernel itself: one launch
-      if (!slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
+      // stream capture (hipGraph): the forward must not wait for anything, so the count has to be asynchronous, and it is
+      // not published to the host at all (a replayed graph would keep writing into a slot that has long been recycled)
+      hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(st, &cap_st) == hipSuccess && cap_st == hipStreamCaptureStatusActive;
+      if (capturing && !async_count)
+        return fail(set_err(GSR_ERR_STATE, "gsr_forward: a stream capture needs GSR_FLAG_ASYNC_COUNT and an earlier forward of "
+                            "the same (P, H, W) on this device (the pair count cannot be waited for while capturing)"));
+      if (!capturing && !slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
       c->fwd_stream = st;
       hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint32_t*)dkey,
                          (const uint4*)bout, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
@@ -862,7 +872,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   // sums and the projection chain rule (the colour attack; BASELINE configs 2 and 3).
   const bool geom = dmeans3D || dmeans2D || dopacities || dscales || drotations || dcov3D;
   // an asynchronous-count forward: its pair count must have fitted the capacity guess (else the image it produced was
-  // poisoned with NaN and nothing downstream of it is meaningful)
+  // poisoned with NaN and nothing downstream of it is meaningful).  (A forward recorded into a hipGraph publishes
+  // nothing to the host: c->slot is empty and this is a no-op.)
   if (ctx_resolve_count(c) != GSR_OK) return set_err(GSR_ERR_DEVICE, "gsr_backward: reading the forward's pair count failed");
   if (c->overflow)
     return set_err(GSR_ERR_OVERFLOW, "gsr_backward: the forward emitted %llu (tile, Gaussian) pairs, more than the capacity "
@@ -957,7 +968,10 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     if (c->lanegroup && c->shs && geom && !c->D)
       return done(set_err(GSR_ERR_STATE, "gsr_backward: the forward of this context was run without its backward state"));
     if (c->lanegroup) {
-      if (c->raw) {
+      if (c->raw && accumulate) {
+        if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      } else if (c->raw) {
         if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
         else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
       } else {
@@ -1053,7 +1067,16 @@ int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, 
     case 4: src = c->order; bytes = sizeof(uint32_t) * (size_t)c->P; break;
     case 5: src = c->off; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
     case 6:                                                                   // (kept for old callers: same as 7)
-    case 7: src = c->G0; bytes = sizeof(float4) * 3 * (size_t)c->P; break;   // splat records [P][3] float4, storage order
+    case 7: {                                                                 // splat records [P][3] float4, storage order
+      const size_t need = sizeof(float4) * 3 * (size_t)c->P;
+      if ((int64_t)need > dst_bytes)
+        return set_err(GSR_ERR_INVALID, "gsr_ctx_export: item %d needs %zu bytes, buffer has %lld", what, need, (long long)dst_bytes);
+      if (c->P == 0) return GSR_OK;
+      // the records sit REC float4 apart in the workspace: copied out packed, 48 bytes each
+      HIP_TRY("ctx export", hipMemcpy2DAsync(dst, sizeof(float4) * 3, c->G0, sizeof(float4) * REC, sizeof(float4) * 3,
+                                             (size_t)c->P, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+      return GSR_OK;
+    }
     case 8: src = c->dv; bytes = sizeof(uint32_t) * DV_WORDS; break;          // device-side scalars (DV_*)
     case 9: src = c->offg; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_export: unknown item %d", what);

@@ -40,8 +40,14 @@ __device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
 
 constexpr uint32_t RECT_MASK = 0xFFFu;
 // The three float4 of a splat record are interleaved (48 contiguous bytes per Gaussian): X0/X1/X2 below are the same
-// array offset by 0/1/2 float4 and are indexed [REC * i], so a record gather touches one or two 64-byte sectors.
-constexpr int REC = 3;
+// array offset by 0/1/2 float4 and are indexed [REC * i].  REC = 3: 48 contiguous bytes per Gaussian, half of the records
+// straddle two 64-byte sectors.  -DGSR_REC=4 puts them at a 64-byte pitch (one sector per gather): measured in round 3,
+// the compositors' counted traffic falls (K6 597 -> 500 MB, K7 749 -> 686 MB) and their run time does not move, while
+// every small kernel that touches the records gets a little slower (one-stream rate 1123 -> 1111 views/s): not the default.
+#ifndef GSR_REC
+#define GSR_REC 3
+#endif
+constexpr int REC = GSR_REC;
 constexpr int RANK_BITS = 28;                       // pair value = depth rank | strip mask << 28
 constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 
@@ -430,7 +436,7 @@ __device__ __forceinline__ int item_of_block(int b, int nitems, int mode) {
 // priority class (length relative to the longest list) that the render kernels hand to s_setprio: the long
 // lists issue ahead of their SIMD's other waves.  Results do not depend on the schedule.
 // ------------------------------------------------------------------------------------------------
-constexpr int SCHED_BINS = 1024;
+constexpr int SCHED_BINS = 4096;                      // one bin per list length (clamped): few same-bin LDS atomics
 constexpr int SCHED_LDS_TILES = 12288;               // 48 KB of list lengths (1080p has 8160 tiles)
 constexpr uint32_t SCHED_TILE_MASK = (1u << 28) - 1u;
 __device__ __forceinline__ uint32_t wave_max_u32_fwd(uint32_t v) {
@@ -438,8 +444,31 @@ __device__ __forceinline__ uint32_t wave_max_u32_fwd(uint32_t v) {
   for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
   return v;
 }
+// exclusive scan of one value per thread over the 1024-thread block (16 waves); `ws` is 16 words of LDS
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* ws, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();                                   // ws may still be read from a previous call
+  if (lane == 63) ws[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t x = ws[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  total = tot;
+  return base + inc - v;
+}
 // seg_shift = 0: no tile is split.  rec_cap: capacity of the boundary-record buffer (a tile whose records would not
-// fit stays unsplit); nrec_out receives the number of records in use.
+// fit stays unsplit); nrec_out receives the number of records in use.  Tiles whose span is still the empty
+// (0xFFFFFFFF, 0) the tile sort starts from are given (0, 0).
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
@@ -447,22 +476,23 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
-  // the tiles' list lengths are read from HBM once and kept in LDS for the three passes below (up to SCHED_LDS_TILES
+  // the tiles' list lengths are read from HBM once and kept in LDS for the passes below (up to SCHED_LDS_TILES
   // tiles; beyond that -- 4K images -- the later passes read `ranges` again)
   __shared__ uint32_t slen[SCHED_LDS_TILES];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
   const bool in_lds = ntiles <= SCHED_LDS_TILES;
   auto tile_len = [&](int i) -> uint32_t {
     if (in_lds) return slen[i];
     const uint2 r = ranges[i];
     return r.y - r.x;
   };
-  hist[t] = 0;
+#pragma unroll
+  for (int k = 0; k < SCHED_BINS / 1024; ++k) hist[t + k * 1024] = 0;
   if (t == 0) smax = 0;
   __syncthreads();
   uint32_t mymax = 0;
   for (int i0 = t; i0 < ntiles; i0 += 8 * 1024) {
-    // eight independent loads in flight per thread (the loop used to pay one memory round trip per 1024 tiles)
+    // eight independent loads in flight per thread
     uint2 r[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -479,7 +509,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
       if (i < ntiles) {
         const uint32_t len = r[k].y - r[k].x;
         if (in_lds) slen[i] = len;
-        atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
+        atomicAdd(&hist[min(len, (uint32_t)SCHED_BINS - 1u)], 1u);
         mymax = max(mymax, len);
       }
     }
@@ -487,68 +517,53 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
   mymax = wave_max_u32_fwd(mymax);
   if (lane == 0) atomicMax(&smax, mymax);
   __syncthreads();
-  // exclusive scan over the bins in DESCENDING length order: thread t owns bin 1023 - t
-  const uint32_t v = hist[SCHED_BINS - 1 - t];
-  uint32_t inc = v;
+  // exclusive scan over the bins in DESCENDING length order: thread t owns bins 4095 - 4t .. 4095 - 4t - 3
+  {
+    constexpr int BPT = SCHED_BINS / 1024;
+    uint32_t c[BPT], s = 0;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-    if (lane >= d) inc += o;
+    for (int k = 0; k < BPT; ++k) { c[k] = hist[SCHED_BINS - 1 - (t * BPT + k)]; s += c[k]; }
+    uint32_t total;
+    uint32_t run = block_excl_scan_1024(s, wsum, total);
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) { hist[SCHED_BINS - 1 - (t * BPT + k)] = run; run += c[k]; }   // becomes the bin's cursor
   }
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  __syncthreads();
-  hist[SCHED_BINS - 1 - t] = base + inc - v;      // becomes the bin's cursor
   __syncthreads();
   const float prio_scale = 4.0f / (float)(smax + 1u);
   for (int i = t; i < ntiles; i += 1024) {
     const uint32_t len = tile_len(i);
-    const uint32_t p = atomicAdd(&hist[min(len >> 2, (uint32_t)SCHED_BINS - 1u)], 1u);
+    const uint32_t p = atomicAdd(&hist[min(len, (uint32_t)SCHED_BINS - 1u)], 1u);
     const uint32_t prio = min(3u, (uint32_t)((float)len * prio_scale));    // 0..3: length relative to the longest list
     sched[p] = (uint32_t)i | (prio << 28);
   }
   // ---- boundary records of the split tiles: exclusive scan of nseg over the tiles, in tile order ------------------
+  // thread t owns the consecutive tiles [t * tpt, (t + 1) * tpt): ONE block scan instead of one per 1024 tiles
   if (segoff == nullptr) return;
-  __syncthreads();
   const uint32_t seg_len = 1u << seg_shift;
-  uint32_t carry = 0;                                  // records of the tiles in front of this round (uniform)
-  for (int i0 = 0; i0 < ntiles; i0 += 1024) {          // 1024 tiles per round, coalesced
-    const int i = i0 + t;
-    uint32_t nseg = 0;
-    if (i < ntiles && seg_shift != 0u) {
+  const int tpt = (ntiles + 1023) / 1024;
+  const int i_lo = t * tpt, i_hi = min(i_lo + tpt, ntiles);
+  uint32_t mine = 0;
+  if (seg_shift != 0u)
+    for (int i = i_lo; i < i_hi; ++i) {
       const uint32_t len = tile_len(i);
-      if (len > seg_len) nseg = (len + seg_len - 1u) >> seg_shift;
+      if (len > seg_len) mine += (len + seg_len - 1u) >> seg_shift;
     }
-    uint32_t inc2 = nseg;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)inc2, d, 64);
-      if (lane >= d) inc2 += o;
+  uint32_t total;
+  uint32_t run = block_excl_scan_1024(mine, wsum, total);
+  for (int i = i_lo; i < i_hi; ++i) {
+    const uint32_t len = tile_len(i);
+    uint32_t nseg = 0;
+    if (seg_shift != 0u && len > seg_len) nseg = (len + seg_len - 1u) >> seg_shift;
+    uint32_t off = SEG_NONE;
+    if (nseg != 0u && run + nseg <= rec_cap) {
+      off = run;
+      for (uint32_t j = 1; j < nseg; ++j) rec_item[run + j - 1u] = make_uint2((uint32_t)i, j);
+      rec_item[run + nseg - 1u] = make_uint2((uint32_t)i, 0u);
     }
-    __syncthreads();                                   // wsum is re-used every round
-    if (lane == 63) wsum[wave] = inc2;
-    __syncthreads();
-    uint32_t run = carry + inc2 - nseg, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const uint32_t ws = wsum[w];
-      if (w < wave) run += ws;
-      total += ws;
-    }
-    if (i < ntiles) {
-      uint32_t off = SEG_NONE;
-      if (nseg != 0u && run + nseg <= rec_cap) {
-        off = run;
-        for (uint32_t j = 1; j < nseg; ++j) rec_item[run + j - 1u] = make_uint2((uint32_t)i, j);
-        rec_item[run + nseg - 1u] = make_uint2((uint32_t)i, 0u);
-      }
-      segoff[i] = off;
-    }
-    carry += total;
+    segoff[i] = off;
+    run += nseg;
   }
-  if (t == 0) *nrec_out = min(carry, rec_cap);
+  if (t == 0) *nrec_out = min(total, rec_cap);
 }
 __device__ __forceinline__ void set_wave_priority(uint32_t prio) {
   if (prio == 3u) __builtin_amdgcn_s_setprio(3);
@@ -1204,7 +1219,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     return;
   }
   const bool acc = a.accumulate != 0;
-  auto put = [acc](float* p, float v) { *p = acc ? *p + v : v; };
+  auto put = [acc](float* p, float v) { if (acc) *p += v; else *p = v; };
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
   for (uint32_t e = o0; e < o1; ++e) {
     const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
@@ -1458,11 +1473,14 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color(PreArgs a) {
   __shared__ float slots[PREF_WAVES * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* ws = &slots[wave * 64 * 4];
-  const int g = blockIdx.x * PREF_BLOCK + wave * 64 + lane;
+  // grid-stride over the 256-Gaussian chunks: on the side stream the kernel is launched with FEWER workgroups than
+  // chunks, so that it holds only a couple of waves per SIMD while the binning chain's short kernels come and go
+  for (int chunk = blockIdx.x; chunk * PREF_BLOCK < a.P; chunk += gridDim.x) {
+  const int g = chunk * PREF_BLOCK + wave * 64 + lane;
   const bool ok = g < a.P && a.tcnt[g] != 0u;
   const uint64_t live = __ballot(ok);
   const int nlive = __popcll(live);
-  if (nlive == 0) return;
+  if (nlive == 0) continue;
   if (ok) {
     const bool second = g >= a.Pa;
     const int gl = second ? g - a.Pa : g;
@@ -1526,6 +1544,10 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color(PreArgs a) {
       else if (q == 1) *reinterpret_cast<float*>(&a.G2[REC * gg]) = clamp_flagged(c2);
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slots are rewritten by the next chunk
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 
@@ -1536,7 +1558,9 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color(PreArgs a) {
 constexpr int ROW_CHUNK = 128;     // partial rows staged per round (6 KB per wave)
 constexpr int HAND_W = 7;          // hand-over: unit direction (3) + clamped dL/drgb (3), odd stride
 
-template <bool RAW, bool GEOM>
+// ACC: the outputs are added to instead of overwritten (PreBwdArgs::accumulate) -- a template parameter so that the
+// overwriting kernel contains no loads of its outputs at all.
+template <bool RAW, bool GEOM, bool ACC = false>
 __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
   __shared__ float shand[PRE_WAVES * 64 * HAND_W];
@@ -1549,8 +1573,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   if (nw <= 0) return;
   uint32_t o0 = 0, o1 = 0;
   if (g < a.P) { o0 = a.offg[g] * a.nsub; o1 = a.offg[g + 1] * a.nsub; }
-  const bool acc = a.accumulate != 0;
-  auto put = [acc](float* p, float v) { *p = acc ? *p + v : v; };
+  constexpr bool acc = ACC;
+  auto put = [](float* p, float v) { if (ACC) *p += v; else *p = v; };
   // the record and the position of a Gaussian with rows are requested now, ahead of the row summation that does not
   // depend on them (the kernel is a chain of dependent memory phases per wave: every phase started early is time won)
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e2 = e0;

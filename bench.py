@@ -299,6 +299,7 @@ def main():
         torch.cuda.synchronize()
         if rank == 0 and not pgd_loop:
             log(f"warmup step {i} done, N={D.last_num_rendered(out['render'])}")
+    out = None
     ar_events.clear()
     info = {}
     # pair / visible counts of every camera of the ring (the roofline figures use their means)

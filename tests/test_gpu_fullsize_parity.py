@@ -11,6 +11,8 @@ long lists), which the small oracle cases never reach.
 import math
 
 import pytest
+import os
+
 import torch
 
 from oracle import oracle_r as O
@@ -115,12 +117,29 @@ def hip_raw(model, cam, bg, gc, flags=0, fused=True, objects=False, go=None, col
     return out, grads
 
 
-def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=0.12, objects=False):
+def _note(line):
+    """Observed figures of the parity runs (fragile shares, errors): printed, and appended to gpurun_out/parity_notes.txt
+    when that directory exists (DESIGN.md quotes them)."""
+    print(line)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_notes.txt"), "a") as f:
+            f.write(line + "\n")
+
+
+def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=0.08, objects=False, tag=""):
+    """frag_frac: cap on the share of window pixels the oracle may flag fragile -- at most twice what this binary shows on
+    the case (observed in round 3: cfg 3 0.036, classic surface 0.026, dense point 0.039, cfg 5
+    0.078, cfg 2 0.169 -- long lists of faint splats --, cfg 3 under the oracle's own depth order 0.186); the observed
+    share is printed and recorded."""
     color = out["render"].detach().cpu().double()
     err = (color - ro.color.detach()).abs().max(dim=0).values
     solid = m & ~ro.fragile_px
     frag = m & ro.fragile_px
-    assert frag.sum().item() <= frag_frac * m.sum().item(), f"{int(frag.sum())} fragile pixels of {int(m.sum())}"
+    share = frag.sum().item() / max(m.sum().item(), 1)
+    _note(f"[{tag or 'windows'}] fragile share {share:.4f} (cap {frag_frac}), solid RGB err {err[solid].max().item():.2e}"
+          + (f", fragile RGB err {err[frag].max().item():.2e}" if frag.any() else ""))
+    assert share <= frag_frac, f"{int(frag.sum())} fragile pixels of {int(m.sum())}"
     assert err[solid].max().item() <= RGB_TOL, f"RGB max abs err {err[solid].max().item():.3e} on the windows"
     if frag.any():
         assert err[frag].max().item() <= 1e-2
@@ -179,13 +198,31 @@ def test_cfg3_nyc_1m_1080p_all_gradients_vs_windowed_oracle():
     gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(99)) * m
     ro, rgrads, gc, _ = oracle_raw("nyc-1M", 2, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev))
-    rep = compare(out, grads, ro, rgrads, m)
+    rep = compare(out, grads, ro, rgrads, m, tag="cfg3 nyc-1M fused")
     print("cfg3 windows", wins, "longest list", longest, rep)
     # the same view with long lists NOT split over waves and the other tile splits: same numbers within rounding
     for flags in (D.FLAG_NO_SEGMENTS, D.FLAG_FWD_SHARED, D.flag_fwd_split(4) | D.flag_bwd_split(2), D.flag_fwd_split(1) | D.flag_tile_map(0)):
         out2, grads2 = hip_raw(model, cam, bg.to(dev), gc.to(dev), flags=flags)
         assert (out2["render"] - out["render"]).abs().max().item() <= 2e-6, flags
-        compare(out2, grads2, ro, rgrads, m)
+        compare(out2, grads2, ro, rgrads, m, tag=f"cfg3 nyc-1M flags {flags:#x}")
+
+
+def test_cfg3_windows_with_the_oracles_own_depth_order():
+    """The same comparison WITHOUT handing the HIP path's depth keys to the oracle: the oracle
+    sorts on its own float32(float64 depth) keys and flags, per pixel, the list neighbours whose keys may sort the other
+    way round in another float32 arithmetic.  More pixels are fragile; the solid ones must agree all the same."""
+    D = _hip()
+    dev, model, cams = _scene_on_gpu("nyc-1M", 3)
+    cam = cams[2]
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
+    wins = wins[1:4]                                       # a 99th-percentile tile window, the ragged corner, the border
+    m = window_mask(wins, 1080, 1920)
+    gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(17)) * m
+    ro, rgrads, gc, _ = oracle_raw("nyc-1M", 2, bg, gc, wins, keys=None)
+    out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev))
+    rep = compare(out, grads, ro, rgrads, m, frag_frac=0.38, tag="cfg3 nyc-1M, oracle's own depth order")
+    print("own-order windows", wins, rep)
 
 
 def test_dense_10m_pairs_vs_windowed_oracle():
@@ -205,7 +242,7 @@ def test_dense_10m_pairs_vs_windowed_oracle():
     ro, rgrads, gc, _ = oracle_raw("nyc-1M", 1, bg, gc, wins, keys=keys, scale=scale)
     assert ro.num_rendered > 20000
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), scale=scale)
-    rep = compare(out, grads, ro, rgrads, m, frag_frac=0.25)
+    rep = compare(out, grads, ro, rgrads, m, frag_frac=0.08, tag="dense 10M pairs")
     print("dense windows", wins, "longest list", longest, rep)
 
 
@@ -220,7 +257,7 @@ def test_cfg3_classic_activated_surface_vs_windowed_oracle():
     gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(7)) * m
     ro, rgrads, gc, _ = oracle_raw("nyc-1M", 0, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), fused=False)
-    compare(out, grads, ro, rgrads, m)
+    compare(out, grads, ro, rgrads, m, tag="cfg3 classic surface")
 
 
 def test_cfg2_hydrant_full_800px_sh_gradients_vs_windowed_oracle():
@@ -237,9 +274,9 @@ def test_cfg2_hydrant_full_800px_sh_gradients_vs_windowed_oracle():
     ro, rgrads, gc, _ = oracle_raw("hydrant-full", 0, bg, gc, wins, keys=keys)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), color_only=True)
     assert set(grads) == {"f_dc", "f_rest"}
-    compare(out, grads, ro, rgrads, m, names=("f_dc", "f_rest"), frag_frac=0.25)
+    compare(out, grads, ro, rgrads, m, names=("f_dc", "f_rest"), frag_frac=0.25, tag="cfg2 hydrant-full SH only")
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev))
-    compare(out, grads, ro, rgrads, m, frag_frac=0.25)
+    compare(out, grads, ro, rgrads, m, frag_frac=0.25, tag="cfg2 hydrant-full all")
 
 
 def test_cfg5_airport_4k_full_backward_vs_windowed_oracle():
@@ -256,7 +293,7 @@ def test_cfg5_airport_4k_full_backward_vs_windowed_oracle():
     go = torch.randn(16, 2160, 3840, generator=g) * 0.2 * m
     ro, rgrads, gc, go = oracle_raw("airport-4K", 0, bg, gc, wins, keys=keys, objects=True, go=go)
     out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev), objects=True, go=go.to(dev))
-    rep = compare(out, grads, ro, rgrads, m, names=RAW + ("objects_dc",), objects=True)
+    rep = compare(out, grads, ro, rgrads, m, names=RAW + ("objects_dc",), objects=True, frag_frac=0.155, tag="cfg5 airport-4K objects")
     print("cfg5 windows", wins, "longest list", longest, rep)
 
 

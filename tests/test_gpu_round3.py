@@ -180,7 +180,10 @@ def _tile_list_parity(scene, n_views=1, windows=None, **kw):
         assert int((ranges[:, 1] - ranges[:, 0]).sum()) == N == int(pairs.numel())
         assert N - n_frag_h == int(gid_o.numel()) - n_frag_o
         if int(frag.sum()) == 0:
-            assert torch.equal(ranges, ranges_o) and torch.equal(gids, gid_o) and N == int(gid_o.numel())
+            lens, lens_o = ranges[:, 1] - ranges[:, 0], ranges_o[:, 1] - ranges_o[:, 0]
+            nz = lens_o > 0                                # (an empty tile's span is (0, 0) here, (start, start) there)
+            assert torch.equal(lens, lens_o) and torch.equal(ranges[nz], ranges_o[nz])
+            assert torch.equal(gids, gid_o) and N == int(gid_o.numel())
     return int(frag.sum()), N
 
 
@@ -323,3 +326,49 @@ def test_asynchronous_pair_count_matches_and_reports_overflow():
         assert n3 == n2 and torch.equal(img2, img3)
     finally:
         D.set_flags(0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fragile pixels: where the oracle says a float32 threshold test may flip, the HIP value must be
+# what ONE of the two branch outcomes gives -- the oracle run in float64 and in float32 takes different sides of most
+# such edges -- not merely "within 1e-2".
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene,kw", [("hydrant-1k", {}), ("nyc-1M", dict(P=60000, width=640, height=360))])
+def test_fragile_pixels_land_on_a_float32_or_float64_outcome(scene, kw):
+    D = _hip()
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.scenes import make_scene
+    dev = torch.device("cuda:0")
+    model, cams, _ = make_scene(scene, device=dev, n_views=1, **kw)
+    cam = cams[0]
+    H, W = cam.image_height, cam.image_width
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    with D.extra_flags(D.FLAG_NO_CULL):
+        full = render(cam, model, PipelineParams(skip_objects=True), bg)
+    depth = D.export_state(full["render"], "G").view(-1, 12)[:, 9].cpu()
+    radii = full["radii"].cpu()
+    depth = torch.where(radii > 0, depth, torch.zeros_like(depth))
+    with torch.no_grad():
+        hip = render(cam, model, PipelineParams(skip_objects=True), bg)["render"].cpu().double()
+    cpu = lambda t: t.detach().cpu()
+    st = O.Settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), cpu(bg), 1.0, cpu(cam.world_view_transform),
+                    cpu(cam.full_proj_transform), 3, cpu(cam.camera_center), False, False)
+    O.check_depth_keys(depth, cpu(model.get_xyz), st, radii)
+    args = (cpu(model.get_xyz), None, cpu(model.get_opacity), st)
+    kws = dict(shs=cpu(model.get_features), scales=cpu(model.get_scaling), rotations=cpu(model.get_rotation), depth_key=depth)
+    with torch.no_grad():
+        r64 = O.rasterize(*args, dtype=torch.float64, **kws)
+        r32 = O.rasterize(*args, dtype=torch.float32, **kws)
+    frag = r64.fragile_px | r32.fragile_px
+    e64 = (hip - r64.color.double()).abs().max(dim=0).values
+    e32 = (hip - r32.color.double()).abs().max(dim=0).values
+    best = torch.minimum(e64, e32)
+    assert e64[~frag].max().item() <= 1e-4
+    n = int(frag.sum())
+    on_branch = int((best[frag] <= 1e-4).sum()) if n else 0
+    print(f"{scene}: fragile px {n} ({n / frag.numel():.4f}), on a float32/float64 outcome: {on_branch}, "
+          f"worst of the rest {best[frag].max().item() if n else 0.0:.2e}")
+    if n:
+        # a pixel with SEVERAL edge decisions may mix the branches; nearly all have one
+        assert on_branch >= 0.9 * n
+        assert best[frag].max().item() <= 1e-2
