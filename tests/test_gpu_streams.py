@@ -83,4 +83,8 @@ def test_pgd_attack_same_history_with_and_without_streams():
     torch.cuda.synchronize()
     for a, b in zip(h1, h3):
         assert abs(a - b) <= 1e-4 * max(abs(a), 1.0)
-    assert (m1._xyz - m3._xyz).abs().max().item() <= 1e-4
+    # same per-view gradients summed in another order (one bucket per stream, folded once): the normalised steps agree to
+    # a small fraction of the distance the positions moved
+    moved = (m1._xyz - model._xyz).abs().max().item()
+    assert moved > 1e-3
+    assert (m1._xyz - m3._xyz).abs().max().item() <= 2e-2 * moved
