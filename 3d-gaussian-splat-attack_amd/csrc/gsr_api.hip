@@ -597,6 +597,28 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const dim3 blkPre(PREG_BLOCK), gridPre(nk1), blkCol(PREF_BLOCK), gridCol(nkc);
   const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
   uint32_t nbound = 0;
+  // K1's colour half: on the side stream unless the caller turned that off (GSR_FLAG_NO_SIDE_STREAM / GSR_SIDE_STREAM=0).
+  // GSR_FORK_LATE=1 (experiment) starts it behind the depth sort instead of behind the geometry half.
+  PreArgs color_pa{};
+  bool want_color = false;
+  static const int fork_late = [] { const char* e = getenv("GSR_FORK_LATE"); return e ? atoi(e) : 0; }();
+  auto launch_color = [&]() -> int {
+    static const int side_env = [] { const char* e = getenv("GSR_SIDE_STREAM"); return e ? atoi(e) : 1; }();
+    hipStream_t cs = st;
+    if (side_env != 0 && !(s->flags & GSR_FLAG_NO_SIDE_STREAM) && side_stream_for(dev, st, side)) {
+      F_TRY("side stream", hipEventRecord(side.fork, st));
+      F_TRY("side stream", hipStreamWaitEvent(side.side, side.fork, 0));
+      cs = side.side;
+      side_used = true;
+    }
+    // beside the chain: a thin grid (GSR_COLOR_BLOCKS workgroups looping over the chunks); alone: one per chunk
+    static const int col_blocks = [] { const char* e = getenv("GSR_COLOR_BLOCKS"); int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
+    const dim3 gridC(side_used ? std::min<unsigned>(gridCol.x, (unsigned)col_blocks) : gridCol.x);
+    if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, color_pa);
+    else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, color_pa);
+    if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
+    return GSR_OK;
+  };
   if (P > 0) {
     {
       StageTimer t(GSR_STAGE_PREPROCESS, st);
@@ -620,23 +642,9 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         pa.cull = cull; pa.bo = bo;
         if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
         else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
-        if (!colors_precomp) {
-          // colour half: on the side stream unless the caller turned that off (GSR_FLAG_NO_SIDE_STREAM / GSR_SIDE_STREAM=0)
-          static const int side_env = [] { const char* e = getenv("GSR_SIDE_STREAM"); return e ? atoi(e) : 1; }();
-          hipStream_t cs = st;
-          if (side_env != 0 && !(s->flags & GSR_FLAG_NO_SIDE_STREAM) && side_stream_for(dev, st, side)) {
-            F_TRY("side stream", hipEventRecord(side.fork, st));
-            F_TRY("side stream", hipStreamWaitEvent(side.side, side.fork, 0));
-            cs = side.side;
-            side_used = true;
-          }
-          // beside the chain: a thin grid (GSR_COLOR_BLOCKS workgroups looping over the chunks); alone: one per chunk
-          static const int col_blocks = [] { const char* e = getenv("GSR_COLOR_BLOCKS"); int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
-          const dim3 gridC(side_used ? std::min<unsigned>(gridCol.x, (unsigned)col_blocks) : gridCol.x);
-          if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, pa);
-          else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, pa);
-          if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
-        }
+        color_pa = pa;
+        want_color = !colors_precomp;
+        if (want_color && !fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
       } else
         hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, cull, means3D, scales, rotations, cov3D_precomp,
                            opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
@@ -670,6 +678,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                               tcnt, vtmp, st);
       F_LAUNCH("depth sort");
     }
+    if (want_color && fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
     if (!async_count) {
       // (the rank-order scan is enqueued after this wait: it records the owners of the emission chunks' first slots, an
       // array sized by N; the depth sort keeps the GPU busy well past the host's wake-up)

@@ -6,8 +6,8 @@
 //           d = x - x0, each ROW clipped to the eps ball: d *= eps / (||d_row|| + 1e-7) when ||d_row|| > eps
 //           (torch.renorm(p=2, dim=0, maxnorm=eps));  x = x0 + d                          (attack.py:53-119, 138-173)
 // Rows are whole Gaussians (cols = 3, 4, 1 or 45 floats).  A wave owns 64 consecutive rows = one contiguous span of
-// the three tensors: it is copied through LDS with coalesced loads (cols is odd or small, so lane r walking row r is
-// bank-conflict free for the 45-float rows) and written back the same way.
+// the three tensors: it is copied through LDS with coalesced 16-byte loads (cols is odd or small, so lane r walking row r
+// is bank-conflict free for the 45-float rows) and written back the same way.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,11 +16,19 @@ namespace gsr {
 
 constexpr int PGD_MAX_COLS = 48;
 
-// per-block partial sums of squares (float per thread, double across the block: the order is fixed => reproducible)
+// per-block partial sums of squares (float per thread, double across the block: the order is fixed => reproducible).
+// 16-byte loads when the tensor starts on a 16-byte boundary (n / 4 float4 + a scalar tail), 4-byte loads otherwise.
 __global__ void __launch_bounds__(256) k_pgd_sumsq(const float* __restrict__ g, size_t n, double* __restrict__ partial) {
   __shared__ double wsum[4];
   float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
+  // (a gradient that is a slice of a flat bucket starts at a multiple of P floats: 16-byte aligned only for some P)
+  const size_t n4 = (reinterpret_cast<uintptr_t>(g) & 15u) == 0u ? (n >> 2) : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = g4[i];
+    acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc = fmaf(g[i], g[i], acc);
   double d = (double)acc;
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) d += __shfl_xor(d, s, 64);
@@ -30,17 +38,20 @@ __global__ void __launch_bounds__(256) k_pgd_sumsq(const float* __restrict__ g, 
 }
 
 // L2 == true: `partial[nb]` holds the block sums of squares of g.
+// A wave's 64 rows are one contiguous, 256-byte aligned span of 64 * cols floats: it is moved with 16-byte accesses
+// (a full wave's span is a whole number of float4; the last, partial wave of a tensor falls back to 4-byte accesses).
 template <bool L2>
 __global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const float* __restrict__ g,
                                                  const float* __restrict__ x0, size_t rows, int cols, float alpha,
                                                  float eps, const double* __restrict__ partial, int nb) {
-  __shared__ float sd[64 * PGD_MAX_COLS];     // the wave's deltas x_new - x0
+  __shared__ __attribute__((aligned(16))) float sd[64 * PGD_MAX_COLS];     // the wave's deltas x_new - x0
   __shared__ float sf[64];                    // per-row clip factors
   const int lane = threadIdx.x;
   const size_t r0 = (size_t)blockIdx.x * 64;
   const int nr = (int)min((size_t)64, rows - r0);
   const size_t base = r0 * (size_t)cols;
   const int n = nr * cols;
+  const bool vec = nr == 64 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x0)) & 15u) == 0u;
   float scale = 0.f;                            // alpha / ||g||  (0 when the gradient is zero: no step)
   if (L2) {
     double t = 0.0;
@@ -50,16 +61,36 @@ __global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const fl
     const float nrm = sqrtf((float)t);
     scale = nrm > 0.f ? alpha / nrm : 0.f;
   }
-  for (int i = lane; i < n; i += 64) {
-    const float xv = x[base + i], gv = g[base + i], ov = x0[base + i];
-    float xn;
+  auto upd = [&](float xv, float gv, float ov, float& dlt) -> float {
     if (L2) {
-      xn = fmaf(-scale, gv, xv);
-      sd[i] = xn - ov;
-    } else {
-      const float sg = gv > 0.f ? 1.f : (gv < 0.f ? -1.f : 0.f);      // torch.sign (NaN -> NaN is not reproduced: 0)
-      xn = fmaf(-alpha, sg, xv);
-      x[base + i] = fminf(fmaxf(xn - ov, -eps), eps) + ov;
+      const float xn = fmaf(-scale, gv, xv);
+      dlt = xn - ov;
+      return xn;
+    }
+    const float sg = gv > 0.f ? 1.f : (gv < 0.f ? -1.f : 0.f);        // torch.sign (NaN -> NaN is not reproduced: 0)
+    const float xn = fmaf(-alpha, sg, xv);
+    dlt = 0.f;
+    return fminf(fmaxf(xn - ov, -eps), eps) + ov;
+  };
+  if (vec) {
+    const int n4 = n >> 2;                      // 16 * cols
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* g4 = reinterpret_cast<const float4*>(g + base);
+    const float4* o4 = reinterpret_cast<const float4*>(x0 + base);
+    float4* xo4 = reinterpret_cast<float4*>(x + base);
+    float4* sd4 = reinterpret_cast<float4*>(sd);
+    for (int i = lane; i < n4; i += 64) {
+      const float4 xv = x4[i], gv = g4[i], ov = o4[i];
+      float4 d, r;
+      r.x = upd(xv.x, gv.x, ov.x, d.x); r.y = upd(xv.y, gv.y, ov.y, d.y);
+      r.z = upd(xv.z, gv.z, ov.z, d.z); r.w = upd(xv.w, gv.w, ov.w, d.w);
+      if (L2) sd4[i] = d; else xo4[i] = r;
+    }
+  } else {
+    for (int i = lane; i < n; i += 64) {
+      float d;
+      const float r = upd(x[base + i], g[base + i], x0[base + i], d);
+      if (L2) sd[i] = d; else x[base + i] = r;
     }
   }
   if (!L2) return;
@@ -80,9 +111,24 @@ __global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const fl
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int i = lane; i < n; i += 64) {
-    const int r = i / cols;
-    x[base + i] = fmaf(sd[i], sf[r], x0[base + i]);
+  if (vec) {
+    const int n4 = n >> 2;
+    const float4* o4 = reinterpret_cast<const float4*>(x0 + base);
+    float4* xo4 = reinterpret_cast<float4*>(x + base);
+    const float4* sd4 = reinterpret_cast<const float4*>(sd);
+    for (int i = lane; i < n4; i += 64) {
+      const float4 ov = o4[i], d = sd4[i];
+      const int e = 4 * i;
+      float4 r;
+      r.x = fmaf(d.x, sf[e / cols], ov.x); r.y = fmaf(d.y, sf[(e + 1) / cols], ov.y);
+      r.z = fmaf(d.z, sf[(e + 2) / cols], ov.z); r.w = fmaf(d.w, sf[(e + 3) / cols], ov.w);
+      xo4[i] = r;
+    }
+  } else {
+    for (int i = lane; i < n; i += 64) {
+      const int r = i / cols;
+      x[base + i] = fmaf(sd[i], sf[r], x0[base + i]);
+    }
   }
 }
 

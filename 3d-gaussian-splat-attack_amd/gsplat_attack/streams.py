@@ -24,11 +24,20 @@ import contextlib
 import torch
 
 
+_STREAM_POOL = {}      # device -> streams shared by every StreamRing on it
+
+
 class StreamRing:
     def __init__(self, n: int, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.n = max(int(n), 1)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)] if self.n > 1 else []
+        # The streams are shared by all rings of a device (and handed out in the same order): libgsraster keeps its
+        # workspace blocks with the stream that used them last, so a ring on fresh streams would make every view of its
+        # first round allocate device memory again (tens of milliseconds per PGD call at 1 M Gaussians).
+        pool = _STREAM_POOL.setdefault(str(self.device), [])
+        while self.n > 1 and len(pool) < self.n:
+            pool.append(torch.cuda.Stream(device=self.device))
+        self.streams = pool[:self.n] if self.n > 1 else []
         self._i = 0
         self._forked = False
         self.current = 0            # index of the stream the innermost `with ring.next()` block runs on

@@ -56,4 +56,11 @@ python3 bench.py --steps 100 --warmup 10 --streams 1 --no-cpu-baseline --no-extr
 python3 bench.py --steps 100 --warmup 10 --scene hydrant-full --no-cpu-baseline --no-extras > $R/gpurun_out/r03_bench_hydrantfull.json 2> $OUT/bench_c2.err || exit 1
 python3 bench.py --steps 50 --warmup 5 --scene airport-4K --no-cpu-baseline --no-extras > $R/gpurun_out/r03_bench_airport4k.json 2> $OUT/bench_c5.err || exit 1
 python3 bench.py --steps 50 --warmup 5 --objects --no-cpu-baseline --no-extras > $R/gpurun_out/r03_bench_objects.json 2> $OUT/bench_obj.err || exit 1
+# kernel statistics of config 2 (S-hydrant-full @800x800) and config 5 (S-airport-4K), one stream
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -o s -- python3 $R/bench.py --steps 100 --warmup 10 --regions 2 --streams 1 --scene hydrant-full --no-cpu-baseline --no-extras > /dev/null 2> $OUT/stats_c2.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o s -- python3 $R/bench.py --steps 50 --warmup 5 --regions 2 --streams 1 --scene airport-4K --no-cpu-baseline --no-extras > /dev/null 2> $OUT/stats_c5.err || exit 1
+cd $R
+cp $OUT/stats_c2/s_kernel_stats.csv $R/gpurun_out/r03_kernel_stats_hydrantfull_1stream.csv
+cp $OUT/stats_c5/s_kernel_stats.csv $R/gpurun_out/r03_kernel_stats_airport4k_1stream.csv
 echo collected

@@ -124,6 +124,32 @@ def test_fused_pgd_step_matches_the_tensor_formulation(shape, kind):
             assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("kind", ["linf", "l2"])
+def test_fused_pgd_step_on_tensors_that_start_off_a_16_byte_boundary(kind):
+    """Gradients that are slices of a flat bucket start at a multiple of P floats -- 4-byte aligned only for odd P: the
+    kernels' 16-byte accesses must fall back, not fault or read the wrong floats."""
+    from gsplat_attack import pgd
+    g = torch.Generator().manual_seed(11)
+    rows, cols = 4099, 45
+    step = pgd.l2_step_ if kind == "l2" else pgd.linf_step_
+    for off in (1, 2, 3):
+        x, grad = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g) * 2.0
+        x0 = x + torch.randn(rows, cols, generator=g)
+        want = x.clone()
+        step(want, grad, 0.5, 0.8, x0)
+
+        def shifted(t):
+            buf = torch.zeros(t.numel() + 4, device="cuda")
+            v = buf[off:off + t.numel()].view(rows, cols)
+            v.copy_(t)
+            assert v.data_ptr() % 16 == 4 * off and v.is_contiguous()
+            return v
+        got = shifted(x)
+        step(got, shifted(grad), 0.5, 0.8, shifted(x0))
+        torch.cuda.synchronize()
+        assert torch.allclose(got.cpu(), want, atol=2e-6, rtol=1e-5), (off, kind)
+
+
 def test_render_with_a_reference_style_pipe_object_takes_the_fused_path():
     """A pipe object with only the reference's three switches (attack.py:254-256) -- what render() sees after
     gsplat_attack.patch_reference() -- still gets the fused raw-parameter path: the image equals the classic surface's
