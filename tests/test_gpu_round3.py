@@ -372,3 +372,100 @@ def test_fragile_pixels_land_on_a_float32_or_float64_outcome(scene, kw):
         # a pixel with SEVERAL edge decisions may mix the branches; nearly all have one
         assert on_branch >= 0.9 * n
         assert best[frag].max().item() <= 1e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Edge cases of the device-side binning chain (round 3): nothing visible, one visible, a depth range that needs the
+# widest digits, more Gaussians than one scan chunk size handles
+# ---------------------------------------------------------------------------------------------------------------------
+def _raw_render(D, dev, xyz, scale_log, opac_logit, W=160, H=96, bg=(0.2, 0.4, 0.6), flags=0, grad=True):
+    from gsplat_attack.cameras import Camera
+    from gsplat_attack.gaussian_model import GaussianModel
+    from gsplat_attack.renderer import PipelineParams, render
+    P = xyz.shape[0]
+    g = torch.Generator().manual_seed(P % 1000 + 3)
+    model = GaussianModel.from_tensors(xyz, torch.randn(P, 1, 3, generator=g) * 0.5, torch.randn(P, 15, 3, generator=g) * 0.1,
+                                       scale_log, torch.randn(P, 4, generator=g), opac_logit, torch.zeros(P, 1, 16),
+                                       sh_degree=3, device=dev, requires_grad=grad)
+    cam = Camera(R=torch.eye(3).numpy(), T=torch.zeros(3).numpy(), FoVx=1.0, FoVy=2 * math.atan(math.tan(0.5) * H / W),
+                 width=W, height=H, device=dev)
+    with D.extra_flags(flags):
+        out = render(cam, model, PipelineParams(skip_objects=True), torch.tensor(bg, device=dev))
+    return model, cam, out
+
+
+def test_no_gaussian_in_front_of_the_camera_renders_the_background():
+    D = _hip()
+    dev = torch.device("cuda:0")
+    P = 5000
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.randn(P, 3, generator=g)
+    xyz[:, 2] = -xyz[:, 2].abs() - 0.5                      # all behind the camera
+    model, cam, out = _raw_render(D, dev, xyz, torch.full((P, 3), -3.0), torch.zeros(P, 1))
+    assert int(out["radii"].max()) == 0 and D.last_num_rendered(out["render"]) == 0
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+    assert torch.equal(out["render"], bg[:, None, None].expand_as(out["render"]))
+    out["render"].sum().backward()
+    for p in model.parameters():
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0
+
+
+def test_one_visible_gaussian_among_culled_ones():
+    D = _hip()
+    dev = torch.device("cuda:0")
+    P = 3000
+    xyz = torch.zeros(P, 3)
+    xyz[:, 2] = -1.0
+    xyz[1234] = torch.tensor([0.0, 0.0, 3.0])
+    model, cam, out = _raw_render(D, dev, xyz, torch.full((P, 3), -2.0), torch.full((P, 1), 2.0))
+    radii = out["radii"]
+    assert int((radii > 0).sum()) == 1 and int(radii[1234]) > 0
+    dv = D.export_state(out["render"], "dv")
+    assert int(dv[1]) == 1 and D.export_state(out["render"], "order").tolist() == [1234]
+    n = D.last_num_rendered(out["render"])
+    assert n >= 1 and float((out["render"].detach() - torch.tensor([0.2, 0.4, 0.6], device=dev)[:, None, None]).abs().max()) > 0.01
+    out["render"].sum().backward()
+    gx = model._xyz.grad.detach().clone()
+    assert float(gx[1234].abs().max()) > 0
+    gx[1234] = 0
+    assert float(gx.abs().max()) == 0.0
+
+
+def test_depth_range_that_needs_the_widest_digits_sorts_exactly():
+    """View depths from 0.25 to 3e5: max - min of the float keys spans 30+ bits, so the three depth passes use 10/11-bit
+    digits (the benchmark scene: 9).  The order must be the stable argsort of the float32 depth."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    P = 40000
+    g = torch.Generator().manual_seed(7)
+    z = torch.exp(torch.rand(P, generator=g) * (math.log(3e5) - math.log(0.25)) + math.log(0.25))
+    z[::7] = z[3]                                           # exact ties: stability
+    xy = (torch.rand(P, 2, generator=g) - 0.5) * 0.6
+    xyz = torch.cat([xy * z[:, None], z[:, None]], dim=1)
+    scale = torch.log(0.01 * z)[:, None].expand(P, 3).contiguous()      # ~1.7 px on screen whatever the depth
+    model, cam, out = _raw_render(D, dev, xyz, scale, torch.zeros(P, 1), flags=D.FLAG_NO_CULL)
+    dv = D.export_state(out["render"], "dv")
+    assert int(dv[3]) >= 10, f"digit width {int(dv[3])}"
+    order = D.export_state(out["render"], "order").long()
+    depth = D.export_state(out["render"], "G").view(-1, 12)[:, 9]
+    vis = out["radii"] > 0
+    assert order.numel() == int(vis.sum())
+    ids = torch.nonzero(vis).flatten()
+    want = ids[torch.argsort(depth[ids], stable=True)]
+    assert torch.equal(order, want)
+
+
+def test_more_gaussians_than_the_small_scan_chunk_handles():
+    """P > 2^21: the rank-order scan runs its 4096-element variant (and records the emission chunks' owners from it);
+    the default path must give the bits of the full-rect path."""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    P = (1 << 21) + 70001
+    g = torch.Generator().manual_seed(2)
+    xyz = torch.randn(P, 3, generator=g) * torch.tensor([1.5, 0.9, 1.0]) + torch.tensor([0.0, 0.0, 4.0])
+    scale = torch.full((P, 3), math.log(0.004)) + torch.randn(P, 3, generator=g) * 0.3
+    opac = torch.randn(P, 1, generator=g)
+    a = _raw_render(D, dev, xyz, scale, opac, W=256, H=160, grad=False)[2]
+    b = _raw_render(D, dev, xyz, scale, opac, W=256, H=160, grad=False, flags=D.FLAG_NO_CULL)[2]
+    assert int((a["radii"] > 0).sum()) > 100000
+    assert torch.equal(a["radii"], b["radii"]) and torch.equal(a["render"], b["render"])
