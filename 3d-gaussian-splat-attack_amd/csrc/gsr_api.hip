@@ -869,7 +869,8 @@ int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const flo
 
 static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
                          float* dshs, float* dsh_dc, float* dsh_objs, float* dcolors_precomp, float* dopacities,
-                         float* dscales, float* drotations, float* dcov3D, void* stream, bool accumulate = false) {
+                         float* dscales, float* drotations, float* dcov3D, void* stream, bool accumulate = false,
+                         int nchunks = 1, gsr_chunk_fn chunk_done = nullptr, void* chunk_user = nullptr) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_backward: null context");
   if (!grad_color) return set_err(GSR_ERR_INVALID, "gsr_backward: grad_color is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -960,7 +961,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   {
     StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
     PreBwdArgs pa;
-    pa.P = P; pa.K = c->K; pa.va = view_args(c->st);
+    pa.P = P; pa.g0 = 0; pa.K = c->K; pa.va = view_args(c->st);
     pa.offg = c->offg; pa.G0 = c->G0; pa.G1 = c->G1; pa.G2 = c->G2;
     pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
     pa.tag_lo = tag_lo; pa.tag_hi = tag_hi; pa.nsub = nsub;
@@ -971,25 +972,37 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
     pa.accumulate = accumulate ? 1 : 0;
-    const dim3 gridK9((unsigned)((P + PRE_BLOCK - 1) / PRE_BLOCK));
     if (c->raw && ((pa.dsh == nullptr) != (pa.dsh_dc == nullptr)))
       return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
     if (c->lanegroup && c->shs && geom && !c->D)
       return done(set_err(GSR_ERR_STATE, "gsr_backward: the forward of this context was run without its backward state"));
-    if (c->lanegroup) {
-      if (c->raw && accumulate) {
-        if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-        else hipLaunchKernelGGL((k_pre_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-      } else if (c->raw) {
-        if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-        else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-      } else {
-        if (geom) hipLaunchKernelGGL((k_pre_bwd<false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-        else hipLaunchKernelGGL((k_pre_bwd<false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+    // The per-Gaussian stage covers the Gaussians in `nchunks` ranges (multiples of 64), one launch each; after a
+    // range's launch is enqueued the caller is told (chunk_done): its gradients are complete in stream order, so a
+    // collective over that range can be issued while the next range is still being computed.
+    nchunks = std::max(1, std::min(nchunks, (P + 63) / 64));
+    const int per = (((P + nchunks - 1) / nchunks) + 63) / 64 * 64;
+    for (int ck = 0; ck < nchunks; ++ck) {
+      const int gb = std::min(ck * per, P), ge = (ck == nchunks - 1) ? P : std::min((ck + 1) * per, P);
+      if (ge > gb) {
+        pa.g0 = gb; pa.P = ge;
+        const dim3 gridK9((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK));
+        if (c->lanegroup) {
+          if (c->raw && accumulate) {
+            if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            else hipLaunchKernelGGL((k_pre_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+          } else if (c->raw) {
+            if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+          } else {
+            if (geom) hipLaunchKernelGGL((k_pre_bwd<false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            else hipLaunchKernelGGL((k_pre_bwd<false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+          }
+        } else {
+          if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+          else hipLaunchKernelGGL((k_preprocess_bwd<false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+        }
       }
-    } else {
-      if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-      else hipLaunchKernelGGL((k_preprocess_bwd<false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+      if (chunk_done) chunk_done(chunk_user, ck, (int64_t)gb, (int64_t)ge);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
@@ -1021,6 +1034,15 @@ int gsr_backward_raw_into(GsrCtx* c, const float* grad_color, const float* grad_
   if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw_into: context came from gsr_forward; use gsr_backward");
   return backward_impl(c, grad_color, grad_objects, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, dobjects_dc, nullptr,
                        dopacity_logit, dlog_scaling, drotation_raw, nullptr, stream, accumulate != 0);
+}
+
+int gsr_backward_raw_chunked(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dxyz, float* dmeans2D,
+                             float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
+                             float* dlog_scaling, float* drotation_raw, int32_t accumulate, int32_t nchunks,
+                             gsr_chunk_fn chunk_done, void* user, void* stream) {
+  if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw_chunked: context came from gsr_forward; use gsr_backward");
+  return backward_impl(c, grad_color, grad_objects, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, dobjects_dc, nullptr,
+                       dopacity_logit, dlog_scaling, drotation_raw, nullptr, stream, accumulate != 0, nchunks, chunk_done, user);
 }
 
 int gsr_mark_visible(const GsrSettings* s, int32_t P, const float* means3D, uint8_t* present, void* stream) {

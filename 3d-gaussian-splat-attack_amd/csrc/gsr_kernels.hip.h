@@ -1166,7 +1166,8 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
 // Gaussian's (tile, Gaussian) pairs are contiguous too (slots are numbered in storage order).
 // ------------------------------------------------------------------------------------------------
 struct PreBwdArgs {
-  int P, K;
+  int P, K;               // P: END of the range of Gaussians this launch covers (= the scene's count for a whole launch)
+  int g0;                 // first Gaussian of the range (a multiple of 64); block b owns Gaussians g0 + 64 b ...
   ViewArgs va;
   const uint32_t* offg;   // [P+1] exclusive scan of tiles touched, storage order
   const float4* G0;
@@ -1201,7 +1202,7 @@ struct PreBwdArgs {
 // object-feature gradients are produced.
 template <bool GEOM>
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
-  const int g = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const int g = a.g0 + blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int K = a.K;
   if (g >= a.P) return;
   const uint32_t o0 = a.offg[g] * a.nsub, o1 = a.offg[g + 1] * a.nsub;
@@ -1565,7 +1566,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
   __shared__ float shand[PRE_WAVES * 64 * HAND_W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw0 = blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
+  const int gw0 = a.g0 + blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
   const int g = gw0 + lane;
   float4* wrow = &srow[wave * ROW_CHUNK * PART_F4];
   float* hand = &shand[wave * 64 * HAND_W];

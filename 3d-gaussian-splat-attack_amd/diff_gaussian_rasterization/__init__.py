@@ -70,6 +70,9 @@ def extra_flags(flags: int):
 GSR_STAGES = ("preprocess", "depth_sort", "bin", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd")
 
 
+_CHUNK_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64)   # gsr_chunk_fn
+
+
 class _CSettings(ctypes.Structure):
     # field order and types mirror `struct GsrSettings` in include/gsraster.h
     _fields_ = [
@@ -118,6 +121,8 @@ def _load():
     lib.gsr_backward_raw.argtypes = [vp] * 12
     lib.gsr_backward_raw_into.restype = ctypes.c_int
     lib.gsr_backward_raw_into.argtypes = [vp] * 11 + [i32, vp]
+    lib.gsr_backward_raw_chunked.restype = ctypes.c_int
+    lib.gsr_backward_raw_chunked.argtypes = [vp] * 11 + [i32, i32, _CHUNK_FN, vp, vp]
     lib.gsr_forward_raw2.restype = ctypes.c_int
     lib.gsr_forward_raw2.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [i32] + [vp] * 7 + [vp, vp, vp, i64p, vp]
     lib.gsr_ctx_free.restype = None
@@ -419,6 +424,12 @@ class GradBucket:
         self.flat = torch.empty(59 * self.P, dtype=torch.float32, device=device)
         self.fresh = True          # the next backward overwrites instead of adding
         self.used = False          # some backward has written since reset()
+        # The next backward runs its per-Gaussian stage in `chunks` launches over ranges of Gaussians and calls
+        # on_chunk(chunk, g_begin, g_end) after each one is enqueued (gsr_backward_raw_chunked): the hook of a
+        # multi-GPU caller that all-reduces range by range while the rest is still being computed.  One-shot:
+        # both are cleared by that backward.
+        self.chunks = 1
+        self.on_chunk = None
 
     def reset(self):
         self.fresh, self.used = True, False
@@ -426,6 +437,11 @@ class GradBucket:
     def slices(self):
         P = self.P
         return [self.flat[c0 * P:c1 * P] for c0, c1 in zip(self.CUTS[:-1], self.CUTS[1:])]
+
+    def range_slices(self, g_begin: int, g_end: int):
+        """The six pieces of the flat buffer that hold the gradients of Gaussians [g_begin, g_end)."""
+        P, W = self.P, (3, 3, 45, 1, 3, 4)
+        return [self.flat[c0 * P + g_begin * w:c0 * P + g_end * w] for c0, w in zip(self.CUTS[:-1], W)]
 
     def views(self) -> dict:
         """name -> tensor view shaped like the model's parameter (e.g. _features_rest: [P,15,3])."""
@@ -551,7 +567,24 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if P > 0:
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-                if bucket is not None:
+                if bucket is not None and bucket.chunks > 1:
+                    hook, bucket.on_chunk = bucket.on_chunk, None
+                    errs = []
+
+                    def _done(_user, chunk, g0, g1):
+                        try:
+                            if hook is not None:
+                                hook(int(chunk), int(g0), int(g1))
+                        except BaseException as e:       # an exception must not unwind through the C frames
+                            errs.append(e)
+                    cb = _CHUNK_FN(_done)
+                    rc = lib.gsr_backward_raw_chunked(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2),
+                                                      _ptr(d_dc), _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro),
+                                                      0 if bucket.fresh else 1, int(bucket.chunks), cb, None, stream)
+                    bucket.chunks = 1
+                    if errs:
+                        raise errs[0]
+                elif bucket is not None:
                     rc = lib.gsr_backward_raw_into(ctx.holder.handle, _ptr(gcol), _ptr(gobj), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
                                                    _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro),
                                                    0 if bucket.fresh else 1, stream)

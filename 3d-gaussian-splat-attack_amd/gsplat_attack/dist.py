@@ -85,3 +85,58 @@ def allreduce_attribute_grads(model, names: Iterable[str] = ATTACK_PARAMS, group
     for w in works:
         w.wait()
     return sum(g.numel() * g.element_size() for g in grads)
+
+
+class BucketAllReduce:
+    """Sum all-reduce of a GradBucket issued range by range while the backward that fills it is still running
+    (SURVEY.md section 8e).  Arm it on the bucket before the LAST backward of the step:
+
+        ar = BucketAllReduce(bucket, chunks=4)          # bucket.chunks / bucket.on_chunk are set
+        loss.backward()                                 # K9 runs in 4 ranges; each range's six slices are all-reduced
+        ar.wait()                                       # asynchronously (RCCL's own stream) as soon as it is enqueued
+
+    With "nccl" every range is ONE grouped collective (all_reduce_coalesced) that waits only for the work enqueued
+    before it -- the ranges behind it overlap with it.  With "gloo" (tests, rehearsals on one GPU) the slices travel
+    through the host synchronously.  The result is that of one all-reduce of the whole bucket (element-wise sums)."""
+
+    def __init__(self, bucket, chunks: int = 4, group=None):
+        self.bucket, self.group, self.works, self.bytes = bucket, group, [], 0
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if self.active:
+            bucket.chunks = max(int(chunks), 1)
+            bucket.on_chunk = self._on_chunk
+            if bucket.chunks == 1:                       # one range: the hook is not called by the unchunked backward
+                bucket.on_chunk = None
+
+    def _on_chunk(self, chunk: int, g0: int, g1: int):
+        if g1 <= g0:
+            return
+        pieces = self.bucket.range_slices(g0, g1)
+        self.bytes += sum(p.numel() for p in pieces) * 4
+        if dist.get_backend(self.group) == "gloo" and pieces[0].is_cuda:
+            for p in pieces:
+                h = p.cpu()
+                dist.all_reduce(h, group=self.group)
+                p.copy_(h)
+        else:
+            self.works.append(dist.all_reduce_coalesced(pieces, group=self.group, async_op=True))
+
+    def wait(self) -> int:
+        """Blocks the current stream until every issued range is reduced (and reduces the whole bucket now if the
+        backward was not chunked).  Returns the bytes reduced."""
+        if not self.active:
+            return 0
+        if self.bytes == 0:                              # unchunked: one collective over the flat buffer
+            flat = self.bucket.flat
+            if dist.get_backend(self.group) == "gloo" and flat.is_cuda:
+                h = flat.cpu()
+                dist.all_reduce(h, group=self.group)
+                flat.copy_(h)
+            else:
+                dist.all_reduce(flat, group=self.group)
+            self.bytes = flat.numel() * 4
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works = []
+        return self.bytes

@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams independent views are dealt over (view i runs on stream i %% S)")
     ap.add_argument("--views-per-rank", type=int, default=1, help="N > 1: views each rank renders per PGD step")
+    ap.add_argument("--ar-chunks", type=int, default=1,
+                    help="N > 1, one bucket per rank: all-reduce the bucket in this many ranges of Gaussians, each issued "
+                         "while K9 still computes the next (1 = one collective after the backward)")
     ap.add_argument("--independent-views", action="store_true",
                     help="N > 1: round-2 behaviour (views pipelined across steps, all-reduce but no parameter update)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -262,24 +265,26 @@ def main():
         def pgd_step():
             for b_ in buckets:
                 b_.reset()
-            for c_ in rank_cams:
+            ar = None
+            for vi, c_ in enumerate(rank_cams):
                 with ring.next():
-                    render(c_, model, pipe_b, bg, scale_mod[0])["render"].backward(gc)
+                    out_ = render(c_, model, pipe_b, bg, scale_mod[0])["render"]
+                    if vi == len(rank_cams) - 1 and len(buckets) == 1 and args.ar_chunks > 1:
+                        # the step's last backward fills the bucket in ranges; each range is all-reduced as soon as its
+                        # K9 launch is enqueued, while the following ranges are still being computed
+                        ar = gdist.BucketAllReduce(buckets[0], args.ar_chunks)
+                    out_.backward(gc)
             ring.join()
             tot = buckets[0]
             for b_ in buckets[1:]:
                 tot.add_(b_)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            if rehearse:
-                host = tot.flat.cpu()
-                dist.all_reduce(host)
-                tot.flat.copy_(host)
-            else:
-                dist.all_reduce(tot.flat)                  # ONE collective: 59 floats per Gaussian
+            e0.record()                                    # every kernel of the step's rasterisation is enqueued before this
+            if ar is None:
+                ar = gdist.BucketAllReduce(tot, 1)
+            bytes_reduced[0] = ar.wait()                   # ONE collective of 59 floats per Gaussian (or its ranges)
             e1.record()
             ar_events.append((e0, e1))
-            bytes_reduced[0] = tot.flat.numel() * 4
             tot.assign_to(model)
             for n_ in gdist.ATTACK_PARAMS:                 # the identical projected step on every rank (attack.py:53-173)
                 p_ = getattr(model, n_)
@@ -471,6 +476,9 @@ def main():
             result["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
             result["bytes_reduced"] = bytes_reduced[0] or 59 * 4 * P
             result["views_per_rank"] = B
+            result["allreduce_chunks"] = args.ar_chunks if (pgd_loop and min(args.streams, B) == 1) else 1
+            result["allreduce_ms_is"] = ("time the compute stream waits for the collective after the step's last "
+                                         "rasteriser kernel (with --ar-chunks > 1 part of it ran behind K9)")
             result["scaling_note"] = ("N > 1 lines time whole PGD iterations (serialised render -> backward -> all-reduce -> "
                                       "step); compare them with `pgd.cfg4_one_gpu` of the N = 1 line, not with its `value` "
                                       "(independent views, no update)")

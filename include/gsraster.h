@@ -162,6 +162,17 @@ int gsr_backward_raw_into(GsrCtx* ctx, const float* grad_color, const float* gra
                           float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
                           float* dlog_scaling, float* drotation_raw, int32_t accumulate, void* stream);
 
+/* gsr_backward_raw_into with the per-Gaussian stage run as `nchunks` launches over consecutive ranges of Gaussians
+ * (boundaries at multiples of 64).  After each range's launch has been enqueued, chunk_done(user, chunk, g_begin, g_end) is
+ * called on the calling thread: every gradient of Gaussians [g_begin, g_end) is then complete in stream order, so the caller
+ * can issue the multi-GPU sum of that range (six slices of the bucket) while the next range is still being computed
+ * ("reduce while K9 finishes").  Results are bit for bit those of the unchunked call. */
+typedef void (*gsr_chunk_fn)(void* user, int32_t chunk, int64_t g_begin, int64_t g_end);
+int gsr_backward_raw_chunked(GsrCtx* ctx, const float* grad_color, const float* grad_objects, float* dxyz, float* dmeans2D,
+                             float* dfeatures_dc, float* dfeatures_rest, float* dobjects_dc, float* dopacity_logit,
+                             float* dlog_scaling, float* drotation_raw, int32_t accumulate, int32_t nchunks,
+                             gsr_chunk_fn chunk_done, void* user, void* stream);
+
 /* Forward-only render of TWO parameter sets as one scene: the attacked target (a) followed by the frozen background (b),
  * Gaussians numbered a then b (radii [Pa+Pb]).  Replaces what the reference does after every PGD step to check the
  * attack: deep-copy the attacked model, append the background to each of its seven tensors (seven concat_setup calls,

@@ -161,3 +161,39 @@ def test_run_attack_follows_the_references_global_iteration_budget(monkeypatch):
     m2 = M()
     rep = A.run_attack(m2, cams, batch_size=2, max_iters=4, success_fn=lambda im, i: True, save_path="y.ply")
     assert m2.saved == [] and not rep["saved"] and rep["batches"][-1]["views"] == [4, 5] and not rep["batches"][-1]["success"]
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    gdist.init_from_env("gloo")
+    from diff_gaussian_rasterization import GradBucket
+    P = 1000
+    res = {}
+    for chunks in (1, 4):
+        b = GradBucket(P, "cpu")
+        b.flat.copy_(torch.randn(59 * P, generator=torch.Generator().manual_seed(7 + rank)))
+        ar = gdist.BucketAllReduce(b, chunks)
+        if chunks > 1:
+            # what gsr_backward_raw_chunked's callback does after each range of K9 is enqueued (ranges end on multiples of 64)
+            assert b.chunks == chunks and b.on_chunk is not None
+            edges = [0, 256, 512, 768, P]
+            for c in range(chunks):
+                b.on_chunk(c, edges[c], edges[c + 1])
+        assert ar.wait() == 59 * 4 * P
+        res[chunks] = b.flat.clone()
+    torch.save(res, os.path.join(out_dir, f"b{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_all_reduce_by_ranges_on_cpu(tmp_path):
+    """BucketAllReduce (gsplat_attack/dist.py): the six slices of every range all-reduced separately give the sum of the
+    whole flat bucket, identically on both ranks (world size 2, gloo)."""
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt")
+    want = sum(torch.randn(59 * 1000, generator=torch.Generator().manual_seed(7 + r)) for r in range(2))
+    for chunks in (1, 4):
+        assert torch.equal(r0[chunks], r1[chunks])
+        assert torch.equal(r0[chunks], want)

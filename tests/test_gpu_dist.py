@@ -135,3 +135,61 @@ def test_bench_pgd_loop_rehearsal_prints_the_multi_gpu_fields(tmp_path):
     assert d["bytes_reduced"] == 59 * 4 * 20000 and d["allreduce_ms"] > 0
     assert len(d["regions_ms"]) == 2 and d["value"] > 0 and d["steps"] == 2
     assert abs(d["value"] - 2 * 2 * 2 / (sorted(d["regions_ms"])[1] * 1e-3)) / d["value"] < 0.02
+    # config 4's shape: one view per rank, the bucket all-reduced in four ranges behind K9
+    cmd2 = [c for c in cmd]
+    cmd2[cmd2.index("--views-per-rank") + 1] = "1"
+    cmd2[cmd2.index("--master-port") + 1] = str(_free_port())
+    cmd2 += ["--ar-chunks", "4"]
+    out = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["views_per_rank"] == 1 and d["allreduce_chunks"] == 4 and d["bytes_reduced"] == 59 * 4 * 20000
+
+
+def _chunk_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import diff_gaussian_rasterization as D
+    from gsplat_attack import dist as gdist
+    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.scenes import make_scene
+    gdist.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    model, cams, _ = make_scene("nyc-1M", device=dev, n_views=2, **KW)
+    P = model.get_xyz.shape[0]
+    gc = torch.randn(3, KW["height"], KW["width"], generator=torch.Generator().manual_seed(rank)).to(dev)
+    res = {}
+    for chunks in (1, 4, 7):
+        bucket = D.GradBucket(P, dev)
+        pipe = PipelineParams(skip_objects=True, grad_bucket=bucket)
+        out = render(cams[rank], model, pipe, torch.zeros(3, device=dev))["render"]
+        seen = []
+        ar = gdist.BucketAllReduce(bucket, chunks)
+        if chunks > 1:
+            inner = bucket.on_chunk
+            bucket.on_chunk = lambda c, g0, g1: (seen.append((c, g0, g1)), inner(c, g0, g1))
+        out.backward(gc)
+        nbytes = ar.wait()
+        torch.cuda.synchronize()
+        assert nbytes == 59 * 4 * P
+        if chunks > 1:
+            assert len(seen) == chunks and seen[0][1] == 0 and seen[-1][2] == P
+            assert all(a[2] == b[1] and a[2] % 64 == 0 for a, b in zip(seen, seen[1:]))
+        res[chunks] = bucket.flat.detach().cpu()
+    torch.save(res, os.path.join(out_dir, f"c{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_all_reduce_in_ranges_equals_the_single_collective(tmp_path):
+    """gsr_backward_raw_chunked + BucketAllReduce: the bucket all-reduced range by range from the backward's per-chunk
+    callback holds, bit for bit, what one all-reduce of the whole bucket gives, on both ranks."""
+    world, port = 2, _free_port()
+    mp.spawn(_chunk_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "c0.pt"), torch.load(tmp_path / "c1.pt")
+    for chunks in (1, 4, 7):
+        assert torch.equal(r0[chunks], r1[chunks]), chunks            # replicas agree
+        assert torch.equal(r0[chunks], r0[1]), chunks                 # and the ranges add up to the single collective
+    assert float(r0[1].abs().max()) > 0
