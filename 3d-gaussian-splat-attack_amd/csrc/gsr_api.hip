@@ -100,7 +100,7 @@ void* pool_alloc(int dev, size_t bytes, hipStream_t st) {
   // Best fit among the free blocks last used on THIS stream (work enqueued later on the same stream is ordered
   // after the old user by the stream itself).  A block last used on another stream would need a host-side wait
   // for that stream, which would serialise views pipelined over several streams: it is taken only once the pool
-  // already holds POOL_SOFT_CAP bytes, otherwise a new block is allocated for this stream.
+  // already holds pool_soft_cap() bytes, otherwise a new block is allocated for this stream.
   int best = -1, other = -1;
   for (size_t i = 0; i < pl.blocks.size(); ++i) {
     const Block& b = pl.blocks[i];
@@ -394,7 +394,7 @@ struct GsrCtx {
   size_t keep_bytes = 0;
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // splat records, storage order (the compositors gather them)
   float* D = nullptr;             // [P,9] d rgb / d view direction (lane-group kernels, SH input, backward expected)
-  bool lanegroup = false;         // K1 ran as k_pre_fwd: K8+K9 runs as k_pre_bwd
+  bool lanegroup = false;         // K1 ran as k_pre_geom + k_pre_color: K8+K9 runs as k_pre_bwd
   uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
   uint32_t* sched = nullptr;      // [ntiles] tiles longest-list-first + priority class

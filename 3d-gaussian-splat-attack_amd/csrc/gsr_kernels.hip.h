@@ -6,15 +6,17 @@
 //                 G0=(px,py,A,B)  G1=(C,opacity,r,g)  G2=(b, depth, rectx_bits, recty_bits)
 //                 rectx_bits = minx | maxx<<12,  recty_bits = miny | maxy<<12   (tile units); a colour whose SH sum was
 //                 clamped at 0 is stored as -0.0f (the clamp flag of the backward)
-//   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF when culled
-//   order[r]      Gaussian index of depth rank r (stable radix argsort of dkey)
-//   off[r]        exclusive scan of tiles touched in depth order, off[P] = N (numbers the emitted pairs)
-//   offg[g]       the same scan in storage order (numbers the backward's partial rows)
+//   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF for a Gaussian that emits no pair
+//   tcnt[g]       tiles of its (tightened) rect; offg[g] = exclusive scan of tcnt in storage order (numbers the
+//                 backward's partial rows), offg[P] = N
+//   order[r]      Gaussian index of depth rank r (stable radix argsort of the live dkey), r < V
+//   off[r]        exclusive scan of tiles touched in depth order, off[V] = N (numbers the emitted pairs)
+//   dv[16]        device-side scalars of the forward (gsr_sort.hip.h, DV_*): N, V, kmin, digit width, overflow, ...
 //   pair_tile/pair_rank[N]  (tile id, Gaussian | strip mask << 28) pairs, emitted in depth-rank order, then stably
 //                 sorted by tile id (=> depth order inside a tile)
 //   ranges[t]     [start,end) of tile t in the sorted pair list
 //   final_T, n_contrib [H*W]  per-pixel transmittance / last contributing list position (1-based)
-//   part[N][12]   backward: per-(tile,Gaussian) partial sums written at the pair's EMISSION slot, so
+//   part[N][12]   backward: per-(tile,Gaussian) partial sums written at the pair's storage-order slot, so
 //                 that the rows of one Gaussian are contiguous and K8/K9 reduces them without atomics
 #pragma once
 #include <hip/hip_runtime.h>
@@ -94,7 +96,7 @@ __device__ __forceinline__ void pre_block_epilogue(const PreBlockOut& o, int g, 
 
 // ------------------------------------------------------------------------------------------------
 // K1, generic form: one thread per Gaussian in storage order, any SH coefficient count K (the layouts the reference
-// uses -- K = 16, the raw dc | rest pair, precomputed colours -- take k_pre_fwd below).
+// uses -- K = 16, the raw dc | rest pair, precomputed colours -- take k_pre_geom / k_pre_color below).
 // cull != 0: the tile rect is shrunk to the alpha >= 1/255 footprint's bounding box (tighten_rect).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArgs va, int cull, const float* __restrict__ means,
@@ -1183,7 +1185,7 @@ struct PreBwdArgs {
   const float* cov3d;
   const float* sh;        // RAW: _features_rest
   const float* sh_dc;     // RAW: _features_dc
-  const float* D;         // [P,9] d rgb / d view direction left by k_pre_fwd (lane-group kernels only)
+  const float* D;         // [P,9] d rgb / d view direction left by k_pre_color (lane-group kernels only)
   float* dmeans3D;
   float* dmeans2D;
   float* dsh;             // RAW: gradient of _features_rest
