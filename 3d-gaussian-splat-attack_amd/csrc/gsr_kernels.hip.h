@@ -251,23 +251,14 @@ __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uin
 // order.  A block emits one chunk of the tile sort's first pass and leaves that pass's digit histogram of its chunk in
 // the radix table: the sort's first histogram launch (a full read of the keys) disappears.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t upper_rank(const uint32_t* off, uint32_t lo, uint32_t hi, uint32_t target) {
-  // largest r in [lo,hi) with off[r] <= target   (off is non-decreasing, off[lo] <= target)
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= target) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // A (tile, Gaussian) pair of the Gaussian's tile rect is kept only if some pixel of the tile can pass
 // the reference's own alpha test (alpha >= 1/255); pairs that cannot are given the key `ntiles`, sort to the
 // tail and are never composited.  The same test per 16x4 strip gives a 4-bit mask that rides in the top bits of
 // the pair's value, so K6/K7 skip strips with scalar bit tests instead of evaluating the splat there.  The rendered
 // image, radii and gradients are unchanged by construction (the test is conservative); only the work shrinks.
 // `cull` = 0 keeps every pair.  dv: device-side counts (DV_N pairs, DV_V ranks).
-// A block = CHUNK / 8 threads emits CHUNK slots, eight per thread with their dependent chains (search -> order[] ->
-// record -> mask) interleaved: the kernel is bound by those chains' latency, not by their arithmetic.
+// A block = CHUNK / 8 threads emits CHUNK slots, eight per thread with their dependent chains (owner -> order[] ->
+// record -> mask) interleaved.  The owner of a slot comes from a running maximum over marks in LDS, not from a search.
 constexpr int EMIT_PER_THREAD = 8;        // slots per thread, in EMIT_BATCHES rounds of EMIT_ILV interleaved chains
 constexpr int EMIT_ILV = 4;
 constexpr int EMIT_GRAIN = rs_chunk(RS_ROUNDS_MIN);     // slots per chunk_first entry (the smaller of the two chunk sizes)
@@ -279,8 +270,11 @@ k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, con
        uint32_t* __restrict__ table, uint32_t nb, uint32_t digit_mask) {
   constexpr int CHUNK = rs_chunk(ROUNDS);
   constexpr int THREADS = CHUNK / EMIT_PER_THREAD;
+  constexpr int WAVES = THREADS / 64;
   __shared__ uint32_t s_off[CHUNK + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_own[CHUNK];   // per slot: its owner's index in s_off
   __shared__ uint32_t s_r[2];
+  __shared__ uint32_t s_w[WAVES];
   __shared__ uint32_t h[RS_BINS];
   const uint32_t N = dv[DV_N], V = dv[DV_V];
   const uint32_t e0 = blockIdx.x * CHUNK;
@@ -298,12 +292,40 @@ k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, con
     s_r[1] = rh;
   }
   if (threadIdx.x < RS_BINS) h[threadIdx.x] = 0;
+  uint4* s_own4 = reinterpret_cast<uint4*>(s_own);
+  s_own4[2 * threadIdx.x] = make_uint4(0, 0, 0, 0);
+  s_own4[2 * threadIdx.x + 1] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   const uint32_t r_lo = s_r[0], r_hi = s_r[1];
-  const uint32_t span = r_hi - r_lo + 1;
-  const bool in_lds = span <= (uint32_t)(CHUNK + 1);
-  if (in_lds)
-    for (uint32_t i = threadIdx.x; i < span; i += THREADS) s_off[i] = off[r_lo + i];
+  const uint32_t span = r_hi - r_lo + 1;                    // <= CHUNK: every rank of the chunk owns a slot of it
+  // Slot -> owner without a search: rank i of the chunk marks the slot its run starts on (rank 0's run starts at or
+  // before e0: it owns the slots in front of the first mark), and a running maximum over the slots spreads the marks.
+  for (uint32_t i = threadIdx.x; i < span; i += THREADS) {
+    const uint32_t v = off[r_lo + i];
+    s_off[i] = v;
+    if (i) s_own[v - e0] = i;
+  }
+  __syncthreads();
+  {
+    uint4 a = s_own4[2 * threadIdx.x], b = s_own4[2 * threadIdx.x + 1];
+    a.y = max(a.y, a.x); a.z = max(a.z, a.y); a.w = max(a.w, a.z);
+    b.x = max(b.x, a.w); b.y = max(b.y, b.x); b.z = max(b.z, b.y); b.w = max(b.w, b.z);
+    uint32_t t = b.w;                                       // inclusive maximum over the lanes below, then the waves below
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(t, d, 64);
+      if ((int)(threadIdx.x & 63) >= d) t = max(t, u);
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = t;
+    uint32_t c = __shfl_up(t, 1, 64);
+    if ((threadIdx.x & 63) == 0) c = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES - 1; ++w) if ((int)(threadIdx.x >> 6) > w) c = max(c, s_w[w]);
+    a.x = max(a.x, c); a.y = max(a.y, c); a.z = max(a.z, c); a.w = max(a.w, c);
+    b.x = max(b.x, c); b.y = max(b.y, c); b.z = max(b.z, c); b.w = max(b.w, c);
+    s_own4[2 * threadIdx.x] = a; s_own4[2 * threadIdx.x + 1] = b;
+  }
   __syncthreads();
 #pragma unroll 1
   for (int bt = 0; bt < EMIT_PER_THREAD / EMIT_ILV; ++bt) {
@@ -316,12 +338,8 @@ k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, con
     uint32_t r = r_lo;
     o[k] = 0;
     if (on[k]) {
-      if (in_lds) {
-        const uint32_t i = upper_rank(s_off, 0, span, e[k]);
-        r = r_lo + i; o[k] = s_off[i];
-      } else {
-        r = upper_rank(off, r_lo, r_hi + 1, e[k]); o[k] = off[r];
-      }
+      const uint32_t i = s_own[e[k] - e0];
+      r = r_lo + i; o[k] = s_off[i];
     }
     g[k] = on[k] ? order[r] : 0u;                          // the pair's value: the Gaussian (storage index)
   }
