@@ -455,6 +455,50 @@ def test_depth_range_that_needs_the_widest_digits_sorts_exactly():
     assert torch.equal(order, want)
 
 
+@pytest.mark.parametrize("dist", ["constant", "two-values", "cluster+outliers", "shell-16-buckets", "shell-40-buckets", "narrow",
+                                  "uniform", "log-uniform"])
+def test_depth_order_is_the_stable_argsort_whatever_the_depth_distribution(dist):
+    """The depth sort (three counting passes whose digit width follows the keys' range) on distributions that stress a
+    sort by depth: every key equal, two values, 95 % of the Gaussians in a shell 1e-3 thick with outliers stretching the
+    key range, shells a few thousand keys deep per 2^16 float steps, a range narrower than one digit, and spread-out
+    ones.  Ties everywhere: the order must be the STABLE argsort of the float32 depths.  (These are the cases a bucketed
+    variant of the sort -- EXPERIMENTS.md, round 3 -- was developed against; they hold for any implementation.)"""
+    D = _hip()
+    dev = torch.device("cuda:0")
+    P = 60000
+    g = torch.Generator().manual_seed(11)
+    u = torch.rand(P, generator=g)
+    if dist == "constant":
+        z = torch.full((P,), 5.0)
+    elif dist == "two-values":
+        z = torch.where(u < 0.3, torch.tensor(2.0), torch.tensor(7.5))
+    elif dist == "cluster+outliers":
+        z = 10.0 + (u - 0.5) * 1e-3
+        z[::20] = torch.exp(torch.rand(P // 20, generator=g) * math.log(400.0)) * 0.3      # 0.3 .. 120
+    elif dist.startswith("shell"):
+        # outliers 0.3 .. 120 make the key range ~27 bits; the shell is 16 (or 40) runs of 2^16 float32 steps deep
+        z = 8.0 + u * (1.0 if dist == "shell-16-buckets" else 2.5)
+        z[::20] = torch.exp(torch.rand(P // 20, generator=g) * math.log(400.0)) * 0.3
+    elif dist == "narrow":
+        z = 5.0 + torch.floor(u * 700.0) * 4.76837158203125e-07                           # 700 adjacent float32 values
+    elif dist == "uniform":
+        z = 1.0 + u * 30.0
+    else:
+        z = torch.exp(u * math.log(1000.0)) * 0.3
+    z[::9] = z[4]                                           # exact ties: stability
+    xy = (torch.rand(P, 2, generator=g) - 0.5) * 0.6
+    xyz = torch.cat([xy * z[:, None], z[:, None]], dim=1)
+    scale = torch.log(0.01 * z)[:, None].expand(P, 3).contiguous()
+    model, cam, out = _raw_render(D, dev, xyz, scale, torch.zeros(P, 1), flags=D.FLAG_NO_CULL, grad=False)
+    order = D.export_state(out["render"], "order").long()
+    depth = D.export_state(out["render"], "G").view(-1, 12)[:, 9]
+    vis = out["radii"] > 0
+    assert order.numel() == int(vis.sum()) and order.numel() > P // 2
+    ids = torch.nonzero(vis).flatten()
+    want = ids[torch.argsort(depth[ids], stable=True)]
+    assert torch.equal(order, want)
+
+
 def test_more_gaussians_than_the_small_scan_chunk_handles():
     """P > 2^21: the rank-order scan runs its 4096-element variant (and records the emission chunks' owners from it);
     the default path must give the bits of the full-rect path."""
