@@ -547,7 +547,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   SlabPlan sp;
   sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey, k1, vtmp, v2, tcnt
   sp.add<uint32_t>((size_t)RS_BINS_DEV * nbP); sp.add<uint32_t>(RS_BINS_DEV);
-  sp.add<uint4>(nk1); sp.add<uint32_t>(nbP + 2);
+  sp.add<uint4>(nk1); sp.add<uint32_t>(nbP + 2); sp.add<unsigned long long>(nbP + 2);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
     pool_free(dev, scratch_blk);
@@ -568,6 +568,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   uint32_t* table = ss.take<uint32_t>((size_t)RS_BINS_DEV * nbP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS_DEV);
   uint4* bout = ss.take<uint4>(nk1);
   uint32_t* psums = ss.take<uint32_t>(nbP + 2);
+  unsigned long long* scan_flags = ss.take<unsigned long long>(nbP + 2);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
   void* tbl_blk = nullptr;
@@ -602,6 +603,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   PreArgs color_pa{};
   bool want_color = false;
   static const int fork_late = [] { const char* e = getenv("GSR_FORK_LATE"); return e ? atoi(e) : 0; }();
+  // the rank-order scan in one launch (blocks wait for their predecessors' sums) or in two (GSR_CHAINED_SCAN=0)
+  static const int chained_scan = [] { const char* e = getenv("GSR_CHAINED_SCAN"); return e ? atoi(e) : 1; }();
   auto launch_color = [&]() -> int {
     static const int side_env = [] { const char* e = getenv("GSR_SIDE_STREAM"); return e ? atoi(e) : 1; }();
     hipStream_t cs = st;
@@ -660,7 +663,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       if (!capturing && !slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
       c->fwd_stream = st;
       hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint32_t*)dkey,
-                         (const uint4*)bout, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
+                         (const uint4*)bout, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token, chained_scan ? scan_flags : nullptr);
       F_LAUNCH("preprocess");
     }
     {
@@ -721,7 +724,11 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       StageTimer t(GSR_STAGE_BIN, st);
       // off[r] = pairs emitted by the ranks in front of r, off[V] = their total; chunk_first[c] = rank that owns slot
       // c * EMIT_GRAIN
-      scan_exclusive_u32(vtmp, c->off, (uint32_t)P, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
+      if (chained_scan)
+        scan_exclusive_u32_chained(vtmp, c->off, (uint32_t)P, c->dv + DV_V, scan_flags, c->dv + DV_OVF, st, chunk_first,
+                                   (uint32_t)EMIT_GRAIN, ngrain);
+      else
+        scan_exclusive_u32(vtmp, c->off, (uint32_t)P, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
       F_LAUNCH("rank scan");
       int sh0; uint32_t mask0;
       radix_first_digit(tile_bits, sh0, mask0);

@@ -182,12 +182,14 @@ __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uin
                                                            const uint4* __restrict__ bout, uint32_t* __restrict__ offg,
                                                            uint32_t* __restrict__ table, uint32_t nb,
                                                            uint32_t* __restrict__ dv, unsigned long long cap,
-                                                           uint32_t* host_slot, uint32_t host_token) {
+                                                           uint32_t* host_slot, uint32_t host_token,
+                                                           unsigned long long* __restrict__ scan_flags) {
   __shared__ uint32_t tmp[4];
   __shared__ unsigned long long tmp64[4];
   __shared__ uint32_t h[RS_BINS_DEV];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   const uint32_t base = b * DCHUNK + tid * DITEMS;
+  if (scan_flags && tid == 0) scan_flags[b] = 0ull;       // the rank-order scan further down the stream starts from cleared words
   // this chunk's tiles-touched counts and depth keys are requested first: they do not depend on the reduction below
   uint32_t v[DITEMS], kk[DITEMS];
 #pragma unroll

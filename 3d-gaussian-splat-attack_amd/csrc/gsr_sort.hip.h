@@ -155,6 +155,77 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply_carry(const uint32_
   if (b == nb - 1 && threadIdx.x == 0) out[n] = carry + total;
 }
 
+// The same scan in ONE launch, for a stream that has a kernel in front which can clear `flags` (one 64-bit word per
+// block, all zero at launch): block b publishes (1 << 32 | its sum) as soon as it has it and then adds up the words of
+// the blocks in front of it, waiting for those not yet published.  Blocks are dispatched in index order and a running
+// block never waits for a later one, so every wait ends; the words are read and written at agent scope (sc1: they
+// never sit stale in an XCD's L2).  A block sums ALL its predecessors' words itself -- a few hundred to a few thousand
+// 8-byte loads spread over 256 threads -- there is no chain of look-backs to serialise on.  The wait is bounded
+// anyway: a word that never arrives sets *err (the forward's overflow flag: the image is poisoned, nothing hangs).
+constexpr uint32_t SCAN_SPIN_LIMIT = 1u << 22;
+template <int ITEMS>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_chained(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                               const uint32_t* __restrict__ n_dev,
+                                                               unsigned long long* flags, uint32_t* __restrict__ chunk_first,
+                                                               uint32_t chunk_len, uint32_t chunk_cap,
+                                                               uint32_t* __restrict__ err) {
+  constexpr int CHUNK = SCAN_THREADS * ITEMS;
+  __shared__ uint32_t tmp[4];
+  if (n_dev) n = min(n, *n_dev);
+  const uint32_t b = blockIdx.x;
+  if (n == 0) { if (b == 0 && threadIdx.x == 0) out[0] = 0u; return; }
+  if (b * CHUNK >= n) return;
+  const uint32_t nb = (n + CHUNK - 1) / CHUNK;
+  const uint32_t base = b * CHUNK + threadIdx.x * ITEMS;
+  uint32_t v[ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+  uint32_t total;
+  const uint32_t excl = block_excl_scan_256(s, tmp, total);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&flags[b], (1ull << 32) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t part = 0;
+  bool late = false;
+  for (uint32_t i = threadIdx.x; i < b; i += SCAN_THREADS) {
+    unsigned long long f = __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t spins = 0; (f >> 32) == 0ull; ++spins) {
+      if (spins >= SCAN_SPIN_LIMIT) { late = true; break; }
+      __builtin_amdgcn_s_sleep(2);
+      f = __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    part += (uint32_t)f;
+  }
+  if (late) *err = 1u;
+  uint32_t carry;
+  block_excl_scan_256(part, tmp, carry);                 // carry = sum of the block sums in front of this block
+  uint32_t run = excl + carry;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    if (base + i < n) out[base + i] = run;
+    if (chunk_first && v[i] != 0u) {
+      for (uint32_t c = (run + chunk_len - 1u) / chunk_len;
+           c < chunk_cap && (unsigned long long)c * chunk_len < (unsigned long long)run + v[i]; ++c)
+        chunk_first[c] = base + i;
+    }
+    run += v[i];
+  }
+  if (b == nb - 1 && threadIdx.x == 0) out[n] = carry + total;
+}
+
+// flags: ceil(n / 2048) 64-bit words, zero when the launch starts (see k_scan_chained); err: see there.
+inline void scan_exclusive_u32_chained(const uint32_t* in, uint32_t* out, uint32_t n, const uint32_t* n_dev,
+                                       unsigned long long* flags, uint32_t* err, hipStream_t st,
+                                       uint32_t* chunk_first = nullptr, uint32_t chunk_len = 1, uint32_t chunk_cap = 0) {
+  if (n == 0) { (void)hipMemsetAsync(out, 0, sizeof(uint32_t), st); return; }
+  if (n <= (2u << 20))
+    hipLaunchKernelGGL((k_scan_chained<8>), dim3((n + 2047) / 2048), dim3(SCAN_THREADS), 0, st, in, out, n, n_dev, flags,
+                       chunk_first, chunk_len, chunk_cap, err);
+  else
+    hipLaunchKernelGGL((k_scan_chained<16>), dim3((n + 4095) / 4096), dim3(SCAN_THREADS), 0, st, in, out, n, n_dev, flags,
+                       chunk_first, chunk_len, chunk_cap, err);
+}
+
 // out may alias in; out holds n + 1 words (out[n_live] = total).  sums: ceil(n / 2048) words.
 inline void scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, const uint32_t* n_dev, uint32_t* sums,
                                hipStream_t st, uint32_t* chunk_first = nullptr, uint32_t chunk_len = 1,
