@@ -276,7 +276,7 @@ GSR_HD void sh_to_rgb_bwd(int deg, int Kstore, const float* sh, const float p[3]
 // Inputs: true partials dL/dA, dL/dB, dL/dC of the conic (B counted once), dL/d(ndc.xy) (= the
 // extension's dL_dmean2D), and the forward inputs.  Outputs: dL/dmean (added into dp), dL/dcov3D
 // packed (dc6), to be pushed further to scale/rotation by cov3d_bwd when those were the inputs.
-GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6], float dA, float dB, float dC,
+GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6], double dA, double dB, double dC,
                               float dndcx, float dndcy, float dp[3], float dc6[6]) {
   float t[3];
   for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
@@ -284,12 +284,16 @@ GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6]
   proj_linear(v, t, pl);
   float a, b, c;
   cov2d_from_M(pl.M, c6, a, b, c);
-  const float det = a * c - b * b;
-  const float d2 = 1.0f / (det * det);   // det >= DILATE^2 - rounding > 0 for a PSD covariance
-  // conic = (c, -b, a)/det
-  const float da = (-c * c * dA + b * c * dB - b * b * dC) * d2;
-  const float db = (2.f * b * c * dA - (det + 2.f * b * b) * dB + 2.f * a * b * dC) * d2;
-  const float dc = (-b * b * dA + a * b * dB - a * a * dC) * d2;
+  // conic = (c, -b, a) / det.  The three sums below cancel to first order for an elongated splat (cov2D ~ l1 u u^T, and
+  // dL/dconic ~ K (u_x^2, 2 u_x u_y, u_y^2) from the pixels along its axis: every term is ~ l1^2 K, their sum ~ l1 l2 K),
+  // so they are formed in double: float32 products lose l1 / l2 (1e4 for a 100:1 needle) times 6e-8 here, on top of
+  // what the summed dL/dconic already carries.  A few dozen double operations per Gaussian, in a memory-bound kernel.
+  const double ad = (double)a, bd = (double)b, cd = (double)c;
+  const double det = ad * cd - bd * bd;
+  const double d2 = 1.0 / (det * det);   // det >= DILATE^2 - rounding > 0 for a PSD covariance
+  const float da = (float)((-cd * cd * dA + bd * cd * dB - bd * bd * dC) * d2);
+  const float db = (float)((2.0 * bd * cd * dA - (det + 2.0 * bd * bd) * dB + 2.0 * ad * bd * dC) * d2);
+  const float dc = (float)((-bd * bd * dA + ad * bd * dB - ad * ad * dC) * d2);
   // D = [[da, db/2],[db/2, dc]];  dL/dSigma3 = M^T D M (symmetric 3x3)
   const float hb = 0.5f * db;
   const float* M = pl.M;
