@@ -1609,8 +1609,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   // ---- sum this Gaussian's partial rows (the wave's rows are one contiguous span) ------------------------------------
   // (the second moments are summed in double: what they feed -- dL/dconic -> dL/dcov2D -- cancels to first order for an
   // elongated splat, see project_splat_bwd, and amplifies the rounding of a float32 running sum over hundreds of rows)
-  float mx = 0.f, my = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-  double mxx = 0.0, mxy = 0.0, myy = 0.0;
+  float dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+  double mx = 0.0, my = 0.0, mxx = 0.0, mxy = 0.0, myy = 0.0;      // (conic . (mx, my) cancels the same way)
   {
     const uint32_t S = a.offg[gw0] * a.nsub, E = a.offg[gw0 + nw] * a.nsub;
     const bool big = (o1 - o0) > (uint32_t)ROW_CHUNK;
@@ -1627,7 +1627,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
           const float4* r = &wrow[(e - c0) * PART_F4];
           const float4 p0 = r[0], p1 = r[1], p2 = r[2];
           if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-          if (GEOM) { mx += p0.x; my += p0.y; mxx += (double)p0.z; mxy += (double)p0.w; myy += (double)p1.x; dop += p1.y; }
+          if (GEOM) { mx += (double)p0.x; my += (double)p0.y; mxx += (double)p0.z; mxy += (double)p0.w; myy += (double)p1.x; dop += p1.y; }
           dr += p1.z; dg += p1.w; db += p2.x;
         }
       }
@@ -1641,23 +1641,23 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       bm &= bm - 1;
       const uint32_t b0 = __shfl(o0, L, 64), b1 = __shfl(o1, L, 64);
       float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      double t2[3] = {0.0, 0.0, 0.0};
+      double t2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       for (uint32_t e = b0 + lane; e < b1; e += 64) {
         const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
         if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
-        if (GEOM) { t[0] += p0.x; t[1] += p0.y; t2[0] += (double)p0.z; t2[1] += (double)p0.w; t2[2] += (double)p1.x; t[5] += p1.y; }
+        if (GEOM) { t2[3] += (double)p0.x; t2[4] += (double)p0.y; t2[0] += (double)p0.z; t2[1] += (double)p0.w; t2[2] += (double)p1.x; t[5] += p1.y; }
         t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
       }
 #pragma unroll
       for (int i = 0; i < 9; ++i) t[i] = __shfl(wave_sum_to_hi(t[i]), 63, 64);
       if (GEOM) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 5; ++i) {
 #pragma unroll
           for (int sft = 32; sft > 0; sft >>= 1) t2[i] += __shfl_xor(t2[i], sft, 64);
         }
       }
-      if (lane == L) { mx = t[0]; my = t[1]; mxx = t2[0]; mxy = t2[1]; myy = t2[2]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
+      if (lane == L) { mx = t2[3]; my = t2[4]; mxx = t2[0]; mxy = t2[1]; myy = t2[2]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
     }
   }
   // ---- phase A: chain rule per Gaussian ------------------------------------------------------------------------------
@@ -1697,8 +1697,8 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       load_view(v, a.va);
       const float A = e0.z, B = e0.w, C = e1.x;
       // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
-      const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
-      const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
+      const float dndcx = (float)(-((double)A * mx + (double)B * my) * (0.5 * (double)v.W));
+      const float dndcy = (float)(-((double)B * mx + (double)C * my) * (0.5 * (double)v.H));
       const double dA = -0.5 * mxx, dB = -mxy, dC = -0.5 * myy;
       if (GEOM && a.dmeans2D) { put(&a.dmeans2D[3 * g], dndcx); put(&a.dmeans2D[3 * g + 1], dndcy); put(&a.dmeans2D[3 * g + 2], 0.f); }
       if (GEOM && a.dopac) put(&a.dopac[g], RAW ? dop * e1.y * (1.f - e1.y) : dop);   // e1.y = sigmoid(raw opacity)
