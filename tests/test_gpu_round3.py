@@ -499,6 +499,33 @@ def test_depth_order_is_the_stable_argsort_whatever_the_depth_distribution(dist)
     assert torch.equal(order, want)
 
 
+def test_needle_splats_keep_their_geometry_gradients():
+    """Splats 100:1 long that cross the whole image: cov2D ~ l1 u u^T, and the published dL/dconic -> dL/dcov2D formula
+    (-c^2 dA + b c dB - b^2 dC) / det^2 cancels to first order.  In float32 it lost l1 / l2 times its rounding -- a random
+    configuration (tests/diag_fuzz.py seed 1192) had one needle whose rotation gradient was 4.5 % off --; K9 forms the
+    cancelling sums in double (gsr_math.h project_splat_bwd).  Six such needles among ordinary splats, against oracle-R
+    float64 on the solid pixels (the oracle flags a band along every needle as fragile: a float32 conic of that shape is
+    uncertain by 1e-4, times terms of 1e4 in the exponent); the float32 formulation fails on the rotation gradients."""
+    import test_gpu_parity as T
+    from gsplat_attack.cameras import look_at_camera
+    g = torch.Generator().manual_seed(5)
+    P = 300
+    xyz = torch.randn(P, 3, generator=g) * torch.tensor([0.5, 0.4, 0.5])
+    scales = torch.exp(torch.randn(P, 3, generator=g) * 0.3 + math.log(0.03))
+    scales[:6, 0] = 2.0                                      # six needles among ordinary splats (the oracle flags the pixels
+    scales[:6, 1:] = 0.02                                    # of a needle-only scene as fragile: their float32 conics differ)
+    rots = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
+    opac = torch.sigmoid(torch.randn(P, 1, generator=g) + 0.5)
+    shs = torch.randn(P, 16, 3, generator=g) * 0.2
+    shs[:, 0] += torch.randn(P, 3, generator=g)
+    inp = dict(means3D=xyz, shs=shs, opacities=opac, scales=scales, rotations=rots)
+    cam = look_at_camera((2.1, 0.8, 2.4), (0.0, 0.0, 0.0), fovx=0.9, width=120, height=72)
+    rep = T.check(inp, cam, torch.tensor([0.1, 0.3, 0.2]), sh_degree=2, scale_modifier=1.0, seed=5, frag_frac=0.6,
+                  elem_frac=5e-3)
+    print("needle splats, normwise gradient error vs float64:", {k: f"{v[0]:.2e}" for k, v in rep.items()})
+    assert rep["rotations"][0] <= 2e-4 and rep["scales"][0] <= 3e-4       # float32 formulation: rotations 5.2e-4
+
+
 def test_more_gaussians_than_the_small_scan_chunk_handles():
     """P > 2^21: the rank-order scan runs its 4096-element variant (and records the emission chunks' owners from it);
     the default path must give the bits of the full-rect path."""
