@@ -121,6 +121,54 @@ def test_per_gaussian_forward_and_backward(lib, precomp_cov):
     assert torch.allclose(m2.grad[:, :2][vm_], u[:, 3:5][vm_])      # means2D receives dL/d(ndc.xy) unchanged
 
 
+def test_backward_of_needle_splats_survives_the_cancellation(lib):
+    """A 100:1 needle seen side-on has cov2D ~ l1 u u^T, and the upstream dL/dconic that its own pixels produce is
+    ~ K (u_x^2, 2 u_x u_y, u_y^2): in dL/dcov2D = (-c^2 dA + b c dB - b^2 dC) / det^2 (and its two siblings) terms of
+    size l1^2 K cancel down to l1 l2 K.  gsr_math.h forms those sums in double; in float32 the scale / rotation
+    gradients of such splats came out 1e-3 .. 1e-2 off (EXPERIMENTS.md, round 3)."""
+    P, K, H, W = 12, 16, 96, 128
+    g = torch.Generator().manual_seed(3)
+    cam = look_at_camera((0.0, 0.0, -3.3), (0.0, 0.0, 0.0), fovx=0.9, fovy=0.7, width=W, height=H)
+    st = settings_for(cam, torch.zeros(3), scale_modifier=1.0)
+    means = (torch.randn(P, 3, generator=g) * 0.3).float()
+    scales = torch.tensor([2.0, 0.02, 0.03]).repeat(P, 1) * torch.exp(torch.randn(P, 3, generator=g) * 0.1)
+    rots = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
+    sh = torch.zeros(P, K, 3)
+    dt = torch.float64
+    m3 = means.to(dt).requires_grad_(True)
+    sc = scales.float().to(dt).requires_grad_(True)
+    ro = rots.float().to(dt).requires_grad_(True)
+    geo = O.preprocess(m3, sc, ro, None, st, torch.zeros(P, 3, dtype=dt))
+    assert bool(geo.valid.all())
+    A, B, C = geo.conic[:, 0].detach(), geo.conic[:, 1].detach(), geo.conic[:, 2].detach()
+    assert float(((A * C - B * B) * 1.0).max()) < 5e-3, "the case is made of needles (conic determinant ~ 1 / (l1 l2))"
+    # long axis u of every splat on screen = eigenvector of the conic's SMALL eigenvalue
+    w, V = torch.linalg.eigh(torch.stack([torch.stack([A, B], 1), torch.stack([B, C], 1)], 1))
+    ux, uy = V[:, 0, 0], V[:, 1, 0]
+    Kc = torch.rand(P, generator=g, dtype=dt) * 50.0 + 10.0
+    u = torch.zeros(P, 8, dtype=dt)
+    u[:, 0], u[:, 1], u[:, 2] = Kc * ux * ux, 2.0 * Kc * ux * uy, Kc * uy * uy
+    u[:, 0:3] += torch.randn(P, 3, generator=g, dtype=dt) * 1e-3 * Kc[:, None]      # what the pixels off the axis add
+    u = torch.tensor(f32(u), dtype=dt)                       # both sides start from the same float32 upstream values
+    (geo.conic * u[:, 0:3]).sum().backward()
+    vm, pm, cp = f32(st.viewmatrix), f32(st.projmatrix), f32(st.campos)
+    mf, sf, rf, shf, up = f32(m3), f32(sc), f32(ro), f32(sh), f32(u)
+    dmeans = np.zeros((P, 3), np.float32)
+    dsh = np.zeros((P, K, 3), np.float32)
+    dsc = np.zeros((P, 3), np.float32)
+    dro = np.zeros((P, 4), np.float32)
+    va = np.ones(P, np.int32)
+    cb = np.zeros(P, np.int32)
+    lib.hm_preprocess_bwd(P, K, H, W, cf(st.tanfovx), cf(st.tanfovy), cf(1.0), 3, ptr(vm), ptr(pm), ptr(cp), ptr(mf), ptr(sf),
+                          ptr(rf), None, ptr(shf), ptr(up), ptr(va), ptr(cb), ptr(dmeans), ptr(dsc), ptr(dro), None, ptr(dsh))
+    for name, a, b in (("scales", dsc, sc.grad), ("rots", dro, ro.grad), ("means", dmeans, m3.grad)):
+        b = b.numpy()
+        rel = np.abs(a - b).max(axis=1) / np.abs(b).max(axis=1)          # per splat: every one of them is a needle
+        print(f"needle backward on the host, {name}: worst per-splat relative error {rel.max():.2e}")
+        # float32 cov2D entries (6e-8 each) times l1 / l2 bound what is left: 3e-4 on the scales; the float32 sums gave 9e-3
+        assert rel.max() < 1e-3, (name, rel)
+
+
 def test_tile_footprint_test_is_conservative(lib):
     """tile_can_contribute must never reject a (tile, Gaussian) pair in which some pixel passes the
     reference's alpha >= 1/255 test (brute force over the 256 pixel centres), and should reject most that do not."""
