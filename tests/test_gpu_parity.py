@@ -96,6 +96,7 @@ def check(inp, cam, bg, sh_degree=3, scale_modifier=1.0, with_gobj=False, seed=9
     err = (color.double() - ref.color).abs().max(dim=0).values
     solid = ~ref.fragile_px
     share = ref.fragile_px.float().mean().item()
+    assert bool(solid.any()), f"the oracle flags every pixel fragile (share {share:.4f}): nothing to compare"
     print(f"fragile share {share:.4f} (cap {frag_frac}), solid RGB err {err[solid].max().item():.2e}")
     assert share <= frag_frac
     assert err[solid].max().item() <= RGB_TOL, f"RGB max abs err {err[solid].max().item():.3e}"
