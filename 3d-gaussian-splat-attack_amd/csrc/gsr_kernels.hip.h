@@ -1216,7 +1216,8 @@ struct PreBwdArgs {
   float* dscales;
   float* drots;
   float* dcov3d;
-  int accumulate;         // != 0: every output is ADDED to (read-modify-write) and Gaussians without pairs are left alone
+  int accumulate;         // != 0 (k_pre_bwd only): the 59 attribute gradients are ADDED to (Gaussians without pairs are
+                          // left alone); dmeans2D and dsh_objs, which belong to one view, are overwritten regardless
 };
 
 // Generic form (any K): one thread per Gaussian walks its own partial rows and its own SH row.
@@ -1228,7 +1229,6 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   const int K = a.K;
   if (g >= a.P) return;
   const uint32_t o0 = a.offg[g] * a.nsub, o1 = a.offg[g + 1] * a.nsub;
-  if (o1 == o0 && a.accumulate) return;   // no pairs: nothing to add
   if (o1 == o0) {   // no pairs: zero gradients
     if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
     if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
@@ -1241,8 +1241,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     if (a.dcov3d) for (int i = 0; i < 6; ++i) a.dcov3d[6 * g + i] = 0.f;
     return;
   }
-  const bool acc = a.accumulate != 0;
-  auto put = [acc](float* p, float v) { if (acc) *p += v; else *p = v; };
+  // (this kernel always overwrites its outputs: accumulation into a caller's bucket exists for the raw-parameter path
+  // only, which runs k_pre_bwd -- gsr_backward_raw_into)
+  auto put = [](float* p, float v) { *p = v; };
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
   for (uint32_t e = o0; e < o1; ++e) {
     const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
@@ -1284,13 +1285,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   if (a.sh) {
     const uint32_t cl = (__float_as_uint(e1.z) >> 31) | ((__float_as_uint(e1.w) >> 31) << 1) | ((__float_as_uint(e2.x) >> 31) << 2);
     const float drgb[3] = {(cl & 1u) ? 0.f : dr, (cl & 2u) ? 0.f : dg, (cl & 4u) ? 0.f : db};
-    if (a.dsh && !acc) {
+    if (a.dsh) {
       sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, a.dsh + (size_t)g * K * 3, dp);
-    } else if (a.dsh && K <= 16) {
-      float scratch[48];
-      sh_to_rgb_bwd(v.sh_degree, K, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
-      for (int i = 0; i < 3 * K; ++i) a.dsh[(size_t)g * K * 3 + i] += scratch[i];
-    } else {
+    } else {      // dL/dSH not wanted: only the view-direction term of dL/dmean (the basis has at most 16 functions)
       float scratch[48];
       sh_to_rgb_bwd(v.sh_degree, 16, a.sh + (size_t)g * K * 3, p, v.cam, drgb, scratch, dp);
     }
@@ -1664,7 +1661,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   float hdir[3] = {0.f, 0.f, 0.f}, hrgb[3] = {0.f, 0.f, 0.f};
   if (g < a.P) {
     if (o1 == o0 && acc) {
-      // nothing to add for a Gaussian without pairs
+      // nothing to add to the caller's bucket for a Gaussian without pairs; the two per-VIEW outputs (screen-space
+      // gradient, object features) are not part of the bucket and are overwritten in either mode
+      if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
+      if (a.dsh_objs) for (int i = 0; i < NUM_OBJ; ++i) a.dsh_objs[(size_t)g * NUM_OBJ + i] = 0.f;
     } else if (o1 == o0) {   // culled: zero gradients (dL/dSH: phase B writes the zeros)
       if (a.dmeans3D) { a.dmeans3D[3 * g] = 0.f; a.dmeans3D[3 * g + 1] = 0.f; a.dmeans3D[3 * g + 2] = 0.f; }
       if (a.dmeans2D) { a.dmeans2D[3 * g] = 0.f; a.dmeans2D[3 * g + 1] = 0.f; a.dmeans2D[3 * g + 2] = 0.f; }
@@ -1691,7 +1691,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
           }
         }
 #pragma unroll
-        for (int c = 0; c < NUM_OBJ; ++c) put(&a.dsh_objs[(size_t)g * NUM_OBJ + c], acc_o[c]);
+        for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc_o[c];      // per view: never added to
       }
       View v;
       load_view(v, a.va);
@@ -1700,7 +1700,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       const float dndcx = (float)(-((double)A * mx + (double)B * my) * (0.5 * (double)v.W));
       const float dndcy = (float)(-((double)B * mx + (double)C * my) * (0.5 * (double)v.H));
       const double dA = -0.5 * mxx, dB = -mxy, dC = -0.5 * myy;
-      if (GEOM && a.dmeans2D) { put(&a.dmeans2D[3 * g], dndcx); put(&a.dmeans2D[3 * g + 1], dndcy); put(&a.dmeans2D[3 * g + 2], 0.f); }
+      if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }   // per view
       if (GEOM && a.dopac) put(&a.dopac[g], RAW ? dop * e1.y * (1.f - e1.y) : dop);   // e1.y = sigmoid(raw opacity)
       float dp[3] = {0.f, 0.f, 0.f};
       if (a.dcolors) { put(&a.dcolors[3 * g], dr); put(&a.dcolors[3 * g + 1], dg); put(&a.dcolors[3 * g + 2], db); }

@@ -32,7 +32,7 @@ from torch import nn
 from . import dist as gdist
 from . import pgd
 from .streams import StreamRing
-from .renderer import PipelineParams, _has_raw_layout, render, render_pair
+from .renderer import PipelineParams, render, render_pair, takes_fused_path
 
 GROUPS = ("color", "position", "scaling", "rotation", "opacity")
 
@@ -125,6 +125,14 @@ def gather_success(flags: Sequence[bool], n_views: int, rank: int, world: int, d
     return [bool(v) for v in full.tolist()]
 
 
+def batch_done(flags: Sequence[bool], n_views: int) -> bool:
+    """The stopping rule of a batch, in ONE place for pgd_attack and run_attack: all views of the batch fooled, or all
+    but one (reference attack.py:560, `num_successes >= len(batch) - 1`); a batch of a single view (batch_mode false,
+    attack.py:590-598) has to succeed itself -- the literal B - 1 = 0 would retire it after one iteration whatever the
+    detector says."""
+    return sum(bool(f) for f in flags) >= max(n_views - 1, 1)
+
+
 def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5, epsilon: float = 5.0,
                groups: Iterable[str] = ("color",), norm: str = "l2", bg: Optional[torch.Tensor] = None,
                loss_fn: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, pipe: Optional[PipelineParams] = None,
@@ -192,8 +200,10 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
         # accumulation into .grad to autograd's read-modify-write.  One bucket per stream, folded once per iteration;
         # the folded bucket IS the all-reduce buffer and becomes .grad without a copy.
         buckets = None
-        if (use_buckets and dev.type == "cuda" and not frozen and getattr(pipe, "fused_activations", True)
-                and _has_raw_layout(model) and all(getattr(model, n).requires_grad for n in gdist.ATTACK_PARAMS)):
+        # (only render()'s fused path fills a bucket: the same predicate decides here -- with convert_SHs_python /
+        # compute_cov3D_python the classic surface runs and autograd accumulates into .grad as before)
+        if (use_buckets and dev.type == "cuda" and not frozen and takes_fused_path(model, pipe)
+                and all(getattr(model, n).requires_grad for n in gdist.ATTACK_PARAMS)):
             from diff_gaussian_rasterization import GradBucket
             P = int(model.get_xyz.shape[0])
             buckets = [GradBucket(P, dev) for _ in range(ring.n if ring is not None else 1)]
@@ -240,8 +250,12 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                 tot = buckets[0]
                 for b in buckets[1:]:
                     tot.add_(b)
-                if not tot.used:                           # a rank without views contributes zeros
-                    tot.flat.zero_()
+                if not tot.used:
+                    if mine:                               # a bucket that no backward of this rank's views wrote: the
+                        raise RuntimeError(                # renders did not take the path the buckets were made for
+                            "pgd_attack: the gradient bucket was not written by any of this rank's views (render() did "
+                            "not take the fused raw-parameter path); pass use_buckets=False")
+                    tot.flat.zero_()                       # a rank without views contributes zeros
                     tot.used, tot.fresh = True, False
                 if world > 1:
                     flat = tot.flat
@@ -283,9 +297,7 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                 flags = gather_success([success_fn(im, i) for im, i in zip(imgs, my_idx)], len(cameras), rank, world, dev)
                 pgd_attack.last_successes = flags
                 rec["successes"] = flags
-                # attack.py:560: all views of the batch, or all but one; a single view (batch_mode false,
-                # attack.py:590-598) has to succeed itself
-                done = sum(flags) >= max(len(cameras) - 1, 1)
+                done = batch_done(flags, len(cameras))
             if log is not None:
                 if dev.type == "cuda":
                     torch.cuda.synchronize()
@@ -340,7 +352,7 @@ def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5
                           success_fn=lambda im, j: success_fn(im, cur[j]), originals=originals, **kw)
         it += len(hist)
         flags = pgd_attack.last_successes or []
-        ok = bool(hist) and sum(flags) >= len(cur) - 1
+        ok = bool(hist) and batch_done(flags, len(cur))
         report.append({"views": cur, "iters": len(hist), "success": bool(ok), "loss": hist[-1] if hist else None})
         if ok:
             pending = pending[len(cur):]

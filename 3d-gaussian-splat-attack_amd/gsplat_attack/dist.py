@@ -95,9 +95,10 @@ class BucketAllReduce:
         loss.backward()                                 # K9 runs in 4 ranges; each range's six slices are all-reduced
         ar.wait()                                       # asynchronously (RCCL's own stream) as soon as it is enqueued
 
-    With "nccl" every range is ONE grouped collective (all_reduce_coalesced) that waits only for the work enqueued
-    before it -- the ranges behind it overlap with it.  With "gloo" (tests, rehearsals on one GPU) the slices travel
-    through the host synchronously.  The result is that of one all-reduce of the whole bucket (element-wise sums)."""
+    With "nccl" the six slices of a range are six asynchronous all-reduces (the public entry point; RCCL's own stream
+    orders them behind the work enqueued before them and the ranges behind overlap with them).  With "gloo" (tests,
+    rehearsals on one GPU) the slices travel through the host synchronously.  The result is that of one all-reduce of
+    the whole bucket (element-wise sums)."""
 
     def __init__(self, bucket, chunks: int = 4, group=None):
         self.bucket, self.group, self.works, self.bytes = bucket, group, [], 0
@@ -119,7 +120,8 @@ class BucketAllReduce:
                 dist.all_reduce(h, group=self.group)
                 p.copy_(h)
         else:
-            self.works.append(dist.all_reduce_coalesced(pieces, group=self.group, async_op=True))
+            for p in pieces:
+                self.works.append(dist.all_reduce(p, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self) -> int:
         """Blocks the current stream until every issued range is reduced (and reduces the whole bucket now if the

@@ -52,6 +52,15 @@ def _has_raw_layout(pc) -> bool:
         return False
 
 
+def takes_fused_path(pc, pipe, override_color=None) -> bool:
+    """True when render() hands the model's RAW parameters to the rasteriser (gsr_forward_raw): the only path that fills a
+    GradBucket.  The reference's two Python switches (gaussian_renderer/__init__.py:62-63,70-78) and an override colour
+    take the classic activated-tensor surface."""
+    return bool(getattr(pipe, "fused_activations", True) and override_color is None
+                and not getattr(pipe, "convert_SHs_python", False) and not getattr(pipe, "compute_cov3D_python", False)
+                and _has_raw_layout(pc))
+
+
 def _settings(cam, pc, pipe, bg_color, scaling_modifier) -> GaussianRasterizationSettings:
     """The 12 fields in call-site order (reference gaussian_renderer/__init__.py:33-49): tan(FoV/2), integer image size,
     the camera's transposed matrices, the model's ACTIVE SH degree, prefiltered always False."""
@@ -77,6 +86,15 @@ class RenderResult(dict):
 
     def __getitem__(self, key):
         return self._resolve() if key == self._LAZY else dict.__getitem__(self, key)
+
+    # dict(result), {**result}, f(**result) and other.update(result) copy a dict SUBCLASS through PyDict_Merge's fast path
+    # (raw stored values, no __getitem__) unless the subclass has its own __iter__: with these two they go through
+    # keys() + __getitem__ and see the resolved entry
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def keys(self):
+        return dict.keys(self)
 
     def get(self, key, default=None):
         return self[key] if key in self else default
@@ -146,9 +164,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     st = _settings(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     no_objects = bool(getattr(pipe, "skip_objects", False))
 
-    fused = (getattr(pipe, "fused_activations", True) and override_color is None and not pipe.convert_SHs_python
-             and not pipe.compute_cov3D_python and _has_raw_layout(pc))
-    if fused:
+    if takes_fused_path(pc, pipe, override_color):
         bucket = getattr(pipe, "grad_bucket", None)
         if callable(bucket):
             bucket = bucket()

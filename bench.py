@@ -140,6 +140,52 @@ def parity_and_cfg1(dev) -> dict:
                          "sample": "oracle-R float32 fwd+bwd, S-hydrant-1k 128x128"}}
 
 
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def fan_out(n: int) -> int:
+    """`python bench.py --gpus N` started as a PLAIN process (no torchrun: WORLD_SIZE unset): this parent starts the N
+    ranks itself -- one child per GPU running this same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    exactly what `python -m torch.distributed.run --nproc-per-node N` would give them -- touches no GPU, lets rank 0's
+    JSON line through on the inherited stdout, and returns non-zero if any child fails (the others are then stopped by
+    their exact PIDs).  Under torchrun this function is never reached."""
+    import signal
+    import subprocess
+    rehearse = os.environ.get("BENCH_REHEARSE_GLOO", "0") == "1"
+    if not rehearse:
+        have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+        if have < n:
+            print(f"[bench] --gpus {n} but this node shows {have} HIP device(s)", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].send_signal(signal.SIGTERM)
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +222,8 @@ def main():
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(fan_out(args.gpus))              # before anything touches a GPU in this (parent) process
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the raster path has no CPU fallback")
     from gsplat_attack import dist as gdist
@@ -190,8 +238,10 @@ def main():
     rank, world, local = gdist.init_from_env("gloo" if rehearse else "nccl")
     if rehearse:
         local = 0
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (torchrun "
+                         f"--nproc-per-node {args.gpus}), or run `python bench.py --gpus {args.gpus}` as a plain process "
+                         "and it starts them itself")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     D._load()
@@ -382,6 +432,14 @@ def main():
     stages = {k: (ms / max(nb_views, 1), calls) for k, (ms, calls) in D.profile_read().items()}
     D.profile(False)
 
+    ranks_seen = 1
+    if world > 1:
+        # every rank adds one: what the collective path really spans (a line that says n_gpus: N while the ranks never
+        # met would be the silent one-GPU measurement again)
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == world, (ranks_seen, world)
     if rank == 0:
         N, V, HW = info["N"], info["V"], H * W
         sb = stage_bytes(P, V, N, HW)
@@ -473,6 +531,12 @@ def main():
         if seq is not None:
             result["sequential"] = seq
         if world > 1:
+            result["ranks_seen"] = ranks_seen
+            try:
+                result["rccl"] = None if rehearse else ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                         # noqa: BLE001 -- a version string must not cost the line
+                result["rccl"] = f"unavailable: {e}"
+            result["collective_backend"] = dist.get_backend()
             result["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
             result["bytes_reduced"] = bytes_reduced[0] or 59 * 4 * P
             result["views_per_rank"] = B

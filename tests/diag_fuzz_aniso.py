@@ -1,40 +1,32 @@
-"""Diagnostic (not a test): the random-configuration parity check with strongly anisotropic splats (log-normal scales with
-sigma 1.2 .. 2.2 per axis: needles and discs of 10:1 .. 1000:1), fragile-pixel allowance lifted and reported.
+"""Diagnostic (not a test): the random-configuration parity check with strongly anisotropic splats (fuzz_cases.aniso_case),
+fragile-pixel allowance lifted and reported, next to the float32 yardstick: oracle-R run in float32 on the same inputs
+and the same loss -- its image and gradient errors against float64 are what float32 arithmetic costs the published
+algorithm itself (round 4: the implementation is held to twice that, not to "explained").
     python tests/diag_fuzz_aniso.py SEED_LO SEED_HI
 """
-import math, os, sys, traceback, torch
+import os, sys, traceback
 sys.path.insert(0, os.path.dirname(__file__))
 import conftest  # noqa
 import test_gpu_parity as T
-from gsplat_attack.cameras import look_at_camera
+from fuzz_cases import aniso_case
 
 bad = []
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
-    g = torch.Generator().manual_seed(seed)
-
-    def u(lo, hi):
-        return lo + (hi - lo) * torch.rand((), generator=g).item()
-    P = int(round(math.exp(u(math.log(20.0), math.log(3000.0)))))
-    W, H = int(u(40, 230)), int(u(40, 170))
-    xyz = torch.randn(P, 3, generator=g) * torch.tensor([u(0.1, 0.6), u(0.1, 0.6), u(0.1, 0.6)])
-    scales = torch.exp(torch.randn(P, 3, generator=g) * u(1.2, 2.2) + math.log(u(0.01, 0.05))).clamp(max=1.5)
-    rots = torch.nn.functional.normalize(torch.randn(P, 4, generator=g))
-    opac = torch.sigmoid(torch.randn(P, 1, generator=g) * u(0.5, 3.0) + u(-2.0, 2.0))
-    shs = torch.randn(P, 16, 3, generator=g) * u(0.05, 0.5)
-    shs[:, 0] += torch.randn(P, 3, generator=g)
-    inp = dict(means3D=xyz, shs=shs, opacities=opac, scales=scales, rotations=rots)
-    dist = u(1.5, 3.5)
-    th, ph = u(0, 2 * math.pi), u(-0.6, 0.6)
-    eye = (dist * math.cos(th) * math.cos(ph), dist * math.sin(ph), dist * math.sin(th) * math.cos(ph))
-    cam = look_at_camera(eye, (u(-0.1, 0.1), u(-0.1, 0.1), u(-0.1, 0.1)), fovx=u(0.3, 1.4), width=W, height=H)
-    bg = torch.rand(3, generator=g)
+    inp, cam, bg, kw, desc = aniso_case(seed)
     try:
-        rep = T.check(inp, cam, bg, sh_degree=int(u(0, 3.999)), scale_modifier=u(0.5, 1.8), with_gobj=False, seed=seed,
-                      frag_frac=1.0, elem_frac=5e-3)
-        worst = max(rep.items(), key=lambda kv: kv[1][0])
-        print(f"seed {seed}: P={P} {W}x{H} ok, worst normwise gradient error {worst[1][0]:.2e} ({worst[0]})", flush=True)
+        rep = T.check(inp, cam, bg, frag_frac=1.0, elem_frac=5e-3, f32_grads=True, **kw)
+        y = T.check.last_yardstick
+        img = (f"fragile {y['fragile']:.3f}, clause B {y['need_b']:.4f}, neither {y['neither_px']} px, hip err "
+               f"{y['worst_any']:.2e} vs float32 oracle {y['f32_vs_f64']:.2e}")
+        if rep:
+            k, v = max(rep.items(), key=lambda kv: kv[1][0])
+            kf, vf = max(rep.items(), key=lambda kv: kv[1][1])
+            print(f"seed {seed}: {desc} ok; {img}; worst normwise gradient error {v[0]:.2e} ({k}; float32 oracle {v[2]:.2e}), "
+                  f"worst off-element share {vf[1]:.2e} ({kf}; float32 oracle {vf[3]:.2e})", flush=True)
+        else:
+            print(f"seed {seed}: {desc} ok (every pixel fragile: image held to the yardstick, no gradients compared); {img}", flush=True)
     except Exception as e:                                   # noqa
         bad.append(seed)
         tb = traceback.extract_tb(e.__traceback__)[-1]
-        print(f"seed {seed}: P={P} {W}x{H} {type(e).__name__}: {str(e)[:200]} at {os.path.basename(tb.filename)}:{tb.lineno}", flush=True)
+        print(f"seed {seed}: {desc} {type(e).__name__}: {str(e)[:300]} at {os.path.basename(tb.filename)}:{tb.lineno}", flush=True)
 print("failed seeds:", bad)

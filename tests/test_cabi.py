@@ -137,3 +137,24 @@ def test_render_result_makes_the_visibility_filter_on_demand():
     assert dict(r2.items())["visibility_filter"].tolist() == [False, True, False, True]
     r3 = RenderResult(render=None, viewspace_points=None, visibility_filter=None, radii=radii, render_object=None)
     assert r3.pop("visibility_filter").tolist() == [False, True, False, True] and "visibility_filter" not in r3
+
+
+def test_render_result_copies_and_splats_see_the_resolved_filter():
+    """dict(result), {**result}, f(**result) and other.update(result) go through CPython's PyDict_Merge, whose
+    fast path for dict subclasses reads the raw stored None; RenderResult has its own __iter__ / keys so that they
+    resolve the lazy entry."""
+    import torch
+    from gsplat_attack.renderer import RenderResult
+    radii = torch.tensor([0, 3, 0, 7], dtype=torch.int32)
+
+    def fresh():
+        return RenderResult(render=None, viewspace_points=None, visibility_filter=None, radii=radii, render_object=None)
+    want = [False, True, False, True]
+    assert dict(fresh())["visibility_filter"].tolist() == want
+    assert {**fresh()}["visibility_filter"].tolist() == want
+    assert (lambda **kw: kw["visibility_filter"])(**fresh()).tolist() == want
+    other = {}
+    other.update(fresh())
+    assert other["visibility_filter"].tolist() == want
+    assert fresh().copy()["visibility_filter"].tolist() == want
+    assert [k for k in fresh()] == ["render", "viewspace_points", "visibility_filter", "radii", "render_object"]

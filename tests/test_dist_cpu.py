@@ -163,6 +163,39 @@ def test_run_attack_follows_the_references_global_iteration_budget(monkeypatch):
     assert m2.saved == [] and not rep["saved"] and rep["batches"][-1]["views"] == [4, 5] and not rep["batches"][-1]["success"]
 
 
+def test_a_single_view_batch_must_succeed_itself(monkeypatch):
+    """run_attack and pgd_attack share ONE stopping rule (attack.batch_done).  With batch_size = 1 the
+    reference's literal `successes >= B - 1` is 0 >= 0: a view whose detector is never fooled would be reported as a
+    success and the model saved.  It has to run its window, be dropped, and nothing is saved."""
+    from gsplat_attack import attack as A
+    assert A.batch_done([False], 1) is False and A.batch_done([True], 1) is True
+    assert A.batch_done([True, False], 2) and not A.batch_done([False, False], 2)
+    assert A.batch_done([True, True, False], 3) and not A.batch_done([True, False, False], 3)
+
+    class M:
+        def __init__(self):
+            for n in A.gdist.ATTACK_PARAMS:
+                setattr(self, n, torch.zeros(2, 3))
+            self.saved = []
+
+        def save_ply(self, path):
+            self.saved.append(path)
+
+    def fake_pgd(model, batch, *, iters, success_fn, **kw):
+        fake_pgd.last_successes = [bool(success_fn(None, j)) for j in range(len(batch))]
+        return [0.0] * (1 if A.batch_done(fake_pgd.last_successes, len(batch)) else iters)
+    fake_pgd.last_successes = None
+    monkeypatch.setattr(A, "pgd_attack", fake_pgd)
+    m = M()
+    rep = A.run_attack(m, [0, 1], batch_size=1, max_iters=5, success_fn=lambda im, i: False, save_path="z.ply")
+    assert [b["success"] for b in rep["batches"]] == [False, False]
+    assert not rep["all_succeeded"] and not rep["saved"] and m.saved == []
+    assert all(b.get("dropped") for b in rep["batches"])
+    m2 = M()
+    rep = A.run_attack(m2, [0, 1], batch_size=1, max_iters=5, success_fn=lambda im, i: True, save_path="z.ply")
+    assert rep["all_succeeded"] and rep["saved"] and m2.saved == ["z.ply"]
+
+
 def _bucket_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -197,3 +230,24 @@ def test_bucket_all_reduce_by_ranges_on_cpu(tmp_path):
     for chunks in (1, 4):
         assert torch.equal(r0[chunks], r1[chunks])
         assert torch.equal(r0[chunks], want)
+
+
+def test_bench_fan_out_parent_reports_a_failing_rank():
+    """bench.py --gpus 2 as a plain command starts two ranks itself and touches no GPU in the parent; here (no HIP device)
+    every rank exits with bench.py's "needs a HIP device" error and the parent must hand a non-zero code on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("only meaningful without a device")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["BENCH_REHEARSE_GLOO"] = "1"                          # skips the device-count check: the children must fail themselves
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "needs a HIP device" in out.stderr and "stopping the other ranks" in out.stderr or out.stderr.count("needs a HIP device") == 2
+    # and without the rehearsal switch the parent itself refuses: fewer devices than ranks
+    env.pop("BENCH_REHEARSE_GLOO")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 2 and "HIP device" in out.stderr

@@ -146,6 +146,27 @@ def test_bench_pgd_loop_rehearsal_prints_the_multi_gpu_fields(tmp_path):
     assert d["views_per_rank"] == 1 and d["allreduce_chunks"] == 4 and d["bytes_reduced"] == 59 * 4 * 20000
 
 
+def test_bench_started_as_a_plain_command_fans_out_by_itself():
+    """`python3 bench.py --gpus 2 ...` WITHOUT torchrun (the shape of the driver's N = 1 command) must start
+    its two ranks itself and measure both -- it used to print a note and time one GPU.  Rehearsed over gloo on the one
+    GPU: the line says n_gpus 2 and ranks_seen 2 (an all-reduced 1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_REHEARSE_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--regions", "2",
+           "--P", "20000", "--width", "320", "--height", "192", "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                              # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["collective_backend"] == "gloo" and d["config"]["loop"] == "pgd"
+    assert d["bytes_reduced"] == 59 * 4 * 20000 and d["value"] > 0
+
+
 def _chunk_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
