@@ -105,6 +105,18 @@ class PhaseTimer:
         return out
 
 
+_CHECK_STREAMS = {}
+
+
+def _check_stream(dev):
+    """One extra stream per device for the success re-renders of pgd_attack (kept: libgsraster's workspace blocks stay
+    with the stream that used them last)."""
+    key = str(dev)
+    if key not in _CHECK_STREAMS:
+        _CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _CHECK_STREAMS[key]
+
+
 def _world():
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         return torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -140,7 +152,7 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                batch_loss: bool = False, loss_reduction: str = "sum", background=None,
                success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
                originals: Optional[dict] = None, use_buckets: bool = True,
-               timer: Optional["PhaseTimer"] = None) -> List[float]:
+               timer: Optional["PhaseTimer"] = None, overlap_success: bool = True) -> List[float]:
     """Runs up to `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
     initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
     pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order.
@@ -164,7 +176,13 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         ("successes") and in pgd_attack.last_successes.
       use_buckets       (default on) the fused backward adds each view's attribute gradients into a per-stream
                         GradBucket instead of handing autograd a fresh 59-float-per-Gaussian buffer per view; off =
-                        round-2 behaviour (A/B, tests)."""
+                        round-2 behaviour (A/B, tests).
+      overlap_success   (default on; device only) the success re-render of iteration i (attack.py:522-530) and the FORWARD of
+                        iteration i + 1's first view both depend on nothing but the stepped parameters: the re-render goes
+                        to a side stream, the next forward is enqueued beside it, and the flags are read when that forward is
+                        in the queue.  If the batch turns out to be done, the speculative forward is dropped -- nothing has
+                        been differentiated, accumulated or stepped -- so the iteration count, the history and the saved
+                        model are those of the serial loop (off: strictly serial, what a PhaseTimer measures)."""
     groups = tuple(groups)
     assert all(g in GROUPS for g in groups) and norm in ("l2", "linf") and loss_reduction in ("sum", "mean")
     dev = model.get_xyz.device
@@ -210,15 +228,57 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             pipe = copy.copy(pipe)
             pipe.grad_bucket = (lambda: buckets[ring.current]) if ring is not None else buckets[0]
         run_flat = None                                    # accumulate_grads with buckets: the running sum
+        overlap = (overlap_success and success_fn is not None and dev.type == "cuda" and not batch_loss and timer is None)
+        check_stream = _check_stream(dev) if overlap else None
+        pending = None                                     # overlap: the success renders whose flags have not been read yet
+        t_mark = [time.perf_counter()]
+
+        def finish_iteration(rec, imgs_and_event):
+            """Reads the success flags of an iteration (its renders are in `imgs_and_event`), logs it; True: batch done."""
+            done = False
+            if imgs_and_event is not None:
+                imgs, ev = imgs_and_event
+                if ev is not None:
+                    with torch.cuda.stream(check_stream):
+                        mine_flags = [success_fn(im, i) for im, i in zip(imgs, my_idx)]
+                    torch.cuda.current_stream(dev).wait_event(ev)      # the parameters are not stepped under the renders
+                else:
+                    mine_flags = [success_fn(im, i) for im, i in zip(imgs, my_idx)]
+                flags = gather_success(mine_flags, len(cameras), rank, world, dev)
+                pgd_attack.last_successes = flags
+                rec["successes"] = flags
+                done = batch_done(flags, len(cameras))
+            if log is not None:
+                if dev.type == "cuda":
+                    torch.cuda.synchronize()
+                now = time.perf_counter()
+                rec["seconds"] = now - t_mark[0]
+                t_mark[0] = now
+                log(rec)
+            if done and save_path is not None and rank == 0:
+                model.save_ply(save_path)
+            return done
+
+        stopped = False
         for it in range(iters):
-            t0 = time.perf_counter()
             if timer is not None:
                 timer.start()
-            if buckets is not None:
-                for b in buckets:
-                    b.reset()
-            elif not accumulate_grads or world > 1:
-                model.zero_grad()                          # multi-GPU: .grad holds THIS step's gradient until reduced
+            if pending is not None and not mine:           # a rank without views has no forward to hide the wait behind
+                stopped = finish_iteration(*pending)
+                pending = None
+                if stopped:
+                    break
+            def clear_gradients():
+                if buckets is not None:
+                    for b in buckets:
+                        b.reset()
+                elif not accumulate_grads or world > 1:
+                    model.zero_grad()                      # multi-GPU: .grad holds THIS step's gradient until reduced
+            # (with a success check pending, the gradients of the previous iteration stay in place until its flags are
+            # read: a batch that turns out to be done returns with them, like the serial loop)
+            cleared = pending is None
+            if cleared:
+                clear_gradients()
             losses = []
             if batch_loss:
                 if mine:
@@ -229,9 +289,19 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                     loss.backward()
                     losses.append(loss.detach())
             else:
-                for cam in mine:                           # one forward+backward per view: peak memory = one view per stream
+                for vi, cam in enumerate(mine):            # one forward+backward per view: peak memory = one view per stream
                     with (ring.next() if ring is not None else contextlib.nullcontext()):
                         img = render(cam, model, pipe, bg)["render"]
+                        if pending is not None:
+                            # the previous iteration's success renders ran beside this forward: now read their flags
+                            stopped = finish_iteration(*pending)
+                            pending = None
+                            if stopped:
+                                del img                    # speculative: never differentiated, nothing accumulated
+                                break
+                        if not cleared:
+                            clear_gradients()
+                            cleared = True
                         if timer is not None:
                             timer.lap("render")
                         loss = loss_fn(img[None])
@@ -245,6 +315,8 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         losses.append(loss.detach())
                 if ring is not None:
                     ring.join()
+                if stopped:
+                    break
             total = torch.stack(losses).sum() if losses else torch.zeros((), device=dev)
             if buckets is not None:
                 tot = buckets[0]
@@ -289,24 +361,27 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                 timer.lap("step")
             history.append(float(total))
             rec = {"iter": it, "loss": history[-1], "views": len(cameras)}
-            done = False
-            if success_fn is not None:
-                imgs = render_combined(model, background, mine, bg, pipe)
-                if timer is not None:
-                    timer.lap("rerender")
-                flags = gather_success([success_fn(im, i) for im, i in zip(imgs, my_idx)], len(cameras), rank, world, dev)
-                pgd_attack.last_successes = flags
-                rec["successes"] = flags
-                done = batch_done(flags, len(cameras))
-            if log is not None:
-                if dev.type == "cuda":
-                    torch.cuda.synchronize()
-                rec["seconds"] = time.perf_counter() - t0
-                log(rec)
-            if done:
-                if save_path is not None and rank == 0:
-                    model.save_ply(save_path)
+            if success_fn is None:
+                finish_iteration(rec, None)
+                continue
+            if overlap:
+                # success renders on the side stream, behind the step; the next iteration's first forward goes beside them
+                stepped = torch.cuda.Event()
+                stepped.record(torch.cuda.current_stream(dev))
+                check_stream.wait_event(stepped)
+                with torch.cuda.stream(check_stream):
+                    imgs = render_combined(model, background, mine, bg, pipe)
+                    rendered = torch.cuda.Event()
+                    rendered.record(check_stream)
+                pending = (rec, (imgs, rendered))
+                continue
+            imgs = render_combined(model, background, mine, bg, pipe)
+            if timer is not None:
+                timer.lap("rerender")
+            if finish_iteration(rec, (imgs, None)):
                 break
+        if pending is not None:                            # the last iteration's flags
+            finish_iteration(*pending)
     finally:
         for p in frozen:
             p.requires_grad_(True)

@@ -79,33 +79,10 @@ def test_nyc_pair_lists_are_depth_sorted_per_tile(nyc):
     D, dev, model, cam, gc = nyc
     from gsplat_attack.renderer import PipelineParams, render
     img = render(cam, model, PipelineParams(skip_objects=True), torch.zeros(3, device=dev))["render"]
-    ranges = D.export_state(img, "ranges").view(-1, 2).long()
-    pairs = D.export_state(img, "pair_rank").long()
-    order0 = D.export_state(img, "order").long()           # the V Gaussians that emit pairs, by depth rank
-    inv = torch.full((model.get_xyz.shape[0],), -1, dtype=torch.long, device=dev)
-    inv[order0] = torch.arange(order0.numel(), device=dev)
-    ranks = inv[pairs & ((1 << 28) - 1)]                 # a pair's value is its Gaussian; its depth rank through `order`
-    assert int((pairs >> 28).max()) <= 15
-    lens = ranges[:, 1] - ranges[:, 0]
-    assert int(lens.min()) >= 0 and int(lens.sum()) <= pairs.numel()
-    # inside every tile's range the depth ranks increase strictly (stable tile sort of rank-major emitted pairs)
-    inc = ranks[1:] > ranks[:-1]
-    starts = torch.zeros(pairs.numel(), dtype=torch.bool, device=dev)
-    nz = lens > 0
-    starts[ranges[nz, 0]] = True
-    covered = torch.zeros(pairs.numel() + 1, dtype=torch.long, device=dev)
-    covered.index_add_(0, ranges[nz, 0], torch.ones(int(nz.sum()), dtype=torch.long, device=dev))
-    covered.index_add_(0, ranges[nz, 1], -torch.ones(int(nz.sum()), dtype=torch.long, device=dev))
-    inside = torch.cumsum(covered, 0)[:-1] > 0
-    must = inside[1:] & ~starts[1:]
-    assert bool(inc[must].all())
-    # ranks map to depths in non-decreasing order
-    order = D.export_state(img, "order").long()
-    recs = D.export_state(img, "G").view(-1, 12)
-    d = recs[order, 9]                                       # every ranked Gaussian's record was written
-    assert bool((d[1:] >= d[:-1]).all())
-    assert bool((model_radii(model, cam, dev)[order] > 0).all())
-    assert int(inv[pairs & ((1 << 28) - 1)].min()) >= 0      # every listed Gaussian is a ranked one
+    # inside every tile's span the entries are in (depth key, Gaussian index) order, strictly
+    from util import check_tile_lists_depth_order
+    ranges, g = check_tile_lists_depth_order(D, img)
+    assert bool((model_radii(model, cam, dev)[g] > 0).all())       # every listed Gaussian is a visible one
 
 
 def test_nyc_cull_and_fused_paths_agree_at_full_size(nyc):

@@ -366,7 +366,7 @@ def test_fragile_pixels_land_on_a_float32_or_float64_outcome(scene, kw):
     y = pixel_yardstick(hip, r64.color, r32.color, r64.fragile_px | r32.fragile_px, tol=1e-4)
     print(yardstick_line(scene, y))
     assert y["worst_solid"] <= 1e-4 and y["neither_solid"] == 0
-    assert y["neither_px"] <= max(3, T.NEITHER_CAP * y["fragile"] * y["n"]), yardstick_line(scene, y)
+    assert y["neither_px"] <= max(T.NEITHER_MIN_PX, T.NEITHER_CAP * y["fragile"] * y["n"]), yardstick_line(scene, y)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -416,7 +416,7 @@ def test_one_visible_gaussian_among_culled_ones():
     radii = out["radii"]
     assert int((radii > 0).sum()) == 1 and int(radii[1234]) > 0
     dv = D.export_state(out["render"], "dv")
-    assert int(dv[1]) == 1 and D.export_state(out["render"], "order").tolist() == [1234]
+    assert int(dv[1]) == 1 and set((D.export_state(out["render"], "pair_rank") & ((1 << 28) - 1)).tolist()) == {1234}
     n = D.last_num_rendered(out["render"])
     assert n >= 1 and float((out["render"].detach() - torch.tensor([0.2, 0.4, 0.6], device=dev)[:, None, None]).abs().max()) > 0.01
     out["render"].sum().backward()
@@ -426,9 +426,32 @@ def test_one_visible_gaussian_among_culled_ones():
     assert float(gx.abs().max()) == 0.0
 
 
+def _check_lists_against_stable_argsort(D, out):
+    """Every tile's list == the Gaussians of that tile in the order of a STABLE argsort of the float32 depths of all visible
+    Gaussians (what the reference's one 64-bit (tile | depth) sort of storage-ordered pairs gives), position by position."""
+    from util import check_tile_lists_depth_order
+    img = out["render"]
+    ranges, g = check_tile_lists_depth_order(D, img)
+    depth = D.export_state(img, "G").view(-1, 12)[:, 9]
+    vis = out["radii"] > 0
+    ids = torch.nonzero(vis).flatten()
+    order = ids[torch.argsort(depth[ids], stable=True)]                 # global stable depth order
+    rank = torch.full((vis.numel(),), -1, dtype=torch.long, device=img.device)
+    rank[order] = torch.arange(order.numel(), device=img.device)
+    r = rank[g]
+    assert int(r.min()) >= 0
+    lens = (ranges[:, 1] - ranges[:, 0])
+    tile_of = torch.repeat_interleave(torch.arange(ranges.shape[0], device=img.device), lens)
+    pos = torch.cat([torch.arange(int(a), int(b), device=img.device) for a, b in ranges[lens > 0].tolist()]) if int(lens.sum()) else r[:0]
+    rr = r[pos]
+    same = tile_of[1:] == tile_of[:-1]
+    assert bool((rr[1:] > rr[:-1])[same].all())                         # strictly increasing global rank inside every tile
+    assert int(lens.sum()) > 0
+
+
 def test_depth_range_that_needs_the_widest_digits_sorts_exactly():
-    """View depths from 0.25 to 3e5: max - min of the float keys spans 30+ bits, so the three depth passes use 10/11-bit
-    digits (the benchmark scene: 9).  The order must be the stable argsort of the float32 depth."""
+    """View depths from 0.25 to 3e5: max - min of the float keys of a tile's list spans 30+ bits, so its depth ordering takes
+    all four 8-bit passes (the benchmark scene: three).  The order must be the stable argsort of the float32 depth."""
     D = _hip()
     dev = torch.device("cuda:0")
     P = 40000
@@ -439,15 +462,7 @@ def test_depth_range_that_needs_the_widest_digits_sorts_exactly():
     xyz = torch.cat([xy * z[:, None], z[:, None]], dim=1)
     scale = torch.log(0.01 * z)[:, None].expand(P, 3).contiguous()      # ~1.7 px on screen whatever the depth
     model, cam, out = _raw_render(D, dev, xyz, scale, torch.zeros(P, 1), flags=D.FLAG_NO_CULL)
-    dv = D.export_state(out["render"], "dv")
-    assert int(dv[3]) >= 10, f"digit width {int(dv[3])}"
-    order = D.export_state(out["render"], "order").long()
-    depth = D.export_state(out["render"], "G").view(-1, 12)[:, 9]
-    vis = out["radii"] > 0
-    assert order.numel() == int(vis.sum())
-    ids = torch.nonzero(vis).flatten()
-    want = ids[torch.argsort(depth[ids], stable=True)]
-    assert torch.equal(order, want)
+    _check_lists_against_stable_argsort(D, out)
 
 
 @pytest.mark.parametrize("dist", ["constant", "two-values", "cluster+outliers", "shell-16-buckets", "shell-40-buckets", "narrow",
@@ -485,13 +500,8 @@ def test_depth_order_is_the_stable_argsort_whatever_the_depth_distribution(dist)
     xyz = torch.cat([xy * z[:, None], z[:, None]], dim=1)
     scale = torch.log(0.01 * z)[:, None].expand(P, 3).contiguous()
     model, cam, out = _raw_render(D, dev, xyz, scale, torch.zeros(P, 1), flags=D.FLAG_NO_CULL, grad=False)
-    order = D.export_state(out["render"], "order").long()
-    depth = D.export_state(out["render"], "G").view(-1, 12)[:, 9]
-    vis = out["radii"] > 0
-    assert order.numel() == int(vis.sum()) and order.numel() > P // 2
-    ids = torch.nonzero(vis).flatten()
-    want = ids[torch.argsort(depth[ids], stable=True)]
-    assert torch.equal(order, want)
+    assert int((out["radii"] > 0).sum()) > P // 2
+    _check_lists_against_stable_argsort(D, out)
 
 
 def test_needle_splats_keep_their_geometry_gradients():

@@ -88,3 +88,39 @@ def test_pgd_attack_same_history_with_and_without_streams():
     moved = (m1._xyz - model._xyz).abs().max().item()
     assert moved > 1e-3
     assert (m1._xyz - m3._xyz).abs().max().item() <= 2e-2 * moved
+
+
+@pytest.mark.parametrize("n_views,streams", [(1, 1), (3, 1), (3, 2)])
+def test_overlapped_success_check_equals_the_serial_loop(n_views, streams, tmp_path):
+    """pgd_attack(overlap_success=True): the success re-render of iteration i runs on a side stream beside the forward of
+    iteration i + 1, which is dropped if the batch turns out to be done.  Same iteration count, bit-equal history, flags
+    and parameters as the strictly serial loop -- with a detector that is never fooled, one fooled on iteration 3, and one
+    fooled at once."""
+    from gsplat_attack.attack import pgd_attack
+    dev, model, cams, pipe, bg, _ = _setup(P=8000, W=160, H=128, n_views=n_views)
+    base = model.clone()
+    bg_model = model.clone()
+    for stop_at in (None, 3, 1):
+        runs = []
+        for overlap in (False, True):
+            m = base.clone()
+            calls = []
+
+            def success(im, i, calls=calls):
+                assert torch.isfinite(im).all()
+                calls.append(i)
+                it = (len(calls) - 1) // n_views + 1          # the iteration whose renders these are
+                return stop_at is not None and it >= stop_at
+            recs = []
+            path = str(tmp_path / f"m_{overlap}_{stop_at}.ply")
+            hist = pgd_attack(m, cams, iters=5, groups=("color", "position"), streams=streams, success_fn=success,
+                              background=bg_model, overlap_success=overlap, log=recs.append, save_path=path)
+            torch.cuda.synchronize()
+            runs.append((hist, [r.get("successes") for r in recs], {n: getattr(m, n).detach().clone() for n in
+                                                                      ("_xyz", "_features_dc", "_features_rest")},
+                         len(calls), pgd_attack.last_successes, __import__("os").path.exists(path)))
+        (h0, f0, p0, c0, l0, s0), (h1, f1, p1, c1, l1, s1) = runs
+        assert len(h0) == (5 if stop_at is None else stop_at)
+        assert h0 == h1 and f0 == f1 and c0 == c1 and l0 == l1 and s0 == s1 == (stop_at is not None)
+        for n in p0:
+            assert torch.equal(p0[n], p1[n]), (n, stop_at)

@@ -78,3 +78,30 @@ def yardstick_line(tag, y):
             f"fragile px on neither {y['neither']:.5f} ({y['neither_px']} px, worst {y['worst_neither']:.2e}), solid px on "
             f"neither {y['neither_solid']}, solid err {y['worst_solid']:.2e}, worst err {y['worst_any']:.2e}, "
             f"oracle f32 vs f64 {y['f32_vs_f64']:.2e}")
+
+
+def check_tile_lists_depth_order(D, img):
+    """Every tile's span of the sorted pair list is in (float32 depth key, Gaussian index) order -- strictly: what a stable
+    depth sort of storage-ordered Gaussians in front of a stable tile sort gives.  Returns (ranges, Gaussian ids)."""
+    dev = img.device
+    ranges = D.export_state(img, "ranges").view(-1, 2).long()
+    pairs = D.export_state(img, "pair_rank").long()
+    assert int((pairs >> 28).max() if pairs.numel() else 0) <= 15
+    g = pairs & ((1 << 28) - 1)
+    depth = D.export_state(img, "G").view(-1, 12)[:, 9]
+    key = depth[g]
+    assert bool((key > 0).all())                              # every listed Gaussian has its record (and depth) written
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.min()) >= 0 and int(lens.sum()) <= pairs.numel()
+    nz = lens > 0
+    starts = torch.zeros(pairs.numel() + 1, dtype=torch.bool, device=dev)
+    starts[ranges[nz, 0]] = True
+    covered = torch.zeros(pairs.numel() + 1, dtype=torch.long, device=dev)
+    covered.index_add_(0, ranges[nz, 0], torch.ones(int(nz.sum()), dtype=torch.long, device=dev))
+    covered.index_add_(0, ranges[nz, 1], -torch.ones(int(nz.sum()), dtype=torch.long, device=dev))
+    inside = torch.cumsum(covered, 0)[:-1] > 0
+    if pairs.numel() > 1:
+        inc = (key[1:] > key[:-1]) | ((key[1:] == key[:-1]) & (g[1:] > g[:-1]))
+        must = inside[1:] & inside[:-1] & ~starts[1:-1]
+        assert bool(inc[must].all()), f"{int((~inc[must]).sum())} list neighbours out of (depth, index) order"
+    return ranges, g
