@@ -668,7 +668,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   auto launch_scan = [&](unsigned long long cap, uint32_t* chunk_first, uint32_t chunk_cap) {
     const bool publish = c->slot.host != nullptr && !slot_armed;      // the host slot is written by the FIRST scan only
     hipLaunchKernelGGL(k_storage_scan, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint2*)bout, c->offg,
-                       live, offl, chunk_first, (uint32_t)EMIT_GRAIN, chunk_cap, nbP, c->dv, cap,
+                       live, offl, c->G0 + 3, chunk_first, (uint32_t)EMIT_GRAIN, chunk_cap, nbP, c->dv, cap,
                        publish ? c->slot.dev : (uint32_t*)nullptr, c->slot.token);
     slot_armed = slot_armed || publish;
   };
@@ -775,7 +775,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         ta.ranges = c->ranges; ta.sched = c->sched; ta.dv = c->dv; ta.dkey = dkey; ta.vals = c->pair_rank; ta.ntiles = ntiles;
         static const int huge_blocks = [] { const char* e = getenv("GSR_TDS_HUGE_BLOCKS"); int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();
         hipLaunchKernelGGL(k_tile_depth_sort_huge, dim3((unsigned)std::min(huge_blocks, ntiles)), dim3(64 * TDS_HUGE_WAVES), 0, st, ta);
-        hipLaunchKernelGGL(k_tile_depth_sort, dim3((unsigned)ntiles), dim3(64 * TDS_WAVES), 0, st, ta);
+        hipLaunchKernelGGL(k_tile_depth_sort, dim3((unsigned)std::min(ntiles, TDS_GRID)), dim3(64 * TDS_WAVES), 0, st, ta);
       }
       F_LAUNCH("tile depth sort");
     }

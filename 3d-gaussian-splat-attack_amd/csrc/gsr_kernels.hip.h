@@ -182,7 +182,7 @@ static_assert(SCHUNK % PREG_BLOCK == 0, "a scan chunk covers whole K1 workgroups
 __global__ void __launch_bounds__(256) k_storage_scan(uint32_t P, const uint32_t* __restrict__ tcnt,
                                                       const uint2* __restrict__ bout, uint32_t* __restrict__ offg,
                                                       uint32_t* __restrict__ live, uint32_t* __restrict__ offl,
-                                                      uint32_t* __restrict__ chunk_first, uint32_t chunk_len,
+                                                      float4* __restrict__ G3, uint32_t* __restrict__ chunk_first, uint32_t chunk_len,
                                                       uint32_t chunk_cap, uint32_t nb, uint32_t* __restrict__ dv,
                                                       unsigned long long cap, uint32_t* host_slot, uint32_t host_token) {
   __shared__ uint32_t tmp[4];
@@ -222,6 +222,9 @@ __global__ void __launch_bounds__(256) k_storage_scan(uint32_t P, const uint32_t
     if (v[i] != 0u) {
       live[j] = base + i;
       offl[j] = run;
+      // -DGSR_REC=4 (experiment, round 4): the record's fourth float4 is padding; its first word carries offg[g], so that
+      // the backward compositor's row numbering needs no gather of its own (one 64-byte sector per list entry)
+      if (REC == 4) reinterpret_cast<uint32_t*>(G3 + (size_t)REC * (base + i))[0] = run;
       if (chunk_first && !ovf) {
         // chunk starts c * chunk_len inside [run, run + v): usually none or one
         for (uint32_t c = (run + chunk_len - 1u) / chunk_len;
@@ -857,8 +860,13 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 // K7: backward composite, same tiling, list walked back to front.  Per (tile, entry) the wave reduces
 // nine sums over its 256 pixels and stores ONE 48-byte row at the pair's emission slot: no global
-// atomics, bitwise reproducible.  Row = (Sq dx, Sq dy, Sq dx^2, Sq dx dy, Sq dy^2, S G dL/dalpha,
-// S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha.
+// atomics, bitwise reproducible.  Row = (Mx, My, Sq dx^2, Sq dx dy, Sq dy^2, S G dL/dalpha,
+// S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha and
+// (Mx, My) = -log2(e) S q (A dx + B dy, B dx + C dy): the conic applied to the first moments PER LANE, before any sum --
+// the published backward forms dG/ddx = -G (A dx + B dy) per pixel; summing S q dx and S q dy first and multiplying by
+// the conic afterwards (rounds 1-3) is the same number on paper and loses the cancellation of a needle-shaped splat
+// (A dx ~ -B dy along its axis) to float32 rounding of the two large sums: 6x the float32 oracle's own error on
+// dL/dmean2D of a 1500:1 needle (tests/diag_aniso_elem.py, seed 106).
 // The 64-lane sums are not butterflies (a DPP add issues at half the rate of a plain one and nine values
 // need 9 x 6 of them): the per-lane values are parked in LDS as they are (ds_write does not occupy the VALU;
 // only dg and db are folded into one register so that an entry is 64 chunks of 8 floats), and after every
@@ -1047,7 +1055,8 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
-      sslot[lane] = (a.offg[r] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
+      const uint32_t row0 = REC == 4 ? reinterpret_cast<const uint32_t*>(a.R2 + (size_t)REC * r + 1)[0] : a.offg[r];
+      sslot[lane] = (row0 + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)r * NUM_OBJ);
         float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
@@ -1136,8 +1145,9 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         float* w = &sred[red_n * RENTRY + red_wofs];
         if (GEOM) {
           const float a0 = sq * dx;
-          w[0] = a0;                                     // value 0: S q dx
-          w[RED_REG] = sqy;                              // value 1: S q dy
+          // values 0, 1: the staged conic words are (-log2e/2) A, -log2e B, (-log2e/2) C
+          w[0] = fmaf(e0.w, sqy, 2.f * e0.z * a0);       // -log2e (A S q dx + B S q dy) of this lane's pixels
+          w[RED_REG] = fmaf(e0.w, a0, 2.f * e1.x * sqy); // -log2e (B S q dx + C S q dy)
           w[2 * RED_REG] = a0 * dx;                      // value 2: S q dx^2
           w[3 * RED_REG] = sqy * dx;                     // value 3: S q dx dy
           w[4 * RED_REG] = sqyy;                         // value 4: S q dy^2
@@ -1282,11 +1292,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   }
   View v;
   load_view(v, a.va);
-  const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
-  const float A = e0.z, B = e0.w, C = e1.x;
-  // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
-  const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
-  const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
+  const float4 e1 = a.G1[REC * g], e2 = a.G2[REC * g];
+  // dL/d(pixel centre) = -(A Sq dx + B Sq dy, B Sq dx + C Sq dy) = (mx, my) / log2(e): K7 applied the conic per lane
+  // (row words 0, 1); screen-space means are reported in NDC units
+  const float dndcx = mx * (0.5f / LOG2E) * (float)v.W;
+  const float dndcy = my * (0.5f / LOG2E) * (float)v.H;
   const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
   if (GEOM && a.dmeans2D) { put(&a.dmeans2D[3 * g], dndcx); put(&a.dmeans2D[3 * g + 1], dndcy); put(&a.dmeans2D[3 * g + 2], 0.f); }
   if (GEOM && a.dopac) put(&a.dopac[g], dop);
@@ -1618,7 +1628,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   // (the second moments are summed in double: what they feed -- dL/dconic -> dL/dcov2D -- cancels to first order for an
   // elongated splat, see project_splat_bwd, and amplifies the rounding of a float32 running sum over hundreds of rows)
   float dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-  double mx = 0.0, my = 0.0, mxx = 0.0, mxy = 0.0, myy = 0.0;      // (conic . (mx, my) cancels the same way)
+  double mx = 0.0, my = 0.0, mxx = 0.0, mxy = 0.0, myy = 0.0;      // (mx, my: K7's conic . first moments, residues of a cancellation)
   {
     const uint32_t S = a.offg[gw0] * a.nsub, E = a.offg[gw0 + nw] * a.nsub;
     const bool big = (o1 - o0) > (uint32_t)ROW_CHUNK;
@@ -1706,10 +1716,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       }
       View v;
       load_view(v, a.va);
-      const float A = e0.z, B = e0.w, C = e1.x;
-      // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
-      const float dndcx = (float)(-((double)A * mx + (double)B * my) * (0.5 * (double)v.W));
-      const float dndcy = (float)(-((double)B * mx + (double)C * my) * (0.5 * (double)v.H));
+      // dL/d(pixel centre) = -(A Sq dx + B Sq dy, B Sq dx + C Sq dy) = (mx, my) / log2(e): K7 applied the conic per lane
+      // (row words 0, 1); screen-space means are reported in NDC units
+      const float dndcx = (float)(mx * (0.5 / (double)LOG2E * (double)v.W));
+      const float dndcy = (float)(my * (0.5 / (double)LOG2E * (double)v.H));
       const double dA = -0.5 * mxx, dB = -mxy, dC = -0.5 * myy;
       if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }   // per view
       if (GEOM && a.dopac) put(&a.dopac[g], RAW ? dop * e1.y * (1.f - e1.y) : dop);   // e1.y = sigmoid(raw opacity)

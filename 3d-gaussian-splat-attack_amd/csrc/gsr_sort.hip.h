@@ -79,7 +79,7 @@ enum {
   DV_N = 0,       // number of (tile, Gaussian) pairs the tile sort / compositors see (0 when the capacity overflowed)
   DV_V = 1,       // Gaussians that emit at least one pair
   DV_NHUGE = 2,   // tiles whose list has >= TDS_HUGE_MIN entries (k_tile_schedule; they come first in sched[])
-  DV_NMID = 3,    // tiles with more entries than one wave sorts by itself (includes the huge ones)
+  DV_NMID = 3,    // tiles with more entries than one wave sorts by itself (> TDS_WAVE_CAP; includes the huge ones)
   DV_OVF = 4,     // 1: more pairs than the capacity this forward's buffers and grids were sized for
   DV_NREC = 5,    // boundary records in use (k_tile_schedule)
   DV_N64 = 6,     // words 6,7: exact 64-bit pair count
@@ -167,8 +167,9 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restri
 // Stable ranking of one wave's 64-element rounds by an (at most 8-bit) digit: rnk[j] = number of elements of this wave in
 // front of element (round j, this lane) with the same digit; cnt[d] (this wave's 256 counters in LDS, zero on entry)
 // ends up holding the wave's count of digit d.  `live` bit j: the element takes part.  Ballots, no per-thread counters.
-template <int ROUNDS>
-__device__ __forceinline__ void wave_rank_rounds(const uint32_t (&dig)[ROUNDS], uint32_t live, int nrounds,
+// digit_of(j): the digit of element (round j, this lane).
+template <int ROUNDS, class DigitOf>
+__device__ __forceinline__ void wave_rank_rounds(DigitOf digit_of, uint32_t live, int nrounds,
                                                  volatile uint32_t* cnt, uint32_t (&rnk)[ROUNDS]) {
   const int lane = threadIdx.x & 63;
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -176,7 +177,7 @@ __device__ __forceinline__ void wave_rank_rounds(const uint32_t (&dig)[ROUNDS], 
   for (int j = 0; j < ROUNDS; ++j) {
     if (j < nrounds) {                               // wave-uniform
       const bool keep = (live >> j) & 1u;
-      const uint32_t d = dig[j];
+      const uint32_t d = digit_of(j);
       uint64_t peers = __ballot(keep);
       // all eight bits a digit can have, unrolled (bits at and above the digit's width are 0 in every lane and leave
       // `peers` as it is): a loop over the actual width costs more than the idle ballots
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
   const uint32_t base = blk0 + wv * (RS_ROUNDS * 64);
   // keys and values are requested before the live count is known (one memory round trip instead of two); positions
   // below the host-side bound n are always readable
-  uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rnk[RS_ROUNDS], dig[RS_ROUNDS];
+  uint32_t key[RS_ROUNDS], val[RS_ROUNDS], rnk[RS_ROUNDS];
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const uint32_t idx = base + j * 64 + lane;
@@ -244,9 +245,8 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     live |= (base + j * 64 + lane < n ? 1u : 0u) << j;
-    dig[j] = (key[j] >> shift) & mask;
   }
-  wave_rank_rounds<RS_ROUNDS>(dig, live, RS_ROUNDS, wcnt[wv], rnk);
+  wave_rank_rounds<RS_ROUNDS>([&](int j) { return (key[j] >> shift) & mask; }, live, RS_ROUNDS, wcnt[wv], rnk);
   __syncthreads();
   uint32_t nvalid;
   {
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     if ((live >> j) & 1u) {
-      const uint32_t p = wcnt[wv][dig[j]] + rnk[j];
+      const uint32_t p = wcnt[wv][(key[j] >> shift) & mask] + rnk[j];
       skey[p] = key[j];
       sval[p] = val[j];
     }

@@ -12,10 +12,12 @@
 // the composite order: LSD counting passes of 8 bits over (key - min key of the list), as many as the list's key range
 // needs (three on the benchmark scene), ranked with wave ballots like the global passes (gsr_sort.hip.h).  Keys and
 // values stay in registers between passes; LDS holds one scatter image (8 bytes per entry) and the digit counters.
-//   * lists of up to 1024 entries: ONE WAVE, no workgroup barrier (four such lists per 256-thread workgroup);
-//   * up to 4094: the four waves of a workgroup together;
-//   * up to 16384: a 1024-thread workgroup (k_tile_depth_sort_huge: a thin persistent grid that exits at once when
-//     k_tile_schedule counted no such tile);
+//   * lists of up to 512 entries (eight 64-element rounds per lane): ONE WAVE, no workgroup barrier (eight such lists per
+//     512-thread workgroup);
+//   * up to 4094: the eight waves of a workgroup together (same registers per lane, so the two modes share one kernel
+//     at eight waves per SIMD);
+//   * up to 16384: a 1024-thread workgroup with sixteen rounds per lane (k_tile_depth_sort_huge: a thin persistent grid
+//     that exits at once when k_tile_schedule counted no such tile);
 //   * beyond: a bitonic network over (depth key, index) in global memory by that workgroup -- slow, correct at any
 //     length (such a tile takes milliseconds to composite anyway).
 #pragma once
@@ -26,12 +28,19 @@
 
 namespace gsr {
 
-constexpr int TDS_ROUNDS = 16;                          // 64-element rounds per wave
-constexpr int TDS_WAVE_CAP = TDS_ROUNDS * 64;           // 1024: one wave sorts a list of this length by itself
-constexpr int TDS_WAVES = 4;
+constexpr int TDS_ROUNDS = 8;                           // 64-element rounds per wave
+constexpr int TDS_WAVE_CAP = TDS_ROUNDS * 64;           // 512: one wave sorts a list of this length by itself
+constexpr int TDS_WAVES = 8;
 constexpr int TDS_BLOCK_CAP = TDS_WAVES * TDS_WAVE_CAP; // 4096
 constexpr int TDS_HUGE_WAVES = 16;
-constexpr int TDS_HUGE_CAP = TDS_HUGE_WAVES * TDS_WAVE_CAP;   // 16384
+constexpr int TDS_HUGE_ROUNDS = 16;
+constexpr int TDS_HUGE_CAP = TDS_HUGE_WAVES * TDS_HUGE_ROUNDS * 64;   // 16384
+// Waves per SIMD the kernel is compiled for: 6 (80 registers, a dozen spilled to scratch; three 512-thread workgroups per
+// CU, the LDS limit) or 4 (no spills, two workgroups per CU).  -DGSR_TDS_OCC=4 builds the other one for an A/B.
+#ifndef GSR_TDS_OCC
+#define GSR_TDS_OCC 6
+#endif
+constexpr int TDS_GRID = 256 * (GSR_TDS_OCC * 4 / TDS_WAVES);   // persistent workgroups of k_tile_depth_sort: all co-resident
 constexpr uint32_t TDS_HUGE_MIN = 4095u;                // = the schedule's last (clamped) length bin: see k_tile_schedule
 constexpr uint32_t TDS_RANK_MASK = (1u << 28) - 1u;     // a pair's value = Gaussian | strip mask << 28
 
@@ -55,22 +64,22 @@ __device__ __forceinline__ void tds_sync() {
   }
 }
 
-// Sorts vals[0 .. len) (global memory, len <= WAVES * TDS_WAVE_CAP) by (dkey[val & mask], position).  Called by all
+// Sorts vals[0 .. len) (global memory, len <= WAVES * ROUNDS * 64) by (dkey[val & mask], position).  Called by all
 // WAVES waves of a group (a wave, or the whole workgroup): `wv` = this wave's index in the group, `gtid` = this thread's.
-// s_key / s_val: WAVES * TDS_WAVE_CAP words each; s_cnt: WAVES * 256 words; s_red: 2 * WAVES + 2 words.
-template <int WAVES>
+// s_key / s_val: WAVES * ROUNDS * 64 words each; s_cnt: WAVES * 256 words; s_red: 2 * WAVES + 4 words.
+template <int WAVES, int ROUNDS>
 __device__ __forceinline__ void tile_list_sort(uint32_t* __restrict__ vals, const uint32_t len,
                                                const uint32_t* __restrict__ dkey, uint32_t* s_key, uint32_t* s_val,
                                                uint32_t* s_cnt, uint32_t* s_red, const int wv, const int gtid) {
   const int lane = gtid & 63;
   // every wave owns a contiguous run of positions (whole rounds): position p = first + 64 j + lane
   const uint32_t per_wave = ((len + WAVES * 64u - 1u) / (WAVES * 64u)) * 64u;
-  const int nrounds = (int)(per_wave >> 6);                               // <= TDS_ROUNDS, the same for every wave
+  const int nrounds = (int)(per_wave >> 6);                               // <= ROUNDS, the same for every wave
   const uint32_t first = (uint32_t)wv * per_wave;
-  uint32_t key[TDS_ROUNDS], val[TDS_ROUNDS], rnk[TDS_ROUNDS], dig[TDS_ROUNDS];
+  uint32_t key[ROUNDS], val[ROUNDS], rnk[ROUNDS];
   uint32_t live = 0, mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
-  for (int j = 0; j < TDS_ROUNDS; ++j) {
+  for (int j = 0; j < ROUNDS; ++j) {
     key[j] = 0u; val[j] = 0u;
     if (j < nrounds) {
       const uint32_t p = first + 64u * j + lane;
@@ -81,7 +90,7 @@ __device__ __forceinline__ void tile_list_sort(uint32_t* __restrict__ vals, cons
     }
   }
 #pragma unroll
-  for (int j = 0; j < TDS_ROUNDS; ++j) {
+  for (int j = 0; j < ROUNDS; ++j) {
     if ((live >> j) & 1u) {
       key[j] = dkey[val[j] & TDS_RANK_MASK];
       mn = min(mn, key[j]); mx = max(mx, key[j]);
@@ -107,10 +116,8 @@ __device__ __forceinline__ void tile_list_sort(uint32_t* __restrict__ vals, cons
     // ---- this wave's digit counters, then the stable rank of every element among the wave's equal digits -------------
 #pragma unroll
     for (int i = 0; i < 4; ++i) myc[lane + 64 * i] = 0u;
-#pragma unroll
-    for (int j = 0; j < TDS_ROUNDS; ++j) dig[j] = ((key[j] - mn) >> shift) & 255u;
     __builtin_amdgcn_wave_barrier();
-    wave_rank_rounds<TDS_ROUNDS>(dig, live, nrounds, myc, rnk);
+    wave_rank_rounds<ROUNDS>([&](int j) { return ((key[j] - mn) >> shift) & 255u; }, live, nrounds, myc, rnk);
     tds_sync<WAVES>();
     // ---- counters -> start of (digit, wave) in the sorted list ---------------------------------------------------------
     if (WAVES == 1) {
@@ -144,16 +151,16 @@ __device__ __forceinline__ void tile_list_sort(uint32_t* __restrict__ vals, cons
     tds_sync<WAVES>();
     // ---- scatter into the LDS image, read back in position order -------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < TDS_ROUNDS; ++j) {
+    for (int j = 0; j < ROUNDS; ++j) {
       if ((live >> j) & 1u) {
-        const uint32_t p = myc[dig[j]] + rnk[j];
+        const uint32_t p = myc[((key[j] - mn) >> shift) & 255u] + rnk[j];
         s_key[p] = key[j];
         s_val[p] = val[j];
       }
     }
     tds_sync<WAVES>();
 #pragma unroll
-    for (int j = 0; j < TDS_ROUNDS; ++j) {
+    for (int j = 0; j < ROUNDS; ++j) {
       if ((live >> j) & 1u) {
         const uint32_t p = first + 64u * j + lane;
         key[j] = s_key[p];
@@ -163,36 +170,45 @@ __device__ __forceinline__ void tile_list_sort(uint32_t* __restrict__ vals, cons
     tds_sync<WAVES>();                                   // the image and the counters are rewritten by the next pass
   }
 #pragma unroll
-  for (int j = 0; j < TDS_ROUNDS; ++j) {
+  for (int j = 0; j < ROUNDS; ++j) {
     if ((live >> j) & 1u) vals[first + 64u * j + lane] = val[j];
   }
 }
 
-// Work items in schedule order (longest list first).  Item i < n_mid: the workgroup's four waves sort tile sched[i]
-// together (the huge ones among them are skipped here: k_tile_depth_sort_huge).  Items behind: four tiles per
-// workgroup, one per wave.  The grid covers the worst case (ntiles items); surplus workgroups exit.
-__global__ void __launch_bounds__(64 * TDS_WAVES) k_tile_depth_sort(TileSortArgs a) {
+// Work items in schedule order (longest list first).  Item i < n_mid: the workgroup's eight waves sort tile sched[i]
+// together (the huge ones among them are skipped here: k_tile_depth_sort_huge).  Items behind: eight tiles per item, one
+// per wave.  A persistent grid (TDS_GRID workgroups, four per CU) loops over the items: no dispatch of thousands of
+// workgroups that find nothing to do, and the long lists start first.
+__global__ void __launch_bounds__(64 * TDS_WAVES, GSR_TDS_OCC) k_tile_depth_sort(TileSortArgs a) {
   __shared__ uint32_t s_key[TDS_BLOCK_CAP];
   __shared__ uint32_t s_val[TDS_BLOCK_CAP];
   __shared__ uint32_t s_cnt[TDS_WAVES * 256];
   __shared__ uint32_t s_red[2 * TDS_WAVES + 4];
-  const uint32_t n_mid = min(a.dv[DV_NMID], (uint32_t)a.ntiles), n_huge = min(a.dv[DV_NHUGE], n_mid);
-  const uint32_t b = blockIdx.x;
+  const uint32_t ntiles = (uint32_t)a.ntiles;
+  const uint32_t n_mid = min(a.dv[DV_NMID], ntiles), n_huge = min(a.dv[DV_NHUGE], n_mid);
+  const uint32_t n_items = n_mid + (ntiles - n_mid + TDS_WAVES - 1u) / TDS_WAVES;
   const int wv = (int)(threadIdx.x >> 6);
-  if (b < n_mid) {
-    if (b < n_huge) return;
-    const uint32_t tile = a.sched[b] & TDS_RANK_MASK;
-    const uint2 rg = a.ranges[tile];
-    tile_list_sort<TDS_WAVES>(a.vals + rg.x, rg.y - rg.x, a.dkey, s_key, s_val, s_cnt, s_red, wv, (int)threadIdx.x);
-  } else {
-    const uint32_t i = n_mid + (b - n_mid) * TDS_WAVES + (uint32_t)wv;
-    if (i >= (uint32_t)a.ntiles) return;
-    const uint32_t tile = a.sched[i] & TDS_RANK_MASK;
-    const uint2 rg = a.ranges[tile];
-    const uint32_t len = rg.y - rg.x;
-    if (len < 2u) return;
-    tile_list_sort<1>(a.vals + rg.x, len, a.dkey, s_key + TDS_WAVE_CAP * wv, s_val + TDS_WAVE_CAP * wv, s_cnt + 256 * wv,
-                      s_red, 0, (int)(threadIdx.x & 63));
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    if (it < n_mid) {
+      if (it >= n_huge) {
+        const uint32_t tile = a.sched[it] & TDS_RANK_MASK;
+        const uint2 rg = a.ranges[tile];
+        tile_list_sort<TDS_WAVES, TDS_ROUNDS>(a.vals + rg.x, rg.y - rg.x, a.dkey, s_key, s_val, s_cnt, s_red, wv, (int)threadIdx.x);
+      }
+      __syncthreads();                                   // the LDS image is reused by this workgroup's next item
+    } else {
+      const uint32_t i = n_mid + (it - n_mid) * TDS_WAVES + (uint32_t)wv;
+      if (i < ntiles) {
+        const uint32_t tile = a.sched[i] & TDS_RANK_MASK;
+        const uint2 rg = a.ranges[tile];
+        const uint32_t len = rg.y - rg.x;
+        if (len >= 2u)
+          tile_list_sort<1, TDS_ROUNDS>(a.vals + rg.x, len, a.dkey, s_key + TDS_WAVE_CAP * wv, s_val + TDS_WAVE_CAP * wv,
+                                        s_cnt + 256 * wv, s_red, 0, (int)(threadIdx.x & 63));
+      }
+      // (a wave-mode item touches only this wave's slices of the image: a workgroup barrier is needed only where a
+      // block-mode item follows, and those all come first in the loop)
+    }
   }
 }
 
@@ -219,7 +235,7 @@ __global__ void __launch_bounds__(64 * TDS_HUGE_WAVES) k_tile_depth_sort_huge(Ti
     const uint32_t len = rg.y - rg.x;
     uint32_t* v = a.vals + rg.x;
     if (len <= (uint32_t)TDS_HUGE_CAP) {
-      tile_list_sort<TDS_HUGE_WAVES>(v, len, a.dkey, s_key, s_val, s_cnt, s_red, wv, (int)threadIdx.x);
+      tile_list_sort<TDS_HUGE_WAVES, TDS_HUGE_ROUNDS>(v, len, a.dkey, s_key, s_val, s_cnt, s_red, wv, (int)threadIdx.x);
       __syncthreads();                                   // the LDS image is reused by the next tile of this workgroup
       continue;
     }

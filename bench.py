@@ -46,7 +46,22 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "r03_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r03.sh)
+PMC_FILE = "r04_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r04.sh)
+
+
+def sources_digest() -> str:
+    """SHA-256 over the library's sources (csrc/*, include/gsraster.h).  profiles/collect_r04.sh stores it next to the PMC
+    counters it collects; a bench line quotes those counters as `roofline.traffic` only while the digest still matches --
+    a kernel change silently keeping the old traffic figure was possible before."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "3d-gaussian-splat-attack_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "gsraster.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def log(msg: str) -> None:
@@ -458,10 +473,15 @@ def main():
         # were taken on this very workload
         traffic = None
         valu = None
+        traffic_note = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            if pmc.get("sources_sha256") != sources_digest():
+                traffic_note = (f"profiles/{PMC_FILE} was collected from other kernel sources than this build's (digest "
+                                "mismatch): not quoted; run profiles/collect_r04.sh again")
+                raise LookupError(traffic_note)
             kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2, 1>",
-                    "preprocess_bwd": "void gsr::k_pre_bwd<true, true>",
+                    "preprocess_bwd": "void gsr::k_pre_bwd<true, true, false>",
                     "preprocess": "void gsr::k_pre_color<true>"}.get(dom)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
@@ -472,8 +492,10 @@ def main():
                     valu = {"bound": "fp32 VALU issue", "wave_instr_per_launch": round(n_valu),
                             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                             "frac": round(ach / peak, 4), "launch_ms": per[dom]["avg_ms"]}
-        except Exception:
+        except Exception as e:                             # noqa: BLE001
             traffic = None
+            valu = None
+            traffic_note = traffic_note or f"profiles/{PMC_FILE}: {type(e).__name__}"
         B_total = 304 * P + 548 * V + 116 * N + 40 * HW
         views_per_step = world * B
         t_view = med / (args.steps * B)
@@ -513,7 +535,7 @@ def main():
                                       + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": None if traffic is None else
+                         "traffic_source": traffic_note if traffic is None else
                          f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
                          "this workload (not measured inside this run; FETCH_SIZE doubled per MI355X_MICROARCH.md)",
                          "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,

@@ -227,7 +227,7 @@ int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
  * order = (depth key, Gaussian index) inside a tile), 2 = n_contrib [H*W] u32, 3 = final_T [H*W] f32, (4, 5: the global
  * depth order of rounds 1-3 -- gone, GSR_ERR_INVALID), 7 (and, for old callers, 6) = splat records [P][3] float4 in
  * storage order (layout: csrc/gsr_kernels.hip.h; written for Gaussians that emit pairs), 8 = the forward's device-side
- * scalars [16] u32 (0 pairs, 1 V = Gaussians that emit pairs, 2 tiles with >= 4095 list entries, 3 tiles with > 1024,
+ * scalars [16] u32 (0 pairs, 1 V = Gaussians that emit pairs, 2 tiles with >= 4095 list entries, 3 tiles with > 512,
  * 4 overflow flag, 5 boundary records, 6-7 64-bit pair count), 9 = offg [P+1] u32 (storage-order scan of tiles touched:
  * numbers the emitted pairs and the backward's partial rows). */
 int gsr_ctx_export(const GsrCtx* ctx, int32_t what, void* dst, int64_t dst_bytes, void* stream);

@@ -150,10 +150,13 @@ def check(inp, cam, bg, sh_degree=3, scale_modifier=1.0, with_gobj=False, seed=9
         report[k] = (norm, frac)
         if rg32 is not None:
             n32, f32 = grad_error(rg32[k], gr, elem_tol=5 * GRAD_TOL)
-            report[k] = (norm, frac, n32, f32)
+            # element by element: off = more than 5e-3 relative AND more than twice the float32 oracle's error there
+            _, frac_y = grad_error(grads[k], gr, elem_tol=5 * GRAD_TOL, yard=rg32[k])
+            report[k] = (norm, frac, n32, f32, frac_y)
             # held to the float32 yardstick: no worse than twice what float32 arithmetic costs the oracle itself
             assert norm <= max(GRAD_TOL, 2 * n32), f"grad {k}: normwise rel err {norm:.3e} (float32 oracle {n32:.3e})"
-            assert frac <= max(elem_frac, 2 * f32), f"grad {k}: {frac:.2e} of the significant elements off (float32 oracle {f32:.2e})"
+            assert frac_y <= elem_frac, (f"grad {k}: {frac_y:.2e} of the significant elements off by more than {5 * GRAD_TOL} and "
+                                         f"more than twice the float32 oracle's own error ({frac:.2e} without the yardstick)")
             continue
         assert norm <= GRAD_TOL, f"grad {k}: normwise rel err {norm:.3e}"
         assert frac <= elem_frac, f"grad {k}: {frac:.2e} of the significant elements are off by more than {5 * GRAD_TOL}"

@@ -23,9 +23,12 @@ def model_inputs(model, with_objs=True):
     return d
 
 
-def grad_error(g, ref, elem_tol=5e-3):
+def grad_error(g, ref, elem_tol=5e-3, yard=None):
     """(normwise max error / max|ref|,  fraction of significant elements whose relative error exceeds
-    elem_tol).  Significant = within 3 decades of the group's largest magnitude."""
+    elem_tol).  Significant = within 3 decades of the group's largest magnitude.
+    yard: the same gradient from the float32 oracle.  An element then counts as off only if its error also exceeds TWICE
+    the float32 oracle's own error on that element (the per-element form of the float32 yardstick: a component that is
+    the residue of a cancellation is as wrong in the oracle's float32 run as in any float32 implementation)."""
     g = g.detach().double().cpu().reshape(-1)
     ref = ref.detach().double().cpu().reshape(-1)
     scale = ref.abs().max().item()
@@ -34,7 +37,10 @@ def grad_error(g, ref, elem_tol=5e-3):
     err = (g - ref).abs()
     norm = (err.max() / scale).item()
     big = ref.abs() > 1e-3 * scale
-    frac = ((err[big] / ref.abs()[big]) > elem_tol).double().mean().item() if big.any() else 0.0
+    off = (err / ref.abs().clamp_min(1e-300)) > elem_tol
+    if yard is not None:
+        off = off & (err > 2.0 * (yard.detach().double().cpu().reshape(-1) - ref).abs())
+    frac = off[big].double().mean().item() if big.any() else 0.0
     return norm, frac
 
 
