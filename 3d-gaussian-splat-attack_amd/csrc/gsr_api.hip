@@ -600,6 +600,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const dim3 blkPre(PREG_BLOCK), gridPre(nk1), blkCol(PREF_BLOCK), gridCol(nkc);
   const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
   // K1's colour half: on the side stream unless the caller turned that off (GSR_FLAG_NO_SIDE_STREAM / GSR_SIDE_STREAM=0).
+  // GSR_FORK_AT (experiment): where the side stream forks off -- 0 behind the geometry half (default), 1 behind the
+  // emission, 2 behind the tile sort.
+  static const int fork_at = [] { const char* e = getenv("GSR_FORK_AT"); int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
+  bool want_color = false;
   PreArgs color_pa{};
   auto launch_color = [&]() -> int {
     static const int side_env = [] { const char* e = getenv("GSR_SIDE_STREAM"); return e ? atoi(e) : 1; }();
@@ -642,7 +646,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
       else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
       color_pa = pa;
-      if (!colors_precomp) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
+      want_color = !colors_precomp;
+      if (want_color && fork_at == 0) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
     } else
       hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, cull, means3D, scales, rotations, cov3D_precomp,
                          opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
@@ -722,6 +727,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                              (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
         F_LAUNCH("emit");
       }
+      if (want_color && fork_at == 1) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
       int res;
       {
         StageTimer t(GSR_STAGE_TILE_SORT, st);
@@ -729,6 +735,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                                reinterpret_cast<uint32_t*>(c->ranges), (uint32_t)ntiles);
         F_LAUNCH("tile sort");
       }
+      if (want_color) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
       c->pair_rank = res ? rankB : rankA;
       c->rank_blk = res ? pairs_blk[3] : pairs_blk[1];
       pool_free(dev, tbl_blk);
@@ -779,6 +786,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       }
       F_LAUNCH("tile depth sort");
     }
+    if (want_color) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }   // (no pairs at all)
     if (side_used) F_TRY("side stream", hipStreamWaitEvent(st, side.join, 0));   // the colours are in place from here on
     StageTimer t(GSR_STAGE_RENDER_FWD, st);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
