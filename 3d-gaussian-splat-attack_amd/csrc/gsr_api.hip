@@ -23,7 +23,6 @@
 #include "../../include/gsraster.h"
 #include "gsr_kernels.hip.h"
 #include "gsr_sort.hip.h"
-#include "gsr_tilesort.hip.h"
 #include "gsr_knn.hip.h"
 #include "gsr_pgd.hip.h"
 
@@ -245,8 +244,8 @@ bool slot_wait(const CountSlot& s, hipStream_t st) {
   return true;
 }
 
-// Pair counts seen by earlier forwards, per (device, P, H, W): the capacity a later forward of that size is enqueued
-// against before its own count is known (forward_impl).
+// Pair counts seen by earlier forwards, per (device, P, H, W): the capacity guess of an asynchronous-count forward
+// (GSR_FLAG_ASYNC_COUNT).  An entry is dropped when a forward overflowed its guess, so the next one counts synchronously.
 struct CapKey { int dev, P, H, W; };
 struct CapEntry { CapKey k; unsigned long long n; };
 std::mutex g_cap_mu;
@@ -259,17 +258,20 @@ bool cap_lookup(const CapKey& k, unsigned long long& n) {
   return false;
 }
 
-void cap_store(const CapKey& k, unsigned long long n) {
+void cap_store(const CapKey& k, unsigned long long n, bool erase) {
   std::lock_guard<std::mutex> lk(g_cap_mu);
   for (size_t i = 0; i < g_caps.size(); ++i) {
     const CapKey& q = g_caps[i].k;
     if (q.dev == k.dev && q.P == k.P && q.H == k.H && q.W == k.W) {
-      g_caps[i].n = std::max(g_caps[i].n, n);           // the largest view of this size so far: cameras of one scene differ
+      if (erase) { g_caps[i] = g_caps.back(); g_caps.pop_back(); }
+      else g_caps[i].n = n;
       return;
     }
   }
-  if (g_caps.size() >= 256) g_caps.clear();
-  g_caps.push_back(CapEntry{k, n});
+  if (!erase) {
+    if (g_caps.size() >= 256) g_caps.clear();
+    g_caps.push_back(CapEntry{k, n});
+  }
 }
 
 // Side stream of a caller stream: K1's colour half (SH -> RGB, the bulk of K1's bytes) runs there, beside the binning
@@ -312,7 +314,7 @@ void pending_harvest() {
     PendingSlot& ps = g_pending[i];
     if (slot_landed(ps.slot)) {
       const unsigned long long n = (unsigned long long)ps.slot.host[HS_N64] | ((unsigned long long)ps.slot.host[HS_N64 + 1] << 32);
-      cap_store(ps.key, n);
+      cap_store(ps.key, n, ps.slot.host[HS_OVF] != 0u);
       slot_put(ps.slot);
       g_pending[i] = g_pending.back();
       g_pending.pop_back();
@@ -393,7 +395,7 @@ struct GsrCtx {
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // splat records, storage order (the compositors gather them)
   float* D = nullptr;             // [P,9] d rgb / d view direction (lane-group kernels, SH input, backward expected)
   bool lanegroup = false;         // K1 ran as k_pre_geom + k_pre_color: K8+K9 runs as k_pre_bwd
-  uint32_t *offg = nullptr, *pair_rank = nullptr;
+  uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
   uint32_t* sched = nullptr;      // [ntiles] tiles longest-list-first + priority class
   float* final_T = nullptr;
@@ -409,7 +411,7 @@ static int ctx_resolve_count(GsrCtx* c) {
   c->overflow = c->slot.host[HS_OVF] != 0u;
   c->n_known = true;
   const CapKey key{c->dev, c->P, c->st.image_height, c->st.image_width};
-  cap_store(key, c->n64);
+  cap_store(key, c->n64, c->overflow);
   slot_put(c->slot);
   return GSR_OK;
 }
@@ -514,24 +516,23 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
 
   const size_t Pp = (size_t)std::max(P, 1);
   pending_harvest();
-  // Pair capacity.  The pair count N is a device-side result of the storage scan; the host needs a bound on it to size the
-  // pair buffers and the grids behind it.  When an earlier forward of the same (P, H, W) on this device has left a count
-  // behind, this forward is enqueued WHOLE against that count + 25 % and the host looks at the real count afterwards --
-  // it has long landed by then; should it exceed the capacity (the kernels saw N = 0 and the overflow flag and did
-  // nothing), everything behind the scan is enqueued again with the exact count.  Without such an entry the scan runs
-  // first, the host waits for the count, and the rest follows.  GSR_FLAG_ASYNC_COUNT (or GSR_ASYNC_COUNT=1): the host
-  // never looks; an overflow leaves a NaN image and an error from backward.
+  // Asynchronous pair count (GSR_FLAG_ASYNC_COUNT, or GSR_ASYNC_COUNT=1 in the environment): the host does not wait
+  // for the pair count; buffers and grids are sized from the count an earlier forward of the same (P, H, W) saw, with
+  // head-room.  Without such an entry this forward counts synchronously (and leaves the entry behind).
   static const int async_env = [] { const char* e = getenv("GSR_ASYNC_COUNT"); return e ? atoi(e) : 0; }();
-  static const int spec_env = [] { const char* e = getenv("GSR_SPECULATE"); return e ? atoi(e) : 1; }();
-  const CapKey cap_key{dev, P, H, W};
-  unsigned long long seen = 0;
-  const bool have_cap = P > 0 && cap_lookup(cap_key, seen);
-  const bool async_count = have_cap && (async_env != 0 || (s->flags & GSR_FLAG_ASYNC_COUNT));
-  const bool speculate = have_cap && (async_count || spec_env != 0);
+  unsigned long long cap_pairs = MAX_PAIRS - 1;
+  bool async_count = false;
+  if (P > 0 && (async_env != 0 || (s->flags & GSR_FLAG_ASYNC_COUNT))) {
+    unsigned long long seen = 0;
+    if (cap_lookup(CapKey{dev, P, H, W}, seen)) {
+      cap_pairs = std::min<unsigned long long>(seen + seen / 4 + 65536ull, MAX_PAIRS - 1);
+      async_count = true;
+    }
+  }
   // ---- kept slab ---------------------------------------------------------------------------
   SlabPlan kp;
   kp.add<float4>(REC * Pp);   // G records (storage order)
-  kp.add<uint32_t>(Pp + 1);   // offg
+  kp.add<uint32_t>(Pp); kp.add<uint32_t>(Pp + 1); kp.add<uint32_t>(Pp + 1);   // order, off, offg
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<uint32_t>(DV_WORDS); kp.add<uint32_t>(ntiles);
   // the SH layouts the reference uses (and precomputed colours) take the lane-group kernels
   c->lanegroup = raw || (shs && K == 16) || colors_precomp != nullptr;
@@ -540,12 +541,13 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
-  const uint32_t nbP = (uint32_t)((Pp + SCHUNK - 1) / SCHUNK);             // chunks of the storage scan
+  const uint32_t nbP = (uint32_t)((Pp + DCHUNK - 1) / DCHUNK);             // chunks of the storage scan / depth sort
   const uint32_t nk1 = (uint32_t)((Pp + PREG_BLOCK - 1) / PREG_BLOCK);     // workgroups of K1's geometry half
   const uint32_t nkc = (uint32_t)((Pp + PREF_BLOCK - 1) / PREF_BLOCK);     // ... of its colour half
   SlabPlan sp;
-  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp + 1);   // dkey, tcnt, live, offl
-  sp.add<uint2>(nk1);
+  sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey, k1, vtmp, v2, tcnt
+  sp.add<uint32_t>((size_t)RS_BINS_DEV * nbP); sp.add<uint32_t>(RS_BINS_DEV);
+  sp.add<uint4>(nk1); sp.add<uint32_t>(nbP + 2);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
     pool_free(dev, scratch_blk);
@@ -554,28 +556,23 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   }
   Slab ks{static_cast<char*>(c->keep_blk), c->keep_bytes, 0};
   c->G0 = ks.take<float4>(REC * Pp); c->G1 = c->G0 + 1; c->G2 = c->G0 + 2;   // interleaved records, REC float4 apart
-  c->offg = ks.take<uint32_t>(Pp + 1);
+  c->order = ks.take<uint32_t>(Pp); c->off = ks.take<uint32_t>(Pp + 1); c->offg = ks.take<uint32_t>(Pp + 1);
   c->ranges = ks.take<uint2>(ntiles); c->final_T = ks.take<float>(HW); c->n_contrib = ks.take<uint32_t>(HW);
   c->dv = ks.take<uint32_t>(DV_WORDS);
   c->sched = ks.take<uint32_t>(ntiles);
   if (want_D) c->D = ks.take<float>(9 * Pp);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
-  uint32_t* dkey = ss.take<uint32_t>(Pp); uint32_t* tcnt = ss.take<uint32_t>(Pp);
-  uint32_t* live = ss.take<uint32_t>(Pp); uint32_t* offl = ss.take<uint32_t>(Pp + 1);
-  uint2* bout = ss.take<uint2>(nk1);
+  uint32_t* dkey = ss.take<uint32_t>(Pp); uint32_t* k1 = ss.take<uint32_t>(Pp); uint32_t* vtmp = ss.take<uint32_t>(Pp);
+  uint32_t* v2 = ss.take<uint32_t>(Pp); uint32_t* tcnt = ss.take<uint32_t>(Pp);
+  uint32_t* table = ss.take<uint32_t>((size_t)RS_BINS_DEV * nbP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS_DEV);
+  uint4* bout = ss.take<uint4>(nk1);
+  uint32_t* psums = ss.take<uint32_t>(nbP + 2);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
   void* tbl_blk = nullptr;
   SideStream side{};
   bool side_used = false;
-  auto drop_pass = [&]() {          // the pair-proportional buffers of one enqueued pass (stream-ordered reuse: safe)
-    pool_free(dev, tbl_blk);
-    tbl_blk = nullptr;
-    for (void*& b : pairs_blk) { if (b && b != c->rank_blk) pool_free(dev, b); b = nullptr; }
-    pool_free(dev, c->rank_blk); c->rank_blk = nullptr; c->pair_rank = nullptr;
-    pool_free(dev, c->seg_blk); c->seg_blk = nullptr; c->bnd = nullptr; c->segoff = nullptr; c->rec_item = nullptr;
-  };
   auto fail = [&](int code) {
     if (side_used) (void)hipStreamWaitEvent(st, side.join, 0);   // nothing of this forward may outlive its workspace
     pool_free(dev, scratch_blk);
@@ -599,12 +596,12 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const dim3 blk(256);
   const dim3 blkPre(PREG_BLOCK), gridPre(nk1), blkCol(PREF_BLOCK), gridCol(nkc);
   const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
+  uint32_t nbound = 0;
   // K1's colour half: on the side stream unless the caller turned that off (GSR_FLAG_NO_SIDE_STREAM / GSR_SIDE_STREAM=0).
-  // GSR_FORK_AT (experiment): where the side stream forks off -- 0 behind the geometry half (default), 1 behind the
-  // emission, 2 behind the tile sort.
-  static const int fork_at = [] { const char* e = getenv("GSR_FORK_AT"); int v = e ? atoi(e) : 0; return (v >= 0 && v <= 2) ? v : 0; }();
-  bool want_color = false;
+  // GSR_FORK_LATE=1 (experiment) starts it behind the depth sort instead of behind the geometry half.
   PreArgs color_pa{};
+  bool want_color = false;
+  static const int fork_late = [] { const char* e = getenv("GSR_FORK_LATE"); return e ? atoi(e) : 0; }();
   auto launch_color = [&]() -> int {
     static const int side_env = [] { const char* e = getenv("GSR_SIDE_STREAM"); return e ? atoi(e) : 1; }();
     hipStream_t cs = st;
@@ -622,141 +619,156 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
     return GSR_OK;
   };
-  hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(st, &cap_st) == hipSuccess && cap_st == hipStreamCaptureStatusActive;
-  if (capturing && !async_count)
-    return fail(set_err(GSR_ERR_STATE, "gsr_forward: a stream capture needs GSR_FLAG_ASYNC_COUNT and an earlier forward of "
-                        "the same (P, H, W) on this device (the pair count cannot be waited for while capturing)"));
   if (P > 0) {
-    StageTimer t(GSR_STAGE_PREPROCESS, st);
-    PreBlockOut bo;
-    bo.bout = bout;
-    bo.ranges = P >= ntiles ? c->ranges : nullptr;      // the tile ranges are cleared by K1's first threads
-    bo.ntiles = ntiles;
-    if (c->lanegroup) {
-      PreArgs pa;
-      pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
-      pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
-      pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt;
-      pa.Pa = segb ? P - segb->Pb : P;
-      pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
-      pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
-      pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
-      pa.cull = cull; pa.bo = bo;
-      if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
-      else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
-      color_pa = pa;
-      want_color = !colors_precomp;
-      if (want_color && fork_at == 0) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
-    } else
-      hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, cull, means3D, scales, rotations, cov3D_precomp,
-                         opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
-    F_LAUNCH("preprocess");
-    if (!capturing && !slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
-    c->fwd_stream = st;
+    {
+      StageTimer t(GSR_STAGE_PREPROCESS, st);
+      PreBlockOut bo;
+      bo.bout = bout;
+      bo.ranges = P >= ntiles ? c->ranges : nullptr;      // the tile ranges are cleared by K1's first threads
+      bo.ntiles = ntiles;
+      if (!bo.ranges) {                                   // fewer Gaussians than tiles: spans (0xFFFFFFFF, 0) by two fills
+        F_TRY("ranges", hipMemset2DAsync(c->ranges, sizeof(uint2), 0xFF, sizeof(uint32_t), ntiles, st));
+        F_TRY("ranges", hipMemset2DAsync(reinterpret_cast<char*>(c->ranges) + sizeof(uint32_t), sizeof(uint2), 0, sizeof(uint32_t), ntiles, st));
+      }
+      if (c->lanegroup) {
+        PreArgs pa;
+        pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
+        pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
+        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt;
+        pa.Pa = segb ? P - segb->Pb : P;
+        pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
+        pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
+        pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
+        pa.cull = cull; pa.bo = bo;
+        if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
+        color_pa = pa;
+        want_color = !colors_precomp;
+        if (want_color && !fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
+      } else
+        hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, cull, means3D, scales, rotations, cov3D_precomp,
+                           opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
+      // storage-order numbering of the pairs (where the backward puts its partial rows), the depth sort's digit width
+      // and first histogram, the device-side pair count -- published to the host slot by the kernel itself: one launch
+      // stream capture (hipGraph): the forward must not wait for anything, so the count has to be asynchronous, and it is
+      // not published to the host at all (a replayed graph would keep writing into a slot that has long been recycled)
+      hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(st, &cap_st) == hipSuccess && cap_st == hipStreamCaptureStatusActive;
+      if (capturing && !async_count)
+        return fail(set_err(GSR_ERR_STATE, "gsr_forward: a stream capture needs GSR_FLAG_ASYNC_COUNT and an earlier forward of "
+                            "the same (P, H, W) on this device (the pair count cannot be waited for while capturing)"));
+      if (!capturing && !slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
+      c->fwd_stream = st;
+      hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint32_t*)dkey,
+                         (const uint4*)bout, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
+      F_LAUNCH("preprocess");
+    }
+    {
+      StageTimer t(GSR_STAGE_DEPTH_SORT, st);
+      // Stable argsort of the live depth keys in three passes whose digit width the device chose from the keys' range:
+      // order[r] = Gaussian of depth rank r, r < V = dv[DV_V].  Pass 0 drops the Gaussians that emit nothing (its
+      // histogram came from k_storage_scan_hist), the last pass also gathers cnt[r] = tiles touched by rank r.
+      const uint32_t* nV = c->dv + DV_V;
+      DigitSpec d0{c->dv, 0, 0, 0u}, d1{c->dv, 1, 0, 0u}, d2{c->dv, 2, 0, 0u};
+      radix_pass<RS_BINS_DEV>(dkey, nullptr, k1, vtmp, (uint32_t)P, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
+                              c->dv + DV_V, nullptr, nullptr, st);
+      radix_pass<RS_BINS_DEV>(k1, vtmp, dkey, v2, (uint32_t)P, nV, d1, DROUNDS, table, tsums, true, 0, 0, nullptr, nullptr,
+                              nullptr, st);
+      radix_pass<RS_BINS_DEV>(dkey, v2, nullptr, c->order, (uint32_t)P, nV, d2, DROUNDS, table, tsums, true, 0, 0, nullptr,
+                              tcnt, vtmp, st);
+      F_LAUNCH("depth sort");
+    }
+    if (want_color && fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
+    if (!async_count) {
+      // (the rank-order scan is enqueued after this wait: it records the owners of the emission chunks' first slots, an
+      // array sized by N; the depth sort keeps the GPU busy well past the host's wake-up)
+      if (ctx_resolve_count(c) != GSR_OK) return fail(set_err(GSR_ERR_DEVICE, "gsr_forward: reading the pair count failed"));
+      if (c->n64 >= MAX_PAIRS)   // NSUB * N must stay below 2^32
+        return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: %llu (tile, Gaussian) pairs exceed the supported %llu "
+                            "(splats cover too many tiles: check scales / scale_modifier)", c->n64, MAX_PAIRS));
+      nbound = (uint32_t)c->n64;
+    } else {
+      nbound = (uint32_t)cap_pairs;
+    }
   } else {
+    F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
     F_TRY("init", hipMemsetAsync(c->offg, 0, sizeof(uint32_t), st));
     F_TRY("init", hipMemsetAsync(c->dv, 0, sizeof(uint32_t) * DV_WORDS, st));
+    F_TRY("ranges", hipMemsetAsync(c->ranges, 0, sizeof(uint2) * ntiles, st));
     c->n_known = true;
   }
-  // the tile spans start as (0xFFFFFFFF, 0); with fewer Gaussians than tiles K1's threads do not cover them: two fills
-  auto clear_ranges = [&]() -> int {
-    F_TRY("ranges", hipMemset2DAsync(c->ranges, sizeof(uint2), 0xFF, sizeof(uint32_t), ntiles, st));
-    F_TRY("ranges", hipMemset2DAsync(reinterpret_cast<char*>(c->ranges) + sizeof(uint32_t), sizeof(uint2), 0, sizeof(uint32_t), ntiles, st));
-    return GSR_OK;
-  };
-  if (P < ntiles) { const int r0 = clear_ranges(); if (r0 != GSR_OK) return r0; }
-
-  // Storage-order numbering of the pairs, compaction of the Gaussians that emit any, the owners of the emission chunks'
-  // first slots, the device-side pair count -- one launch (k_storage_scan).  count_only: nothing behind it is sized yet.
-  bool slot_armed = false;
-  auto launch_scan = [&](unsigned long long cap, uint32_t* chunk_first, uint32_t chunk_cap) {
-    const bool publish = c->slot.host != nullptr && !slot_armed;      // the host slot is written by the FIRST scan only
-    hipLaunchKernelGGL(k_storage_scan, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint2*)bout, c->offg,
-                       live, offl, c->G0 + 3, chunk_first, (uint32_t)EMIT_GRAIN, chunk_cap, nbP, c->dv, cap,
-                       publish ? c->slot.dev : (uint32_t*)nullptr, c->slot.token);
-    slot_armed = slot_armed || publish;
-  };
-
-  // Everything behind the scan, sized for at most `cap` pairs: buffers, the scan itself (it records the emission chunks'
-  // owners, an array sized by the capacity), emission, tile sort, tile schedule, depth order inside the tiles, compositor.
-  auto enqueue_rest = [&](unsigned long long cap) -> int {
-    const uint32_t nbound = (uint32_t)cap;
-    c->nbound = nbound;
-    uint32_t* chunk_first = nullptr;
-    uint32_t ngrain = 0;
-    uint32_t *tileA = nullptr, *rankA = nullptr, *tileB = nullptr, *rankB = nullptr, *tableN = nullptr, *tsumsN = nullptr;
-    uint32_t nbN = 0;
-    int rounds = RS_ROUNDS_MIN;
-    if (nbound > 0) {
-      rounds = radix_rounds_for(nbound);
-      const uint32_t chunkN = (uint32_t)rs_chunk(rounds);
-      nbN = (nbound + chunkN - 1) / chunkN;
-      const uint32_t tblN = RS_BINS * nbN;
-      for (int i = 0; i < 4; ++i) {
-        pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)nbound, st);
-        if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", nbound));
-      }
-      ngrain = nbound / EMIT_GRAIN + 4;            // chunk_first entries
-      tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS + ngrain), st);
-      if (!tbl_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: sort table allocation failed"));
-      tileA = static_cast<uint32_t*>(pairs_blk[0]); rankA = static_cast<uint32_t*>(pairs_blk[1]);
-      tileB = static_cast<uint32_t*>(pairs_blk[2]); rankB = static_cast<uint32_t*>(pairs_blk[3]);
-      tableN = static_cast<uint32_t*>(tbl_blk);
-      tsumsN = tableN + tblN;
-      chunk_first = tsumsN + RS_BINS;
+  c->nbound = nbound;
+  if (nbound == 0 && P > 0) F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
+  if (nbound > 0) {
+    const int rounds = radix_rounds_for(nbound);
+    const uint32_t chunkN = (uint32_t)rs_chunk(rounds);
+    const uint32_t nbN = (nbound + chunkN - 1) / chunkN;
+    const uint32_t tblN = RS_BINS * nbN;
+    for (int i = 0; i < 4; ++i) {
+      pairs_blk[i] = pool_alloc(dev, sizeof(uint32_t) * (size_t)nbound, st);
+      if (!pairs_blk[i]) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pair buffers (N=%u) allocation failed", nbound));
     }
-    if (P > 0) {
+    const uint32_t ngrain = nbound / EMIT_GRAIN + 4;            // chunk_first entries
+    tbl_blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)tblN + RS_BINS + ngrain), st);
+    if (!tbl_blk) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: sort table allocation failed"));
+    uint32_t* tileA = static_cast<uint32_t*>(pairs_blk[0]); uint32_t* rankA = static_cast<uint32_t*>(pairs_blk[1]);
+    uint32_t* tileB = static_cast<uint32_t*>(pairs_blk[2]); uint32_t* rankB = static_cast<uint32_t*>(pairs_blk[3]);
+    uint32_t* tableN = static_cast<uint32_t*>(tbl_blk);
+    uint32_t* tsumsN = tableN + tblN;
+    uint32_t* chunk_first = tsumsN + RS_BINS;
+    const int tile_bits = ceil_log2((uint32_t)ntiles + 1);   // keys are 0..ntiles (ntiles = culled pair)
+    {
       StageTimer t(GSR_STAGE_BIN, st);
-      launch_scan(cap, chunk_first, ngrain);
-      F_LAUNCH("storage scan");
+      // off[r] = pairs emitted by the ranks in front of r, off[V] = their total; chunk_first[c] = rank that owns slot
+      // c * EMIT_GRAIN
+      // (two launches: block sums, then carry + local scan.  Round 3's one-launch variant, in which a block waited for its
+      // predecessors' published sums, saved 2.4 us and could, in principle, give up waiting with nothing but a poisoned
+      // image to show for it: removed)
+      scan_exclusive_u32(vtmp, c->off, (uint32_t)P, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
+      F_LAUNCH("rank scan");
+      int sh0; uint32_t mask0;
+      radix_first_digit(tile_bits, sh0, mask0);
+      if (rounds == RS_ROUNDS_MIN)
+        hipLaunchKernelGGL((k_emit<RS_ROUNDS_MIN>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MIN) / EMIT_PER_THREAD), 0, st, (const uint32_t*)c->off, (const uint32_t*)c->order,
+                           (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
+                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
+      else
+        hipLaunchKernelGGL((k_emit<RS_ROUNDS_MAX>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MAX) / EMIT_PER_THREAD), 0, st, (const uint32_t*)c->off, (const uint32_t*)c->order,
+                           (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
+                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
+      F_LAUNCH("emit");
     }
-    if (nbound > 0) {
-      const int tile_bits = ceil_log2((uint32_t)ntiles + 1);   // keys are 0..ntiles (ntiles = culled pair)
-      {
-        StageTimer t(GSR_STAGE_BIN, st);
-        int sh0; uint32_t mask0;
-        radix_first_digit(tile_bits, sh0, mask0);
-        if (rounds == RS_ROUNDS_MIN)
-          hipLaunchKernelGGL((k_emit<RS_ROUNDS_MIN>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MIN) / EMIT_PER_THREAD), 0, st, (const uint32_t*)offl, (const uint32_t*)live,
-                             (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
-                             (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
-        else
-          hipLaunchKernelGGL((k_emit<RS_ROUNDS_MAX>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MAX) / EMIT_PER_THREAD), 0, st, (const uint32_t*)offl, (const uint32_t*)live,
-                             (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
-                             (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
-        F_LAUNCH("emit");
-      }
-      if (want_color && fork_at == 1) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
-      int res;
-      {
-        StageTimer t(GSR_STAGE_TILE_SORT, st);
-        res = radix_sort_pairs(tileA, rankA, tileB, rankB, nbound, c->dv + DV_N, 0, tile_bits, false, tableN, tsumsN, st, true,
-                               reinterpret_cast<uint32_t*>(c->ranges), (uint32_t)ntiles);
-        F_LAUNCH("tile sort");
-      }
-      if (want_color) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
-      c->pair_rank = res ? rankB : rankA;
-      c->rank_blk = res ? pairs_blk[3] : pairs_blk[1];
-      pool_free(dev, tbl_blk);
-      tbl_blk = nullptr;
-      for (void* b : pairs_blk) if (b != c->rank_blk) pool_free(dev, b);
-      for (void*& b : pairs_blk) b = nullptr;
+    int res;
+    {
+      StageTimer t(GSR_STAGE_TILE_SORT, st);
+      res = radix_sort_pairs(tileA, rankA, tileB, rankB, nbound, c->dv + DV_N, 0, tile_bits, false, tableN, tsumsN, st, true,
+                             reinterpret_cast<uint32_t*>(c->ranges), (uint32_t)ntiles);
+      F_LAUNCH("tile sort");
     }
+    c->pair_rank = res ? rankB : rankA;
+    c->rank_blk = res ? pairs_blk[3] : pairs_blk[1];
+    pool_free(dev, tbl_blk);
+    tbl_blk = nullptr;
+    for (void* b : pairs_blk) if (b != c->rank_blk) pool_free(dev, b);
+    for (void*& b : pairs_blk) b = nullptr;
+  }
+  if (side_used) F_TRY("side stream", hipStreamWaitEvent(st, side.join, 0));   // the colours are in place from here on
+  {
+    StageTimer t(GSR_STAGE_RENDER_FWD, st);
     RenderArgs ra;
     ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->G0; ra.R1 = c->G1; ra.R2 = c->G2;
     ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
     ra.sh_objs_b = segb ? segb->objects_dc : nullptr; ra.Pa = segb ? P - segb->Pb : P;
-    ra.map_mode = flag_tile_map(s->flags);
+    const int map_mode_f = flag_tile_map(s->flags);
+    ra.map_mode = map_mode_f;
     ra.sched = c->sched;
-    ra.dv = c->dv;                 // dv[DV_OVF] != 0: more pairs than this pass was sized for -- the image is poisoned
+    ra.dv = async_count ? c->dv : nullptr;
     ra.wave_clock = g_wave_clock_fwd.load();
     // Long tile lists are split into segments for the backward (gsr_kernels.hip.h, "Segments"): the forward stores the
     // per-pixel (T, C) at the segment boundaries.  Not with object channels (their 16 running sums are not stored), not
     // for a forward-only call, not under GSR_FLAG_NO_SEGMENTS.
     static const int seg_shift_env = [] { const char* e = getenv("GSR_SEG_SHIFT"); int v = e ? atoi(e) : 8; return (v >= 6 && v <= 16) ? v : 8; }();
     ra.bnd = nullptr; ra.segoff = nullptr; ra.seg_shift = 0;
-    c->seg_shift = 0; c->rec_cap = 0;
     if (nbound > 0 && ctx_out && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
       const uint32_t per = nbound >> seg_shift_env;
       c->seg_shift = (uint32_t)seg_shift_env;
@@ -771,24 +783,9 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       c->segoff = gs.take<uint32_t>(ntiles);
       ra.bnd = c->bnd; ra.segoff = c->segoff; ra.seg_shift = c->seg_shift;
     }
-    {
-      StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-      // always: it also turns the empty spans the tile sort left untouched into (0, 0), and counts the tiles whose lists
-      // need more than a wave / more than a workgroup's LDS image to be put into depth order
-      hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift,
-                         c->segoff, c->rec_item, c->rec_cap, c->dv);
-      if (nbound > 0) {
-        TileSortArgs ta;
-        ta.ranges = c->ranges; ta.sched = c->sched; ta.dv = c->dv; ta.dkey = dkey; ta.vals = c->pair_rank; ta.ntiles = ntiles;
-        static const int huge_blocks = [] { const char* e = getenv("GSR_TDS_HUGE_BLOCKS"); int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();
-        hipLaunchKernelGGL(k_tile_depth_sort_huge, dim3((unsigned)std::min(huge_blocks, ntiles)), dim3(64 * TDS_HUGE_WAVES), 0, st, ta);
-        hipLaunchKernelGGL(k_tile_depth_sort, dim3((unsigned)std::min(ntiles, TDS_GRID)), dim3(64 * TDS_WAVES), 0, st, ta);
-      }
-      F_LAUNCH("tile depth sort");
-    }
-    if (want_color) { want_color = false; const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }   // (no pairs at all)
-    if (side_used) F_TRY("side stream", hipStreamWaitEvent(st, side.join, 0));   // the colours are in place from here on
-    StageTimer t(GSR_STAGE_RENDER_FWD, st);
+    // always: it also turns the empty spans the tile sort left untouched into (0, 0)
+    hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift,
+                         c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
     ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     const dim3 blkT(64);
     // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
@@ -816,42 +813,6 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
     }
     F_LAUNCH("render forward");
-    return GSR_OK;
-  };
-
-  auto check_count = [&]() -> int {
-    if (ctx_resolve_count(c) != GSR_OK) return fail(set_err(GSR_ERR_DEVICE, "gsr_forward: reading the pair count failed"));
-    if (c->n64 >= MAX_PAIRS)   // NSUB * N must stay below 2^32
-      return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: %llu (tile, Gaussian) pairs exceed the supported %llu "
-                          "(splats cover too many tiles: check scales / scale_modifier)", c->n64, MAX_PAIRS));
-    return GSR_OK;
-  };
-  if (P == 0) {
-    F_TRY("ranges", hipMemsetAsync(c->ranges, 0, sizeof(uint2) * ntiles, st));
-    const int r = enqueue_rest(0);
-    if (r != GSR_OK) return r;
-  } else if (speculate) {
-    const unsigned long long cap = std::min<unsigned long long>(seen + seen / 4 + 65536ull, MAX_PAIRS - 1);
-    int r = enqueue_rest(cap);
-    if (r != GSR_OK) return r;
-    if (!async_count) {
-      if ((r = check_count()) != GSR_OK) return r;
-      if (c->n64 > cap) {
-        // more pairs than the earlier views of this size promised: the kernels above did nothing (N = 0, overflow flag, a
-        // NaN image that is overwritten now).  Again, with the exact count; the tile spans start over too.
-        drop_pass();
-        if ((r = clear_ranges()) != GSR_OK) return r;
-        c->overflow = false;
-        if ((r = enqueue_rest(c->n64)) != GSR_OK) return r;
-      }
-    }
-  } else {
-    // no earlier view of this size to go by: count first (the scan without the emission's chunk owners), wait, size
-    launch_scan(MAX_PAIRS - 1, nullptr, 0);
-    F_LAUNCH("storage scan");
-    int r = check_count();
-    if (r != GSR_OK) return r;
-    if ((r = enqueue_rest(c->n64)) != GSR_OK) return r;
   }
   pool_free(dev, scratch_blk);
   if (num_rendered) *num_rendered = c->n_known ? (int64_t)c->n64 : (int64_t)-1;   // -1: not known yet (asynchronous count)
@@ -931,8 +892,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     return set_err(GSR_ERR_OVERFLOW, "gsr_backward: the forward emitted %llu (tile, Gaussian) pairs, more than the capacity "
                    "%u guessed from earlier views (GSR_FLAG_ASYNC_COUNT); its image was filled with NaN -- render again",
                    c->n64, c->nbound);
-  // (the exact count when the host has it; a forward recorded into a graph publishes nothing: its capacity then)
-  const uint32_t N = c->n_known ? (uint32_t)std::min<unsigned long long>(c->n64, c->nbound) : c->nbound;
+  const uint32_t N = c->nbound;
   void* part_blk = nullptr;
   void* pobj_blk = nullptr;
   float4* part = nullptr;
@@ -1138,9 +1098,8 @@ int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, 
       break;
     case 2: src = c->n_contrib; bytes = sizeof(uint32_t) * HW; break;
     case 3: src = c->final_T; bytes = sizeof(float) * HW; break;
-    case 4:
-    case 5: return set_err(GSR_ERR_INVALID, "gsr_ctx_export: items 4 and 5 (global depth order) no longer exist: the depth "
-                           "order is made per tile (items 0 and 1 hold it)");
+    case 4: src = c->order; bytes = sizeof(uint32_t) * (size_t)c->P; break;
+    case 5: src = c->off; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
     case 6:                                                                   // (kept for old callers: same as 7)
     case 7: {                                                                 // splat records [P][3] float4, storage order
       const size_t need = sizeof(float4) * 3 * (size_t)c->P;
@@ -1276,6 +1235,18 @@ int gsr_debug_wave_clock(unsigned long long* buf) {
 
 int gsr_debug_wave_clock_fwd(unsigned long long* buf) {
   g_wave_clock_fwd.store(buf);
+  return GSR_OK;
+}
+
+int gsr_test_scan(const uint32_t* in, uint32_t* out, uint32_t n, void* stream) {
+  if (!in || !out) return set_err(GSR_ERR_INVALID, "gsr_test_scan: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  void* blk = pool_alloc(dev, sizeof(uint32_t) * ((size_t)n / 2048 + 2), st);
+  if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_test_scan: allocation failed");
+  scan_exclusive_u32(in, out, n, nullptr, static_cast<uint32_t*>(blk), st);
+  pool_free(dev, blk);
+  LAUNCH_CHECK("test scan");
   return GSR_OK;
 }
 

@@ -7,14 +7,13 @@
 //                 rectx_bits = minx | maxx<<12,  recty_bits = miny | maxy<<12   (tile units); a colour whose SH sum was
 //                 clamped at 0 is stored as -0.0f (the clamp flag of the backward)
 //   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF for a Gaussian that emits no pair
-//   tcnt[g]       tiles of its (tightened) rect; offg[g] = exclusive scan of tcnt in storage order (numbers the emitted
-//                 pairs AND the backward's partial rows), offg[P] = N
-//   live[j]       storage index of the j-th Gaussian that emits pairs (storage order), j < V; offl[j] = offg[live[j]],
-//                 offl[V] = N
-//   dv[16]        device-side scalars of the forward (gsr_sort.hip.h, DV_*): N, V, overflow, schedule classes, ...
-//   pair_tile/pair_rank[N]  (tile id, Gaussian | strip mask << 28) pairs, emitted in STORAGE order, stably sorted by tile
-//                 id (=> storage order inside a tile), then every tile's list is sorted by (depth key, storage index) in
-//                 LDS (gsr_tilesort.hip.h) -- the order a stable depth sort in front of the emission would give
+//   tcnt[g]       tiles of its (tightened) rect; offg[g] = exclusive scan of tcnt in storage order (numbers the
+//                 backward's partial rows), offg[P] = N
+//   order[r]      Gaussian index of depth rank r (stable radix argsort of the live dkey), r < V
+//   off[r]        exclusive scan of tiles touched in depth order, off[V] = N (numbers the emitted pairs)
+//   dv[16]        device-side scalars of the forward (gsr_sort.hip.h, DV_*): N, V, kmin, digit width, overflow, ...
+//   pair_tile/pair_rank[N]  (tile id, Gaussian | strip mask << 28) pairs, emitted in depth-rank order, then stably
+//                 sorted by tile id (=> depth order inside a tile)
 //   ranges[t]     [start,end) of tile t in the sorted pair list
 //   final_T, n_contrib [H*W]  per-pixel transmittance / last contributing list position (1-based)
 //   part[N][12]   backward: per-(tile,Gaussian) partial sums written at the pair's storage-order slot, so
@@ -25,7 +24,6 @@
 
 #include "gsr_math.h"
 #include "gsr_sort.hip.h"
-#include "gsr_tilesort.hip.h"
 
 namespace gsr {
 
@@ -58,8 +56,8 @@ constexpr uint32_t RANK_MASK = (1u << RANK_BITS) - 1u;
 // ------------------------------------------------------------------------------------------------
 // K1 and K8+K9 launch shape.  Their waves never talk to each other about Gaussians (each wave owns 64 of them, wave
 // barriers only); a workgroup is a dispatch granule plus, in K1, the unit that hands the storage-order scan its partial
-// sums: per workgroup the tiles touched by its Gaussians and how many of them emit pairs at all, so that no separate
-// reduction pass over tcnt is needed.
+// sums: per workgroup the tiles touched by its Gaussians and the smallest / largest live depth key (the depth sort
+// chooses its digit width from that range), so that no separate reduction pass over tcnt / dkey is needed.
 // ------------------------------------------------------------------------------------------------
 constexpr int PRE_WAVES = 1;                 // K8+K9: one wave + its LDS finds room beside other streams' compositing waves
 constexpr int PRE_BLOCK = 64 * PRE_WAVES;
@@ -69,27 +67,30 @@ constexpr int PREG_WAVES = 4;                // K1, geometry half (small workgro
 constexpr int PREG_BLOCK = 64 * PREG_WAVES;
 
 struct PreBlockOut {
-  uint2* bout;       // [ceil(P / PREG_BLOCK)] per workgroup: (tiles touched, Gaussians that emit pairs)
+  uint4* bout;       // [ceil(P / PREG_BLOCK)] per workgroup: (tiles touched, smallest live depth key or 0xFFFFFFFF, largest or 0, -)
   uint2* ranges;     // [ntiles] set to the empty span (0xFFFFFFFF, 0) here (one tile per thread) when P >= ntiles
   int ntiles;
 };
 
-// cnt: tiles this thread's Gaussian touches (0: it emits nothing)
-__device__ __forceinline__ void pre_block_epilogue(const PreBlockOut& o, int g, uint32_t cnt) {
-  __shared__ uint32_t red[2][PREG_WAVES];
+// cnt: tiles this thread's Gaussian touches; key: its depth key, 0xFFFFFFFF when it emits nothing
+__device__ __forceinline__ void pre_block_epilogue(const PreBlockOut& o, int g, uint32_t cnt, uint32_t key) {
+  __shared__ uint32_t red[3][PREG_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (o.ranges && g < o.ntiles) o.ranges[g] = make_uint2(0xFFFFFFFFu, 0u);     // (start, end) for atomicMin / atomicMax
-  uint32_t s = cnt;
+  uint32_t s = cnt, mn = key, mx = key == 0xFFFFFFFFu ? 0u : key;
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += (uint32_t)__shfl_xor((int)s, d, 64);
-  const uint32_t nl = (uint32_t)__popcll(__ballot(cnt != 0u));
-  if (lane == 0) { red[0][wave] = s; red[1][wave] = nl; }
+  for (int d = 32; d > 0; d >>= 1) {
+    s += (uint32_t)__shfl_xor((int)s, d, 64);
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  }
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = mn; red[2][wave] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t ts = 0, tl = 0;
+    uint32_t ts = 0, tmn = 0xFFFFFFFFu, tmx = 0u;
 #pragma unroll
-    for (int w = 0; w < PREG_WAVES; ++w) { ts += red[0][w]; tl += red[1][w]; }
-    o.bout[blockIdx.x] = make_uint2(ts, tl);
+    for (int w = 0; w < PREG_WAVES; ++w) { ts += red[0][w]; tmn = min(tmn, red[1][w]); tmx = max(tmx, red[2][w]); }
+    o.bout[blockIdx.x] = make_uint4(ts, tmn, tmx, 0u);
   }
 }
 
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
     dkey[g] = key;
     tcnt[g] = cnt;
   }
-  pre_block_epilogue(bo, g, cnt);
+  pre_block_epilogue(bo, g, cnt, key);
 }
 
 // K10
@@ -161,103 +162,94 @@ __global__ void __launch_bounds__(256) k_mark_visible(int P, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: storage-order numbering of the (tile, Gaussian) pairs, in ONE launch behind K1.  Block b owns SCHUNK = 2048
-// Gaussians:
-//   * its carries are the sums of K1's workgroup sums in front of it (a few thousand L2-resident words, summed redundantly
-//     by every block instead of by a dependent single-block kernel): tiles touched and Gaussians that emit pairs;
-//   * offg[g] = exclusive scan of tiles touched in storage order: numbers the emitted pairs and the backward's partial
-//     rows (offg[P] = total);
-//   * the Gaussians that emit pairs are compacted: live[j] = g, offl[j] = offg[g] (the emission works on this list: every
-//     element of it owns at least one output slot);
-//   * chunk_first[c] = the j that owns output slot c * chunk_len, for every emission chunk that starts inside the total
-//     (what a slot-parallel emission would otherwise find by a binary search of offl in global memory);
-//   * the last block publishes the device-side scalars: pair count (exact 64-bit, and the 32-bit count the rest of the
-//     forward uses -- 0 with the overflow flag set when it exceeds `cap`, the capacity the host sized this forward's
-//     buffers and grids for), and V.
+// K2: storage-order numbering of the (tile, Gaussian) pairs + everything the depth sort needs before its first scatter,
+// in ONE launch behind K1.  Block b owns DCHUNK = 2048 Gaussians (= one chunk of the depth sort's first pass):
+//   * its carry is the sum of K1's workgroup sums in front of it (a few thousand L2-resident words, summed redundantly
+//     by every block instead of by a dependent single-block kernel), likewise the global min / max of the live depth keys;
+//   * offg[g] = exclusive scan of tiles touched in storage order (numbers the backward's partial rows; offg[P] = total);
+//   * the digit width w of the depth sort from the key range, and this chunk's histogram of the first digit of the live
+//     keys (culled Gaussians are not counted: the first scatter pass drops them), written to the radix table;
+//   * the last block publishes the device-side scalars: pair count (exact 64-bit, and the 32-bit count the rest of
+//     the forward uses -- 0 with the overflow flag set when it exceeds `cap` or 2^31), kmin, w.
 // ------------------------------------------------------------------------------------------------
-constexpr int SCHUNK = 2048;
-constexpr int SITEMS = SCHUNK / 256;
-static_assert(SCHUNK % PREG_BLOCK == 0, "a scan chunk covers whole K1 workgroups");
+constexpr int DROUNDS = RS_ROUNDS_MIN;               // the depth sort always works in 2048-key chunks (LDS: 2048 bins)
+constexpr int DCHUNK = rs_chunk(DROUNDS);
+constexpr int DITEMS = DCHUNK / 256;
+static_assert(DCHUNK % PREG_BLOCK == 0, "a scan chunk covers whole K1 workgroups");
 
-__global__ void __launch_bounds__(256) k_storage_scan(uint32_t P, const uint32_t* __restrict__ tcnt,
-                                                      const uint2* __restrict__ bout, uint32_t* __restrict__ offg,
-                                                      uint32_t* __restrict__ live, uint32_t* __restrict__ offl,
-                                                      float4* __restrict__ G3, uint32_t* __restrict__ chunk_first, uint32_t chunk_len,
-                                                      uint32_t chunk_cap, uint32_t nb, uint32_t* __restrict__ dv,
-                                                      unsigned long long cap, uint32_t* host_slot, uint32_t host_token) {
+__global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uint32_t* __restrict__ tcnt,
+                                                           const uint32_t* __restrict__ dkey,
+                                                           const uint4* __restrict__ bout, uint32_t* __restrict__ offg,
+                                                           uint32_t* __restrict__ table, uint32_t nb,
+                                                           uint32_t* __restrict__ dv, unsigned long long cap,
+                                                           uint32_t* host_slot, uint32_t host_token) {
   __shared__ uint32_t tmp[4];
   __shared__ unsigned long long tmp64[4];
+  __shared__ uint32_t h[RS_BINS_DEV];
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
-  const uint32_t base = b * SCHUNK + tid * SITEMS;
-  // this chunk's tiles-touched counts are requested first: they do not depend on the reduction below
-  uint32_t v[SITEMS];
+  const uint32_t base = b * DCHUNK + tid * DITEMS;
+  // this chunk's tiles-touched counts and depth keys are requested first: they do not depend on the reduction below
+  uint32_t v[DITEMS], kk[DITEMS];
 #pragma unroll
-  for (int i = 0; i < SITEMS; ++i) v[i] = base + i < P ? tcnt[base + i] : 0u;
+  for (int i = 0; i < DITEMS; ++i) {
+    const bool in = base + i < P;
+    v[i] = in ? tcnt[base + i] : 0u;
+    kk[i] = in ? dkey[base + i] : RS_DROP_KEY;
+  }
   const uint32_t nk1 = (P + PREG_BLOCK - 1) / PREG_BLOCK;
-  const uint32_t front = b * (SCHUNK / PREG_BLOCK);     // K1 workgroups in front of this chunk
-  uint32_t part = 0, partl = 0, alll = 0;
+  const uint32_t front = b * (DCHUNK / PREG_BLOCK);     // K1 workgroups in front of this chunk
+  uint32_t part = 0, mn = 0xFFFFFFFFu, mx = 0u;
   unsigned long long all = 0;
   for (uint32_t i = tid; i < nk1; i += 256) {
-    const uint2 bo = bout[i];
+    const uint4 bo = bout[i];
     part += i < front ? bo.x : 0u;
-    partl += i < front ? bo.y : 0u;
     all += bo.x;
-    alll += bo.y;
+    mn = min(mn, bo.y); mx = max(mx, bo.z);
   }
-  uint32_t carry, carryl, V;
+  uint32_t carry;
   block_excl_scan_256(part, tmp, carry);
-  block_excl_scan_256(partl, tmp, carryl);
-  block_excl_scan_256(alll, tmp, V);
-  const unsigned long long n64 = block_sum_u64(all, tmp64);
-  const bool ovf = n64 > cap;
-  uint32_t sum = 0, nl = 0;
+  const uint32_t kmin = block_min_u32(mn, tmp), kmax = block_max_u32(mx, tmp);
+  const uint32_t w = depth_digit_width(kmin, kmax), mask = (1u << w) - 1u, nbins = 1u << w;
+  for (uint32_t d = tid; d < nbins; d += 256) h[d] = 0;
+  __syncthreads();
+  uint32_t sum = 0;
 #pragma unroll
-  for (int i = 0; i < SITEMS; ++i) { sum += v[i]; nl += v[i] != 0u ? 1u : 0u; }
-  uint32_t total, totall;
+  for (int i = 0; i < DITEMS; ++i) {
+    sum += v[i];
+    if (kk[i] != RS_DROP_KEY) atomicAdd(&h[(kk[i] - kmin) & mask], 1u);
+  }
+  uint32_t total;
   uint32_t run = block_excl_scan_256(sum, tmp, total) + carry;
-  uint32_t j = block_excl_scan_256(nl, tmp, totall) + carryl;
 #pragma unroll
-  for (int i = 0; i < SITEMS; ++i) {
+  for (int i = 0; i < DITEMS; ++i) {
     if (base + i < P) offg[base + i] = run;
-    if (v[i] != 0u) {
-      live[j] = base + i;
-      offl[j] = run;
-      // -DGSR_REC=4 (experiment, round 4): the record's fourth float4 is padding; its first word carries offg[g], so that
-      // the backward compositor's row numbering needs no gather of its own (one 64-byte sector per list entry)
-      if (REC == 4) reinterpret_cast<uint32_t*>(G3 + (size_t)REC * (base + i))[0] = run;
-      if (chunk_first && !ovf) {
-        // chunk starts c * chunk_len inside [run, run + v): usually none or one
-        for (uint32_t c = (run + chunk_len - 1u) / chunk_len;
-             c < chunk_cap && (unsigned long long)c * chunk_len < (unsigned long long)run + v[i]; ++c)
-          chunk_first[c] = j;
-      }
-      ++j;
-    }
     run += v[i];
   }
-  if (b == nb - 1 && tid == 0) {
-    offg[P] = carry + total;
-    offl[V] = carry + total;
-    dv[DV_N] = ovf ? 0u : (uint32_t)n64;
-    dv[DV_V] = V;
-    dv[DV_OVF] = ovf ? 1u : 0u;
-    dv[DV_N64] = (uint32_t)n64; dv[DV_N64 + 1] = (uint32_t)(n64 >> 32);
-    if (host_slot) {
-      // pinned, device-mapped host memory: count and flag first, then -- behind a system-scope fence -- the token the
-      // host is polling for (words: 0,1 = count, 2 = overflow flag, 3 = token)
-      host_slot[0] = (uint32_t)n64; host_slot[1] = (uint32_t)(n64 >> 32); host_slot[2] = ovf ? 1u : 0u;
-      __threadfence_system();
-      __hip_atomic_store(&host_slot[3], host_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  for (uint32_t d = tid; d < nbins; d += 256) table[d * nb + b] = h[d];
+  if (b == nb - 1) {
+    const unsigned long long n64 = block_sum_u64(all, tmp64);
+    if (tid == 0) {
+      offg[P] = carry + total;
+      const bool ovf = n64 > cap;
+      dv[DV_N] = ovf ? 0u : (uint32_t)n64;
+      dv[DV_KMIN] = kmin; dv[DV_W] = w; dv[DV_OVF] = ovf ? 1u : 0u;
+      dv[DV_N64] = (uint32_t)n64; dv[DV_N64 + 1] = (uint32_t)(n64 >> 32);
+      if (host_slot) {
+        // pinned, device-mapped host memory: count and flag first, then -- behind a system-scope fence -- the token the
+        // host is polling for (words: 0,1 = count, 2 = overflow flag, 3 = token)
+        host_slot[0] = (uint32_t)n64; host_slot[1] = (uint32_t)(n64 >> 32); host_slot[2] = ovf ? 1u : 0u;
+        __threadfence_system();
+        __hip_atomic_store(&host_slot[3], host_token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: emit (tile, Gaussian) pairs, one thread per OUTPUT slot (perfectly balanced, coalesced writes), in STORAGE order
-// (consecutive slots belong to consecutive Gaussians: their records are read nearly sequentially).  A block emits one
-// chunk of the tile sort's first pass and leaves that pass's digit histogram of its chunk in the radix table: the sort's
-// first histogram launch (a full read of the keys) disappears.  "rank" below = index into the compacted list of
-// Gaussians that emit pairs (live[], offl[] of k_storage_scan).
+// K3: emit (tile, Gaussian) pairs, one thread per OUTPUT slot (perfectly balanced, coalesced writes), in depth-rank
+// order.  A block emits one chunk of the tile sort's first pass and leaves that pass's digit histogram of its chunk in
+// the radix table: the sort's first histogram launch (a full read of the keys) disappears.
 // ------------------------------------------------------------------------------------------------
 // A (tile, Gaussian) pair of the Gaussian's tile rect is kept only if some pixel of the tile can pass
 // the reference's own alpha test (alpha >= 1/255); pairs that cannot are given the key `ntiles`, sort to the
@@ -265,14 +257,14 @@ __global__ void __launch_bounds__(256) k_storage_scan(uint32_t P, const uint32_t
 // the pair's value, so K6/K7 skip strips with scalar bit tests instead of evaluating the splat there.  The rendered
 // image, radii and gradients are unchanged by construction (the test is conservative); only the work shrinks.
 // `cull` = 0 keeps every pair.  dv: device-side counts (DV_N pairs, DV_V ranks).
-// A block = CHUNK / 8 threads emits CHUNK slots, eight per thread with their dependent chains (owner -> live[] ->
+// A block = CHUNK / 8 threads emits CHUNK slots, eight per thread with their dependent chains (owner -> order[] ->
 // record -> mask) interleaved.  The owner of a slot comes from a running maximum over marks in LDS, not from a search.
 constexpr int EMIT_PER_THREAD = 8;        // slots per thread, in EMIT_BATCHES rounds of EMIT_ILV interleaved chains
 constexpr int EMIT_ILV = 4;
 constexpr int EMIT_GRAIN = rs_chunk(RS_ROUNDS_MIN);     // slots per chunk_first entry (the smaller of the two chunk sizes)
 template <int ROUNDS>
 __global__ void __launch_bounds__(rs_chunk(ROUNDS) / EMIT_PER_THREAD)
-k_emit(const uint32_t* __restrict__ offl, const uint32_t* __restrict__ live, const uint32_t* __restrict__ chunk_first,
+k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_first,
        const uint32_t* __restrict__ dv, const float4* __restrict__ R0, const float4* __restrict__ R1, const float4* __restrict__ R2, int gridx, int W, int H,
        uint32_t ntiles, int cull, uint32_t* __restrict__ pair_tile, uint32_t* __restrict__ pair_rank,
        uint32_t* __restrict__ table, uint32_t nb, uint32_t digit_mask) {
@@ -295,7 +287,7 @@ k_emit(const uint32_t* __restrict__ offl, const uint32_t* __restrict__ live, con
     uint32_t rh = V - 1u;
     if (e1 < N) {                                           // another chunk follows: e1 is its first slot
       const uint32_t rn = chunk_first[(blockIdx.x + 1u) * (CHUNK / EMIT_GRAIN)];
-      rh = offl[rn] == e1 ? rn - 1u : rn;                   // ranks all own at least one slot: offl[] is strictly increasing
+      rh = off[rn] == e1 ? rn - 1u : rn;                    // ranks all own at least one slot: off[] is strictly increasing
     }
     s_r[1] = rh;
   }
@@ -309,7 +301,7 @@ k_emit(const uint32_t* __restrict__ offl, const uint32_t* __restrict__ live, con
   // Slot -> owner without a search: rank i of the chunk marks the slot its run starts on (rank 0's run starts at or
   // before e0: it owns the slots in front of the first mark), and a running maximum over the slots spreads the marks.
   for (uint32_t i = threadIdx.x; i < span; i += THREADS) {
-    const uint32_t v = offl[r_lo + i];
+    const uint32_t v = off[r_lo + i];
     s_off[i] = v;
     if (i) s_own[v - e0] = i;
   }
@@ -349,7 +341,7 @@ k_emit(const uint32_t* __restrict__ offl, const uint32_t* __restrict__ live, con
       const uint32_t i = s_own[e[k] - e0];
       r = r_lo + i; o[k] = s_off[i];
     }
-    g[k] = on[k] ? live[r] : 0u;                           // the pair's value: the Gaussian (storage index)
+    g[k] = on[k] ? order[r] : 0u;                          // the pair's value: the Gaussian (storage index)
   }
   float4 ra[EMIT_ILV], rb[EMIT_ILV], rc[EMIT_ILV];
 #pragma unroll
@@ -500,7 +492,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* w
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
-                                                        uint32_t rec_cap, uint32_t* __restrict__ dv) {
+                                                        uint32_t rec_cap, uint32_t* __restrict__ nrec_out) {
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
@@ -554,15 +546,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
     uint32_t total;
     uint32_t run = block_excl_scan_1024(s, wsum, total);
 #pragma unroll
-    for (int k = 0; k < BPT; ++k) {
-      const int bin = SCHED_BINS - 1 - (t * BPT + k);
-      hist[bin] = run;                                  // becomes the bin's cursor = tiles with longer lists
-      // what the depth ordering of the lists needs to know (gsr_tilesort.hip.h): tiles too long for one wave, and
-      // tiles in the last (clamped) bin, which take the big workgroup
-      if (bin == TDS_WAVE_CAP) dv[DV_NMID] = run;
-      if (bin == SCHED_BINS - 2) dv[DV_NHUGE] = run;
-      run += c[k];
-    }
+    for (int k = 0; k < BPT; ++k) { hist[SCHED_BINS - 1 - (t * BPT + k)] = run; run += c[k]; }   // becomes the bin's cursor
   }
   __syncthreads();
   const float prio_scale = 4.0f / (float)(smax + 1u);
@@ -574,7 +558,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
   }
   // ---- boundary records of the split tiles: exclusive scan of nseg over the tiles, in tile order ------------------
   // thread t owns the consecutive tiles [t * tpt, (t + 1) * tpt): ONE block scan instead of one per 1024 tiles
-  if (segoff == nullptr) { if (t == 0) dv[DV_NREC] = 0u; return; }
+  if (segoff == nullptr) return;
   const uint32_t seg_len = 1u << seg_shift;
   const int tpt = (ntiles + 1023) / 1024;
   const int i_lo = t * tpt, i_hi = min(i_lo + tpt, ntiles);
@@ -599,7 +583,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
     segoff[i] = off;
     run += nseg;
   }
-  if (t == 0) dv[DV_NREC] = min(total, rec_cap);
+  if (t == 0) *nrec_out = min(total, rec_cap);
 }
 __device__ __forceinline__ void set_wave_priority(uint32_t prio) {
   if (prio == 3u) __builtin_amdgcn_s_setprio(3);
@@ -860,13 +844,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // ------------------------------------------------------------------------------------------------
 // K7: backward composite, same tiling, list walked back to front.  Per (tile, entry) the wave reduces
 // nine sums over its 256 pixels and stores ONE 48-byte row at the pair's emission slot: no global
-// atomics, bitwise reproducible.  Row = (Mx, My, Sq dx^2, Sq dx dy, Sq dy^2, S G dL/dalpha,
-// S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha and
-// (Mx, My) = -log2(e) S q (A dx + B dy, B dx + C dy): the conic applied to the first moments PER LANE, before any sum --
-// the published backward forms dG/ddx = -G (A dx + B dy) per pixel; summing S q dx and S q dy first and multiplying by
-// the conic afterwards (rounds 1-3) is the same number on paper and loses the cancellation of a needle-shaped splat
-// (A dx ~ -B dy along its axis) to float32 rounding of the two large sums: 6x the float32 oracle's own error on
-// dL/dmean2D of a 1500:1 needle (tests/diag_aniso_elem.py, seed 106).
+// atomics, bitwise reproducible.  Row = (Sq dx, Sq dy, Sq dx^2, Sq dx dy, Sq dy^2, S G dL/dalpha,
+// S w g_r, S w g_g, S w g_b, tag_lo, tag_hi, -) with q = o G dL/dalpha.
 // The 64-lane sums are not butterflies (a DPP add issues at half the rate of a plain one and nine values
 // need 9 x 6 of them): the per-lane values are parked in LDS as they are (ds_write does not occupy the VALU;
 // only dg and db are folded into one register so that an entry is 64 chunks of 8 floats), and after every
@@ -1055,8 +1034,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
-      const uint32_t row0 = REC == 4 ? reinterpret_cast<const uint32_t*>(a.R2 + (size_t)REC * r + 1)[0] : a.offg[r];
-      sslot[lane] = (row0 + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
+      sslot[lane] = (a.offg[r] + ((uint32_t)ty - miny) * wx + ((uint32_t)tx - minx)) * NSUB + sub;
       if (OBJ) {
         const float4* src = reinterpret_cast<const float4*>(a.sh_objs + (size_t)r * NUM_OBJ);
         float4* dst = reinterpret_cast<float4*>(&so[lane][0]);
@@ -1145,9 +1123,8 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         float* w = &sred[red_n * RENTRY + red_wofs];
         if (GEOM) {
           const float a0 = sq * dx;
-          // values 0, 1: the staged conic words are (-log2e/2) A, -log2e B, (-log2e/2) C
-          w[0] = fmaf(e0.w, sqy, 2.f * e0.z * a0);       // -log2e (A S q dx + B S q dy) of this lane's pixels
-          w[RED_REG] = fmaf(e0.w, a0, 2.f * e1.x * sqy); // -log2e (B S q dx + C S q dy)
+          w[0] = a0;                                     // value 0: S q dx
+          w[RED_REG] = sqy;                              // value 1: S q dy
           w[2 * RED_REG] = a0 * dx;                      // value 2: S q dx^2
           w[3 * RED_REG] = sqy * dx;                     // value 3: S q dx dy
           w[4 * RED_REG] = sqyy;                         // value 4: S q dy^2
@@ -1292,11 +1269,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   }
   View v;
   load_view(v, a.va);
-  const float4 e1 = a.G1[REC * g], e2 = a.G2[REC * g];
-  // dL/d(pixel centre) = -(A Sq dx + B Sq dy, B Sq dx + C Sq dy) = (mx, my) / log2(e): K7 applied the conic per lane
-  // (row words 0, 1); screen-space means are reported in NDC units
-  const float dndcx = mx * (0.5f / LOG2E) * (float)v.W;
-  const float dndcy = my * (0.5f / LOG2E) * (float)v.H;
+  const float4 e0 = a.G0[REC * g], e1 = a.G1[REC * g], e2 = a.G2[REC * g];
+  const float A = e0.z, B = e0.w, C = e1.x;
+  // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
+  const float dndcx = -(A * mx + B * my) * 0.5f * (float)v.W;
+  const float dndcy = -(B * mx + C * my) * 0.5f * (float)v.H;
   const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
   if (GEOM && a.dmeans2D) { put(&a.dmeans2D[3 * g], dndcx); put(&a.dmeans2D[3 * g + 1], dndcy); put(&a.dmeans2D[3 * g + 2], 0.f); }
   if (GEOM && a.dopac) put(&a.dopac[g], dop);
@@ -1502,7 +1479,7 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     a.dkey[g] = key;
     a.tcnt[g] = cnt;
   }
-  pre_block_epilogue(a.bo, g, cnt);
+  pre_block_epilogue(a.bo, g, cnt, key);
 }
 
 // K1, colour half: SH -> RGB for the Gaussians that emit pairs, by FOUR LANES per Gaussian (see above), + d colour /
@@ -1628,7 +1605,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   // (the second moments are summed in double: what they feed -- dL/dconic -> dL/dcov2D -- cancels to first order for an
   // elongated splat, see project_splat_bwd, and amplifies the rounding of a float32 running sum over hundreds of rows)
   float dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-  double mx = 0.0, my = 0.0, mxx = 0.0, mxy = 0.0, myy = 0.0;      // (mx, my: K7's conic . first moments, residues of a cancellation)
+  double mx = 0.0, my = 0.0, mxx = 0.0, mxy = 0.0, myy = 0.0;      // (conic . (mx, my) cancels the same way)
   {
     const uint32_t S = a.offg[gw0] * a.nsub, E = a.offg[gw0 + nw] * a.nsub;
     const bool big = (o1 - o0) > (uint32_t)ROW_CHUNK;
@@ -1716,10 +1693,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       }
       View v;
       load_view(v, a.va);
-      // dL/d(pixel centre) = -(A Sq dx + B Sq dy, B Sq dx + C Sq dy) = (mx, my) / log2(e): K7 applied the conic per lane
-      // (row words 0, 1); screen-space means are reported in NDC units
-      const float dndcx = (float)(mx * (0.5 / (double)LOG2E * (double)v.W));
-      const float dndcy = (float)(my * (0.5 / (double)LOG2E * (double)v.H));
+      const float A = e0.z, B = e0.w, C = e1.x;
+      // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
+      const float dndcx = (float)(-((double)A * mx + (double)B * my) * (0.5 * (double)v.W));
+      const float dndcy = (float)(-((double)B * mx + (double)C * my) * (0.5 * (double)v.H));
       const double dA = -0.5 * mxx, dB = -mxy, dC = -0.5 * myy;
       if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }   // per view
       if (GEOM && a.dopac) put(&a.dopac[g], RAW ? dop * e1.y * (1.f - e1.y) : dop);   // e1.y = sigmoid(raw opacity)

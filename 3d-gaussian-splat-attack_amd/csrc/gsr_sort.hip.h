@@ -1,14 +1,19 @@
-// gsr_sort.hip.h -- wave64 scan helpers and a stable LSD radix sort of (u32 key, u32 value) pairs, hand-written for
-// gfx950.
+// gsr_sort.hip.h -- wave64 scan, exclusive scan over u32 arrays and a stable LSD radix sort of
+// (u32 key, u32 value) pairs, hand-written for gfx950.
 //
-// Replaces what the absent reference extension gets from a vendor scan/sort library.
-// Design for MI355X rather than a translation: the reference sorts N (tile << 32 | depth) 64-bit keys in one go; here
-// the N duplicated pairs are sorted globally on ceil(log2 T) bits of tile id ONLY (two passes at 1080p) and the depth
-// order inside every tile is made afterwards, in LDS, by the tile's own workgroup (gsr_tilesort.hip.h).  Every pass
-// ranks with wave64 ballots (no per-thread digit counters), stages its chunk in LDS and writes digit runs back coalesced.
+// Replaces what the absent reference extension gets from a vendor scan/sort library (SURVEY.md section
+// 2.2, K2/K4).  Design for MI355X rather than a translation: the depth order and the tile binning are
+// two SEPARATE small-key sorts (32-bit depth over the visible Gaussians, then ceil(log2 T) bits of tile id over
+// the N duplicated pairs) instead of one 64-bit (tile<<32|depth) sort over N pairs -- ~4.5x less HBM
+// traffic -- and every pass ranks with wave64 ballots (no per-thread digit counters), stages its
+// chunk in LDS and writes digit runs back coalesced.
 //
-// Element counts may live on the DEVICE (`n_dev`): the forward never waits for the host to learn how many pairs were
-// emitted.  Grids are sized from a host-side upper bound and blocks beyond the live count exit.
+// Round 3: element counts may live on the DEVICE (`n_dev`): the forward never waits for the host to learn how many
+// Gaussians survive the culls or how many pairs they emit.  Grids are sized from a host-side upper bound and blocks
+// beyond the live count exit.  The depth sort's digit layout is chosen on the device too (DigitSpec::dv): the keys'
+// range (max - min of the live depth bits) decides a digit width w = ceil(bits / 3) <= 11, so THREE passes always
+// cover the key (27 significant bits on the benchmark scene -> 9-bit digits) where fixed 8-bit digits need four.
+// Pass 0 also compacts: keys equal to RS_DROP_KEY (culled Gaussians) are neither counted nor written.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,14 +82,96 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* tmp) {
 // ---- device-side scalars of one forward ("dv" block, 16 words, lives in the context's kept slab) --------------------
 enum {
   DV_N = 0,       // number of (tile, Gaussian) pairs the tile sort / compositors see (0 when the capacity overflowed)
-  DV_V = 1,       // Gaussians that emit at least one pair
-  DV_NHUGE = 2,   // tiles whose list has >= TDS_HUGE_MIN entries (k_tile_schedule; they come first in sched[])
-  DV_NMID = 3,    // tiles with more entries than one wave sorts by itself (> TDS_WAVE_CAP; includes the huge ones)
-  DV_OVF = 4,     // 1: more pairs than the capacity this forward's buffers and grids were sized for
+  DV_V = 1,       // Gaussians that emit at least one pair (= live keys of the depth sort)
+  DV_KMIN = 2,    // smallest live depth key
+  DV_W = 3,       // digit width of the three depth passes
+  DV_OVF = 4,     // 1: more pairs than the caller's capacity (asynchronous pair count only)
   DV_NREC = 5,    // boundary records in use (k_tile_schedule)
   DV_N64 = 6,     // words 6,7: exact 64-bit pair count
   DV_WORDS = 16
 };
+
+// ---- exclusive scan over n u32 (two launches: block sums, then carry + local scan) ------------------
+// ITEMS per thread: 8 (2048 per block) or 16 (4096).  n_dev != nullptr: the live count is min(n, *n_dev).
+template <int ITEMS>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partial(const uint32_t* __restrict__ in, uint32_t n,
+                                                               const uint32_t* __restrict__ n_dev,
+                                                               uint32_t* __restrict__ sums) {
+  constexpr int CHUNK = SCAN_THREADS * ITEMS;
+  __shared__ uint32_t tmp[4];
+  if (n_dev) n = min(n, *n_dev);
+  const uint32_t base = blockIdx.x * CHUNK + threadIdx.x * ITEMS;
+  if (blockIdx.x * CHUNK >= n) return;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) s += (base + i < n) ? in[base + i] : 0u;
+  uint32_t total;
+  block_excl_scan_256(s, tmp, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// Second and last launch of the scan: block b forms its own carry from the raw block sums of k_scan_partial (at most
+// a few thousand words, L2 resident) instead of waiting for a single-block scan of them; the last live block also
+// writes the total to out[n_live].
+// chunk_first != nullptr: the scanned values are lengths of consecutive runs of output slots (element r owns slots
+// [out[r], out[r] + in[r])), and chunk_first[c] receives the element that owns slot c * chunk_len, for every chunk
+// that starts inside the total -- what a slot-parallel consumer (k_emit) would otherwise find by a binary search of `out`
+// in global memory, twenty dependent loads per workgroup before its first useful instruction.
+template <int ITEMS>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply_carry(const uint32_t* in, uint32_t* out, uint32_t n,
+                                                                   const uint32_t* __restrict__ n_dev,
+                                                                   const uint32_t* __restrict__ sums,
+                                                                   uint32_t* __restrict__ chunk_first, uint32_t chunk_len,
+                                                                   uint32_t chunk_cap) {
+  constexpr int CHUNK = SCAN_THREADS * ITEMS;
+  __shared__ uint32_t tmp[4];
+  if (n_dev) n = min(n, *n_dev);
+  const uint32_t b = blockIdx.x;
+  if (n == 0) { if (b == 0 && threadIdx.x == 0) out[0] = 0u; return; }
+  if (b * CHUNK >= n) return;
+  const uint32_t nb = (n + CHUNK - 1) / CHUNK;
+  uint32_t part = 0;
+  for (uint32_t i = threadIdx.x; i < b; i += SCAN_THREADS) part += sums[i];
+  uint32_t carry;
+  block_excl_scan_256(part, tmp, carry);                 // carry = sum of the block sums in front of this block
+  const uint32_t base = b * CHUNK + threadIdx.x * ITEMS;
+  uint32_t v[ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; s += v[i]; }
+  uint32_t total;
+  uint32_t run = block_excl_scan_256(s, tmp, total) + carry;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    if (base + i < n) out[base + i] = run;
+    if (chunk_first && v[i] != 0u) {
+      // chunk starts c * chunk_len inside [run, run + v): usually none or one
+      for (uint32_t c = (run + chunk_len - 1u) / chunk_len;
+           c < chunk_cap && (unsigned long long)c * chunk_len < (unsigned long long)run + v[i]; ++c)
+        chunk_first[c] = base + i;
+    }
+    run += v[i];
+  }
+  if (b == nb - 1 && threadIdx.x == 0) out[n] = carry + total;
+}
+
+// out may alias in; out holds n + 1 words (out[n_live] = total).  sums: ceil(n / 2048) words.
+inline void scan_exclusive_u32(const uint32_t* in, uint32_t* out, uint32_t n, const uint32_t* n_dev, uint32_t* sums,
+                               hipStream_t st, uint32_t* chunk_first = nullptr, uint32_t chunk_len = 1,
+                               uint32_t chunk_cap = 0) {
+  if (n == 0) { (void)hipMemsetAsync(out, 0, sizeof(uint32_t), st); return; }
+  if (n <= (2u << 20)) {
+    const uint32_t nb = (n + 2047) / 2048;
+    hipLaunchKernelGGL((k_scan_partial<8>), dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, n_dev, sums);
+    hipLaunchKernelGGL((k_scan_apply_carry<8>), dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, n_dev, (const uint32_t*)sums,
+                       chunk_first, chunk_len, chunk_cap);
+  } else {
+    const uint32_t nb = (n + 4095) / 4096;
+    hipLaunchKernelGGL((k_scan_partial<16>), dim3(nb), dim3(SCAN_THREADS), 0, st, in, n, n_dev, sums);
+    hipLaunchKernelGGL((k_scan_apply_carry<16>), dim3(nb), dim3(SCAN_THREADS), 0, st, in, out, n, n_dev, (const uint32_t*)sums,
+                       chunk_first, chunk_len, chunk_cap);
+  }
+}
 
 // ---- stable LSD radix sort pass over (key,val) pairs ------------------------------------------------
 constexpr int RS_THREADS = 256;
@@ -93,22 +180,45 @@ constexpr int RS_WAVES = 4;
 // 8 (2048 per block: twice the blocks -- a 1 M-key pass is latency-bound and 245 blocks do not even cover the 256 CUs)
 constexpr int RS_ROUNDS_MAX = 16;
 constexpr int RS_ROUNDS_MIN = 8;
-constexpr int RS_BINS = 256;            // bins of a digit: at most 8 bits
+constexpr int RS_BINS = 256;            // bins of a host-specified digit (tile sort, test hooks): at most 8 bits
+constexpr int RS_BINS_DEV = 2048;       // bins of a device-specified digit (depth sort): at most 11 bits
+constexpr uint32_t RS_DROP_KEY = 0xFFFFFFFFu;
 constexpr int rs_chunk(int rounds) { return RS_WAVES * rounds * 64; }
 
-// Which bits of the key a pass sorts on: digit = (key >> shift) & mask (mask + 1 <= RS_BINS bins).
+// Which bits of the key a pass sorts on.  dv == nullptr: (shift, mask) as given by the host, nothing subtracted.
+// dv != nullptr (depth sort): digit width w = dv[DV_W]; pass p sorts bits [p w, (p+1) w) of key - sub, where
+// sub = dv[DV_KMIN] in pass 0 (which stores the reduced keys) and 0 afterwards.
 struct DigitSpec {
+  const uint32_t* dv;
+  int pass;
   int shift;
   uint32_t mask;
 };
+__device__ __forceinline__ void resolve_digit(const DigitSpec& s, int& shift, uint32_t& mask, uint32_t& sub, int& w) {
+  if (s.dv) {
+    w = (int)s.dv[DV_W];
+    shift = s.pass * w;
+    mask = (1u << w) - 1u;
+    sub = s.pass == 0 ? s.dv[DV_KMIN] : 0u;
+  } else {
+    shift = s.shift; mask = s.mask; sub = 0u;
+    w = 32 - __clz(mask);
+  }
+}
 
-template <int RS_ROUNDS>
+// The depth keys' digit width from their range: three passes of w bits cover max - min.
+__device__ __forceinline__ uint32_t depth_digit_width(uint32_t kmin, uint32_t kmax) {
+  const uint32_t bits = kmax > kmin ? 32u - (uint32_t)__clz(kmax - kmin) : 1u;
+  return max(4u, (bits + 2u) / 3u);      // <= 11 for 32-bit keys; at least 16 bins so that tiny ranges stay sane
+}
+
+template <int RS_ROUNDS, int BINS>
 __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n,
                                                            const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                            uint32_t* __restrict__ table, uint32_t nb) {
   constexpr int RS_CHUNK = rs_chunk(RS_ROUNDS);
   constexpr int PER = RS_CHUNK / RS_THREADS;
-  __shared__ uint32_t h[RS_BINS];
+  __shared__ uint32_t h[BINS];
   const uint32_t base = blockIdx.x * RS_CHUNK;
   // the keys are requested before the live count is known (both come from memory: one round trip instead of two);
   // positions below the host-side bound n are always readable
@@ -120,13 +230,15 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_hist(const uint32_t* __res
   }
   if (n_dev) n = min(n, *n_dev);
   if (base >= n) return;                               // dead block: k_radix_rowscan never reads its column
-  const uint32_t nbins = ds.mask + 1u;
+  int shift, w; uint32_t mask, sub;
+  resolve_digit(ds, shift, mask, sub, w);
+  const uint32_t nbins = mask + 1u;
   for (uint32_t d = threadIdx.x; d < nbins; d += RS_THREADS) h[d] = 0;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const uint32_t idx = base + i * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(k[i] >> ds.shift) & ds.mask], 1u);
+    if (idx < n) atomicAdd(&h[((k[i] - sub) >> shift) & mask], 1u);
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < nbins; d += RS_THREADS) table[d * nb + blockIdx.x] = h[d];   // digit-major
@@ -140,9 +252,11 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restri
                                                               const uint32_t* __restrict__ n_dev, uint32_t chunk,
                                                               DigitSpec ds, uint32_t* __restrict__ rowsum) {
   if (n_dev) n = min(n, *n_dev);
+  int shift, w; uint32_t mask, sub;
+  resolve_digit(ds, shift, mask, sub, w);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t d = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);
-  if (d > ds.mask) return;
+  if (d > mask) return;
   const uint32_t nlive = (n + chunk - 1u) / chunk;
   uint32_t* row = table + (size_t)d * nb;
   uint32_t carry = 0;
@@ -164,42 +278,12 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_rowscan(uint32_t* __restri
   if (lane == 0) rowsum[d] = carry;
 }
 
-// Stable ranking of one wave's 64-element rounds by an (at most 8-bit) digit: rnk[j] = number of elements of this wave in
-// front of element (round j, this lane) with the same digit; cnt[d] (this wave's 256 counters in LDS, zero on entry)
-// ends up holding the wave's count of digit d.  `live` bit j: the element takes part.  Ballots, no per-thread counters.
-// digit_of(j): the digit of element (round j, this lane).
-template <int ROUNDS, class DigitOf>
-__device__ __forceinline__ void wave_rank_rounds(DigitOf digit_of, uint32_t live, int nrounds,
-                                                 volatile uint32_t* cnt, uint32_t (&rnk)[ROUNDS]) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int j = 0; j < ROUNDS; ++j) {
-    if (j < nrounds) {                               // wave-uniform
-      const bool keep = (live >> j) & 1u;
-      const uint32_t d = digit_of(j);
-      uint64_t peers = __ballot(keep);
-      // all eight bits a digit can have, unrolled (bits at and above the digit's width are 0 in every lane and leave
-      // `peers` as it is): a loop over the actual width costs more than the idle ballots
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
-      const uint32_t before = __popcll(peers & lt);
-      const uint32_t pre = keep ? cnt[d] : 0u;
-      __builtin_amdgcn_wave_barrier();
-      if (keep && before == 0) cnt[d] = pre + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-      rnk[j] = pre + before;
-    }
-  }
-}
-
 // table: per-digit exclusive-scanned rows [bins][nb] + rowsum[bins] (k_radix_rowscan).
 // iota != 0: values are the element indices (first pass of an argsort).
-template <int RS_ROUNDS>
+// drop != 0: keys equal to RS_DROP_KEY are not ranked and not written -- the output is the compacted list, whose
+//            length block 0 writes to *count_out.
+// keys_out may be null (the last pass of an argsort needs no keys); aux_src/aux_out: aux_out[g] = aux_src[val].
+template <int RS_ROUNDS, int BINS>
 __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __restrict__ keys_in,
                                                               const uint32_t* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out,
@@ -207,11 +291,15 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
                                                               const uint32_t* __restrict__ n_dev, DigitSpec ds,
                                                               const uint32_t* __restrict__ table,
                                                               const uint32_t* __restrict__ rowsum, uint32_t nb,
-                                                              int iota, uint32_t* __restrict__ key_ranges,
-                                                              uint32_t key_limit) {
+                                                              int iota, int drop, uint32_t* __restrict__ count_out,
+                                                              const uint32_t* __restrict__ aux_src,
+                                                              uint32_t* __restrict__ aux_out,
+                                                              uint32_t* __restrict__ key_ranges, uint32_t key_limit) {
   constexpr int RS_CHUNK = rs_chunk(RS_ROUNDS);
-  __shared__ uint32_t wcnt[RS_WAVES][RS_BINS];
-  __shared__ uint32_t gbase[RS_BINS];
+  constexpr int MAXW = BINS == 256 ? 8 : (BINS == 512 ? 9 : (BINS == 1024 ? 10 : 11));
+  static_assert(BINS == (1 << MAXW), "BINS is a power of two between 256 and 2048");
+  __shared__ uint32_t wcnt[RS_WAVES][BINS];
+  __shared__ uint32_t gbase[BINS];
   __shared__ uint32_t tmp[4];
   __shared__ uint32_t skey[RS_CHUNK];
   __shared__ uint32_t sval[RS_CHUNK];
@@ -225,47 +313,98 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const uint32_t idx = base + j * 64 + lane;
     const bool ok = idx < n;
-    key[j] = ok ? keys_in[idx] : 0u;
+    key[j] = ok ? keys_in[idx] : RS_DROP_KEY;
     val[j] = iota ? idx : (ok ? vals_in[idx] : 0u);
   }
   if (n_dev) n = min(n, *n_dev);
-  if (blk0 >= n) return;
-  const int shift = ds.shift;
-  const uint32_t mask = ds.mask, nbins = mask + 1u;
-  // This block's column of the scanned table and the row totals (digit d = tid) are requested now and used after the
-  // ranking loop: they used to be fetched one dependent round trip at a time between the workgroup barriers
-  const bool in = (uint32_t)tid < nbins;
-  const uint32_t tcol = in ? table[(uint32_t)tid * nb + blockIdx.x] : 0u;
-  const uint32_t rsum = in ? rowsum[tid] : 0u;
+  if (blk0 >= n) {
+    if (n == 0 && blockIdx.x == 0 && tid == 0 && count_out) *count_out = 0u;
+    return;
+  }
+  int shift, w; uint32_t mask, sub;
+  resolve_digit(ds, shift, mask, sub, w);
+  const uint32_t nbins = mask + 1u;
+  // This block's column of the scanned table and the row totals (digit d = tid + 256 i) are requested now and used
+  // after the ranking loop: they used to be fetched one dependent round trip at a time between the workgroup barriers
+  // of the digit phase.
+  constexpr int DPT = BINS / RS_THREADS;             // digits per thread
+  uint32_t tcol[DPT], rsum[DPT];
 #pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) wcnt[i][tid] = 0;
+  for (int i = 0; i < DPT; ++i) {
+    const uint32_t d = (uint32_t)tid + (uint32_t)i * RS_THREADS;
+    const bool in = d < nbins;
+    tcol[i] = in ? table[d * nb + blockIdx.x] : 0u;
+    rsum[i] = in ? rowsum[d] : 0u;
+  }
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) {
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) wcnt[i][d] = 0;
+  }
   __syncthreads();
 
   uint32_t live = 0;                                 // bit j: element j of this thread takes part
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
-    live |= (base + j * 64 + lane < n ? 1u : 0u) << j;
+    const uint32_t idx = base + j * 64 + lane;
+    const bool keep = idx < n && !(drop && key[j] == RS_DROP_KEY);
+    key[j] -= sub;
+    live |= (keep ? 1u : 0u) << j;
   }
-  wave_rank_rounds<RS_ROUNDS>([&](int j) { return (key[j] >> shift) & mask; }, live, RS_ROUNDS, wcnt[wv], rnk);
+  const uint64_t lt = (1ull << lane) - 1ull;
+  volatile uint32_t* myc = wcnt[wv];
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const bool keep = (live >> j) & 1u;
+    const uint32_t d = (key[j] >> shift) & mask;
+    uint64_t peers = __ballot(keep);
+    // all the bits a digit of this kernel can have, unrolled (bits at and above the digit's width are 0 in every lane
+    // and leave `peers` as it is): a loop over the actual width costs more than the two or three idle ballots
+#pragma unroll
+    for (int b = 0; b < MAXW; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t before = __popcll(peers & lt);
+    const uint32_t pre = keep ? myc[d] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (keep && before == 0) myc[d] = pre + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rnk[j] = pre + before;
+  }
   __syncthreads();
-  uint32_t nvalid;
+  uint32_t nvalid = 0;
   {
-    // thread = digit: start of the digit in the block-local order, per-wave bases, and the digit's global base
-    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-    uint32_t all;
-    const uint32_t dsl = block_excl_scan_256(c0 + c1 + c2 + c3, tmp, nvalid);
-    const uint32_t dbase = block_excl_scan_256(rsum, tmp, all);       // smaller digits, globally
-    wcnt[0][tid] = dsl;
-    wcnt[1][tid] = dsl + c0;
-    wcnt[2][tid] = dsl + c0 + c1;
-    wcnt[3][tid] = dsl + c0 + c1 + c2;
-    gbase[tid] = dbase + tcol - dsl;
+    // thread = digit (BINS / 256 digits per thread, 256 at a time): start of the digit in the block-local order,
+    // per-wave bases, and the digit's global base
+    uint32_t carry_l = 0, carry_g = 0;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const uint32_t d = (uint32_t)tid + (uint32_t)i * RS_THREADS;
+      if ((uint32_t)i * RS_THREADS >= nbins) break;      // uniform
+      const bool in = d < nbins;
+      const uint32_t c0 = in ? wcnt[0][d] : 0u, c1 = in ? wcnt[1][d] : 0u, c2 = in ? wcnt[2][d] : 0u, c3 = in ? wcnt[3][d] : 0u;
+      uint32_t total, all;
+      const uint32_t dsl = carry_l + block_excl_scan_256(c0 + c1 + c2 + c3, tmp, total);
+      const uint32_t dbase = carry_g + block_excl_scan_256(in ? rsum[i] : 0u, tmp, all);   // smaller digits, globally
+      if (in) {
+        wcnt[0][d] = dsl;
+        wcnt[1][d] = dsl + c0;
+        wcnt[2][d] = dsl + c0 + c1;
+        wcnt[3][d] = dsl + c0 + c1 + c2;
+        gbase[d] = dbase + tcol[i] - dsl;
+      }
+      carry_l += total; carry_g += all;
+    }
+    nvalid = carry_l;
+    if (count_out && blockIdx.x == 0 && tid == 0) *count_out = carry_g;
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     if ((live >> j) & 1u) {
-      const uint32_t p = wcnt[wv][(key[j] >> shift) & mask] + rnk[j];
+      const uint32_t d = (key[j] >> shift) & mask;
+      const uint32_t p = wcnt[wv][d] + rnk[j];
       skey[p] = key[j];
       sval[p] = val[j];
     }
@@ -274,8 +413,10 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
   for (uint32_t p = tid; p < nvalid; p += RS_THREADS) {
     const uint32_t k = skey[p];
     const uint32_t g = gbase[(k >> shift) & mask] + p;
+    const uint32_t v = sval[p];
     if (keys_out) keys_out[g] = k;
-    vals_out[g] = sval[p];
+    vals_out[g] = v;
+    if (aux_out) aux_out[g] = aux_src[v];
     if (key_ranges && k < key_limit) {
       // LAST pass of a sort on the whole key: equal keys end up contiguous, [key_ranges[2k], key_ranges[2k+1]) is key
       // k's span of the output.  A run of equal keys inside this block's sorted chunk is a piece of that span (pieces of
@@ -287,8 +428,8 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
   }
 }
 
-inline uint32_t radix_table_words(uint32_t n) {
-  return RS_BINS * ((n + rs_chunk(RS_ROUNDS_MIN) - 1) / rs_chunk(RS_ROUNDS_MIN));
+inline uint32_t radix_table_words(uint32_t n, uint32_t bins = RS_BINS) {
+  return bins * ((n + rs_chunk(RS_ROUNDS_MIN) - 1) / rs_chunk(RS_ROUNDS_MIN));
 }
 
 inline int radix_rounds_for(uint32_t n) {
@@ -299,29 +440,33 @@ inline int radix_rounds_for(uint32_t n) {
   return n <= (4u << 20) ? RS_ROUNDS_MIN : RS_ROUNDS_MAX;
 }
 
-// One pass, all three launches (hist may be skipped when the caller has filled `table` itself -- k_emit does for the
-// first tile pass).
+// One pass with a host-specified digit, all three launches (hist may be skipped when the caller has filled `table`
+// itself -- k_emit does for the first tile pass).
+template <int BINS>
 inline void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n,
                        const uint32_t* n_dev, const DigitSpec& ds, int rounds, uint32_t* table, uint32_t* sums, bool hist,
-                       int iota, hipStream_t st, uint32_t* key_ranges = nullptr, uint32_t key_limit = 0) {
+                       int iota, int drop, uint32_t* count_out, const uint32_t* aux_src, uint32_t* aux_out,
+                       hipStream_t st, uint32_t* key_ranges = nullptr, uint32_t key_limit = 0) {
   const uint32_t chunk = (uint32_t)rs_chunk(rounds);
   const uint32_t nb = (n + chunk - 1) / chunk;
   if (rounds == RS_ROUNDS_MIN) {
-    if (hist) hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MIN>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, n_dev, ds, table, nb);
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_BINS / RS_WAVES), dim3(RS_THREADS), 0, st, table, nb, n, n_dev, chunk, ds, sums);
-    hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MIN>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, n_dev, ds,
-                       (const uint32_t*)table, (const uint32_t*)sums, nb, iota, key_ranges, key_limit);
+    if (hist) hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MIN, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, n_dev, ds, table, nb);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(BINS / RS_WAVES), dim3(RS_THREADS), 0, st, table, nb, n, n_dev, chunk, ds, sums);
+    hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MIN, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, n_dev, ds,
+                       (const uint32_t*)table, (const uint32_t*)sums, nb, iota, drop, count_out, aux_src, aux_out,
+                       key_ranges, key_limit);
   } else {
-    if (hist) hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MAX>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, n_dev, ds, table, nb);
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(RS_BINS / RS_WAVES), dim3(RS_THREADS), 0, st, table, nb, n, n_dev, chunk, ds, sums);
-    hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MAX>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, n_dev, ds,
-                       (const uint32_t*)table, (const uint32_t*)sums, nb, iota, key_ranges, key_limit);
+    if (hist) hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MAX, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, n_dev, ds, table, nb);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(BINS / RS_WAVES), dim3(RS_THREADS), 0, st, table, nb, n, n_dev, chunk, ds, sums);
+    hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MAX, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, n_dev, ds,
+                       (const uint32_t*)table, (const uint32_t*)sums, nb, iota, drop, count_out, aux_src, aux_out,
+                       key_ranges, key_limit);
   }
 }
 
-// Sorts on key bits [begin_bit, end_bit) with 8-bit (or narrower) digits.  Buffers ping-pong; returns 0 if the result
-// is in (k0,v0), 1 if in (k1,v1).  iota_first: the values of the first pass are the element indices (v0 is then never
-// read).  first_hist_done: `table` already holds the first pass's per-block histogram.
+// Sorts on key bits [begin_bit, end_bit) with host-specified 8-bit (or narrower) digits.  Buffers ping-pong; returns
+// 0 if the result is in (k0,v0), 1 if in (k1,v1).  iota_first: the values of the first pass are the element indices
+// (v0 is then never read).  first_hist_done: `table` already holds the first pass's per-block histogram.
 // key_ranges != nullptr (and begin_bit == 0, end_bit covering every key below key_limit): the last pass also leaves the
 // span [start, end) of every key value below key_limit in key_ranges[2 key .. 2 key + 1], which the caller has set to
 // (0xFFFFFFFF, 0).
@@ -337,12 +482,13 @@ inline int radix_sort_pairs(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* 
   for (int p = 0; p < passes; ++p) {
     // spread the bits evenly over the passes (13 bits -> 7 + 6): longer digit runs per block
     const int w = (bits - (bit - begin_bit) + (passes - p) - 1) / (passes - p);
-    DigitSpec ds{bit, (1u << w) - 1u};
+    DigitSpec ds{nullptr, p, bit, (1u << w) - 1u};
     uint32_t* ki = cur ? k1 : k0; uint32_t* vi = cur ? v1 : v0;
     uint32_t* ko = cur ? k0 : k1; uint32_t* vo = cur ? v0 : v1;
     const bool last = p == passes - 1;
-    radix_pass(ki, vi, ko, vo, n, n_dev, ds, rounds, table, sums, !(p == 0 && first_hist_done),
-               (iota_first && p == 0) ? 1 : 0, st, last ? key_ranges : nullptr, key_limit);
+    radix_pass<RS_BINS>(ki, vi, ko, vo, n, n_dev, ds, rounds, table, sums, !(p == 0 && first_hist_done),
+                        (iota_first && p == 0) ? 1 : 0, 0, nullptr, nullptr, nullptr, st, last ? key_ranges : nullptr,
+                        key_limit);
     cur ^= 1;
     bit += w;
   }

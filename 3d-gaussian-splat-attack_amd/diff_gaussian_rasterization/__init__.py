@@ -144,6 +144,8 @@ def _load():
     lib.gsr_pgd_step.restype = ctypes.c_int
     lib.gsr_pgd_step.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_int32, vp]
+    lib.gsr_test_scan.restype = ctypes.c_int
+    lib.gsr_test_scan.argtypes = [vp, vp, ctypes.c_uint32, vp]
     lib.gsr_test_sort_pairs.restype = ctypes.c_int
     lib.gsr_test_sort_pairs.argtypes = [vp, vp, ctypes.c_uint32, i32, i32, i32, vp]
     lib.gsr_last_error.restype = ctypes.c_char_p
@@ -714,7 +716,7 @@ def last_num_rendered(output: torch.Tensor) -> int:
 
 
 _EXPORTS = {"ranges": (0, torch.int32), "pair_rank": (1, torch.int32), "n_contrib": (2, torch.int32),
-            "final_T": (3, torch.float32),
+            "final_T": (3, torch.float32), "order": (4, torch.int32), "off": (5, torch.int32),
             "R": (7, torch.float32), "G": (7, torch.float32), "dv": (8, torch.int32), "offg": (9, torch.int32)}
 
 
@@ -726,13 +728,17 @@ def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
     P = int(fn.kept[0].shape[0])
     H, W = fn.pack.c.image_height, fn.pack.c.image_width
     T = ((W + 15) // 16) * ((H + 15) // 16)
-    n = {"ranges": 2 * T, "pair_rank": holder.info(0), "n_contrib": H * W, "final_T": H * W,
-         "R": 12 * P, "G": 12 * P, "dv": 16, "offg": P + 1}[name]
+    n = {"ranges": 2 * T, "pair_rank": holder.info(0), "n_contrib": H * W, "final_T": H * W, "order": P,
+         "off": P + 1, "R": 12 * P, "G": 12 * P, "dv": 16, "offg": P + 1}[name]
+    live = None
+    if name in ("order", "off") and P > 0:
+        # only the Gaussians that emit pairs are ranked: dv[1] = V of them (order[:V], off[:V + 1] are meaningful)
+        live = int(export_state(output, "dv")[1].item()) + (1 if name == "off" else 0)
     dst = torch.empty(max(n, 1), dtype=dt, device=output.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(output.device).cuda_stream)
     if holder.lib.gsr_ctx_export(holder.handle, what, dst.data_ptr(), dst.numel() * 4, stream) != 0:
         raise RuntimeError(_err(holder.lib))
-    return dst[:n]
+    return dst[:n if live is None else live]
 
 
 def profile(enable, stages=None) -> None:

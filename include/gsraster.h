@@ -63,14 +63,13 @@ enum {
 #define GSR_FLAG_TILE_MAP(m) ((uint32_t)(((m) & 3u) + 1u) << 12)
 #define GSR_FLAG_NO_SEGMENTS (1u << 16)
 #define GSR_FLAG_FWD_SHARED (1u << 17)
-/* The pair count.  The number of (tile, Gaussian) pairs N is a device-side result; the host sizes the pair buffers and
- * the grids behind it from a bound.  A forward whose (P, H, W) has been rendered before on this device is enqueued whole
- * against the largest count those earlier forwards saw, plus 25 % + 64 K pairs of head-room, and the host reads the real
- * count afterwards (it has landed by then); a count above the capacity re-enqueues everything behind the scan with the
- * exact size.  The first forward of a size counts first and waits once.  GSR_SPECULATE=0 in the environment restores
- * "always count first".  With GSR_FLAG_ASYNC_COUNT the host never looks: *num_rendered is then -1 (ask
- * gsr_ctx_info(ctx, 0) later), and if the scene emits more pairs than the capacity nothing is composited, out_color is
- * filled with NaN and gsr_backward returns GSR_ERR_OVERFLOW (the next forward of that size has the larger capacity). */
+/* Asynchronous pair count.  By default gsr_forward waits (once, early, behind work it has already enqueued) for the
+ * number of (tile, Gaussian) pairs before it sizes the pair buffers -- the only host synchronisation of the path.
+ * With this flag a forward whose (P, H, W) has been rendered before on this device sizes them from the count that
+ * earlier forward saw, plus 25 % + 64 K pairs of head-room, and never waits: *num_rendered is then -1 (ask
+ * gsr_ctx_info(ctx, 0) later).  If the scene emits more pairs than that capacity, nothing is composited, out_color is
+ * filled with NaN, gsr_backward on the context returns GSR_ERR_OVERFLOW, and the next forward counts synchronously
+ * again.  Opt-in: a caller that never looks at the image or calls gsr_backward would not notice an overflow. */
 #define GSR_FLAG_ASYNC_COUNT (1u << 18)
 /* gsr_forward runs the colour half of its per-Gaussian stage (SH -> RGB) on a library-owned side stream, beside the
  * binning chain of the same view, and joins it before compositing (events; the caller's stream semantics are
@@ -224,12 +223,12 @@ int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
 
 /* Copies one internal array of a context into a caller DEVICE buffer (tests / diagnostics):
  * what 0 = tile ranges [T][2] u32, 1 = sorted pair list [N] u32 (Gaussian index | strip mask << 28, tile by tile, depth
- * order = (depth key, Gaussian index) inside a tile), 2 = n_contrib [H*W] u32, 3 = final_T [H*W] f32, (4, 5: the global
- * depth order of rounds 1-3 -- gone, GSR_ERR_INVALID), 7 (and, for old callers, 6) = splat records [P][3] float4 in
- * storage order (layout: csrc/gsr_kernels.hip.h; written for Gaussians that emit pairs), 8 = the forward's device-side
- * scalars [16] u32 (0 pairs, 1 V = Gaussians that emit pairs, 2 tiles with >= 4095 list entries, 3 tiles with > 512,
- * 4 overflow flag, 5 boundary records, 6-7 64-bit pair count), 9 = offg [P+1] u32 (storage-order scan of tiles touched:
- * numbers the emitted pairs and the backward's partial rows). */
+ * order inside a tile), 2 = n_contrib [H*W] u32, 3 = final_T [H*W] f32, 4 = order (depth rank -> Gaussian; the first
+ * V = scalars[1] entries are meaningful: only Gaussians that emit pairs are ranked) [P] u32, 5 = off [P+1] u32 (pairs
+ * emitted in front of rank r; V+1 entries), 7 (and, for old callers, 6) = splat records [P][3] float4 in storage order
+ * (layout: csrc/gsr_kernels.hip.h; written for Gaussians that emit pairs), 8 = the forward's device-side scalars [16]
+ * u32 (0 pairs, 1 V, 2 smallest depth key, 3 depth digit width, 4 overflow flag, 5 boundary records, 6-7 64-bit pair
+ * count), 9 = offg [P+1] u32 (storage-order scan of tiles touched). */
 int gsr_ctx_export(const GsrCtx* ctx, int32_t what, void* dst, int64_t dst_bytes, void* stream);
 
 /* Frees every cached workspace block of the current device (blocks in use by live contexts are kept). */
@@ -241,8 +240,8 @@ void gsr_trim_pool(void);
  * ms[GSR_STAGE_COUNT] with accumulated milliseconds and calls[GSR_STAGE_COUNT] with launch counts. */
 enum {
   GSR_STAGE_PREPROCESS = 0,
-  GSR_STAGE_DEPTH_SORT = 1, /* tile schedule + depth order inside every tile's list (per-tile LDS sort) */
-  GSR_STAGE_BIN = 2,       /* storage scan + emit */
+  GSR_STAGE_DEPTH_SORT = 1,
+  GSR_STAGE_BIN = 2,       /* pack + scan + emit */
   GSR_STAGE_TILE_SORT = 3, /* + tile ranges */
   GSR_STAGE_RENDER_FWD = 4,
   GSR_STAGE_RENDER_BWD = 5,
@@ -268,9 +267,11 @@ int gsr_debug_wave_clock(unsigned long long* buf);
 /* Same for the forward composite (K6): [ntiles * waves per tile][2]. */
 int gsr_debug_wave_clock_fwd(unsigned long long* buf);
 
-/* Test hook (used by tests/ only): the sort primitive of the binning stage on caller buffers.
+/* Test hooks (used by tests/ only): the scan and sort primitives of the binning stage on caller buffers.
+ * gsr_test_scan: out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total), uint32.
  * gsr_test_sort_pairs: stable ascending sort of (keys, vals) on key bits [begin_bit, end_bit), in place;
  *                      iota != 0: vals are ignored on input and the result is the sorting permutation. */
+int gsr_test_scan(const uint32_t* in, uint32_t* out, uint32_t n, void* stream);
 int gsr_test_sort_pairs(uint32_t* keys, uint32_t* vals, uint32_t n, int32_t begin_bit, int32_t end_bit, int32_t iota,
                         void* stream);
 

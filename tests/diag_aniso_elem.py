@@ -23,7 +23,13 @@ keys = T.hip_depth_keys(inp, cam, bg, kw["sh_degree"], kw["scale_modifier"])
 ref, rg = O.forward_backward(inp, st, gc, None, dtype=torch.float64, drop_fragile=True, depth_key=keys)
 gc, _ = O.solid_grads(ref, gc, None)
 r32, rg32 = O.forward_backward(inp, st, gc, None, dtype=torch.float32, drop_fragile=False, depth_key=keys)
+import diff_gaussian_rasterization as D
 color, radii, _, grads = T.run_hip(inp, cam, bg, gc, None, kw["sh_degree"], kw["scale_modifier"])
+variants = {}
+for name, fl in (("no segments", D.FLAG_NO_SEGMENTS), ("no cull", D.FLAG_NO_CULL), ("bwd split 2", D.flag_bwd_split(2)),
+                 ("fwd split 4", D.flag_fwd_split(4)), ("fwd split 1, bwd split 2", D.flag_fwd_split(1) | D.flag_bwd_split(2))):
+    with D.extra_flags(fl):
+        variants[name] = T.run_hip(inp, cam, bg, gc, None, kw["sh_degree"], kw["scale_modifier"])[3]
 print(f"seed {seed} {desc} sh_degree {kw['sh_degree']} scale_modifier {kw['scale_modifier']:.3f} fragile px {float(ref.fragile_px.float().mean()):.3f}")
 a, b, c = grads[group].detach().double().cpu(), rg[group].double(), rg32[group].double()
 scale = b.abs().max().item()
@@ -42,5 +48,7 @@ for idx in torch.nonzero(off).tolist():
           f"f32 {abs(c[j]-b[j]).item()/abs(b[j]).item():.2e}")
     print(f"    Gaussian {i}: scales {sc[0]:.4f} {sc[1]:.4f} {sc[2]:.4f}  opacity {inp['opacities'][i].item():.3f} radius {int(geo.radii[i])} rect {rect} "
           f"conic ({con[0]:.3e}, {con[1]:.3e}, {con[2]:.3e}) det {det:.3e}  aniso {max(con[0], con[2]) / max(det / max(con[0], con[2]), 1e-30):.1e} fragile {bool(geo.fragile[i])}")
+    for name, gv in variants.items():
+        print(f"    [{name}] hip {gv[group].detach().double().cpu()[j].item():+.6e}")
     full = {k: (grads[k][i].detach().cpu().flatten()[:4].tolist(), rg[k][i].flatten()[:4].tolist()) for k in ("means3D", "means2D", "opacities")}
     print("    its other gradients (hip, f64):", full)

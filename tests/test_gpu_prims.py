@@ -1,4 +1,4 @@
-"""Stable radix sort of the binning stage, through the C ABI test hook: bit-exact vs torch."""
+"""Scan and stable radix sort of the binning stage, through the C ABI test hooks: bit-exact vs torch."""
 import ctypes
 
 import pytest
@@ -15,6 +15,18 @@ def _lib():
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 100_000, 1_234_567, 20_000_001])
+def test_exclusive_scan(n):
+    lib, D = _lib()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 1000, (n,), generator=g, dtype=torch.int32).cuda()
+    out = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    rc = lib.gsr_test_scan(x.data_ptr(), out.data_ptr(), n, _stream())
+    assert rc == 0, D._err(lib)
+    ref = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(x.cpu().long(), 0)])
+    assert torch.equal(out.cpu().long() & 0xFFFFFFFF, ref & 0xFFFFFFFF)     # 32-bit prefix sums (the 20 M case wraps)
 
 
 @pytest.mark.parametrize("n,lo,hi", [(1, 0, 32), (1000, 0, 32), (4096, 0, 13), (4097, 0, 8), (300_001, 0, 32),

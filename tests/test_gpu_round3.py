@@ -450,8 +450,8 @@ def _check_lists_against_stable_argsort(D, out):
 
 
 def test_depth_range_that_needs_the_widest_digits_sorts_exactly():
-    """View depths from 0.25 to 3e5: max - min of the float keys of a tile's list spans 30+ bits, so its depth ordering takes
-    all four 8-bit passes (the benchmark scene: three).  The order must be the stable argsort of the float32 depth."""
+    """View depths from 0.25 to 3e5: max - min of the float keys spans 30+ bits, so the three depth passes use 10/11-bit
+    digits (the benchmark scene: 9).  Every tile's list must be in the order of the stable argsort of the float32 depth."""
     D = _hip()
     dev = torch.device("cuda:0")
     P = 40000
@@ -462,6 +462,12 @@ def test_depth_range_that_needs_the_widest_digits_sorts_exactly():
     xyz = torch.cat([xy * z[:, None], z[:, None]], dim=1)
     scale = torch.log(0.01 * z)[:, None].expand(P, 3).contiguous()      # ~1.7 px on screen whatever the depth
     model, cam, out = _raw_render(D, dev, xyz, scale, torch.zeros(P, 1), flags=D.FLAG_NO_CULL)
+    dv = D.export_state(out["render"], "dv")
+    assert int(dv[3]) >= 10, f"digit width {int(dv[3])}"
+    order = D.export_state(out["render"], "order").long()
+    depth = D.export_state(out["render"], "G").view(-1, 12)[:, 9]
+    ids = torch.nonzero(out["radii"] > 0).flatten()
+    assert torch.equal(order, ids[torch.argsort(depth[ids], stable=True)])
     _check_lists_against_stable_argsort(D, out)
 
 

@@ -210,70 +210,3 @@ def test_anisotropic_splats_against_the_float32_yardstick(seed):
     y = T.check.last_yardstick
     print(f"aniso seed {seed} {desc}: hip image err {y['worst_any']:.2e}, float32 oracle {y['f32_vs_f64']:.2e}; "
           + ", ".join(f"{k} {v[0]:.1e}/{v[2]:.1e}" for k, v in rep.items()))
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# Round 4 binning: pairs emitted in storage order, depth order made per tile in LDS (csrc/gsr_tilesort.hip.h)
-# ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("P,W,H,tier", [(700, 48, 32, "one wave per list"), (3000, 32, 32, "eight waves per list"),
-                                        (9000, 32, 16, "1024-thread workgroup, LDS"),
-                                        (40000, 16, 16, "bitonic network in global memory"),
-                                        (20000, 80, 48, "all tiers in one view")])
-def test_every_tier_of_the_per_tile_depth_sort(P, W, H, tier):
-    """Lists of a few hundred, a few thousand, ~9000 and ~40000 entries: every path of k_tile_depth_sort /
-    k_tile_depth_sort_huge must leave each tile's list in the order of a stable argsort of the float32 depths (ties every
-    seventh Gaussian), and the image must not depend on which tier sorted a list."""
-    import math
-    D = _hip()
-    import test_gpu_round3 as R3
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(P)
-    z = 2.0 + torch.rand(P, generator=g) * (6.0 if tier != "all tiers in one view" else 60.0)
-    z[::7] = z[3]                                           # exact ties: the storage index decides
-    spread = 0.35 if tier != "all tiers in one view" else 0.6
-    xy = (torch.rand(P, 2, generator=g) - 0.5) * spread
-    if tier == "all tiers in one view":
-        xy[: P // 2] *= 0.05                                # half of the splats on the centre tiles: lists of thousands
-    xyz = torch.cat([xy * z[:, None], z[:, None]], dim=1)
-    scale = torch.log(0.02 * z)[:, None].expand(P, 3).contiguous()
-    model, cam, out = R3._raw_render(D, dev, xyz, scale, torch.full((P, 1), -2.0), W=W, H=H, grad=False)
-    ranges = D.export_state(out["render"], "ranges").view(-1, 2).long()
-    longest = int((ranges[:, 1] - ranges[:, 0]).max())
-    dv = D.export_state(out["render"], "dv")
-    print(f"{tier}: longest list {longest}, tiles over one wave {int(dv[3])}, huge {int(dv[2])}")
-    want = {"one wave per list": (2, 512), "eight waves per list": (513, 4094), "1024-thread workgroup, LDS": (4095, 16384),
-            "bitonic network in global memory": (16385, 10 ** 9), "all tiers in one view": (4095, 10 ** 9)}[tier]
-    assert want[0] <= longest <= want[1], longest
-    R3._check_lists_against_stable_argsort(D, out)
-    assert bool(torch.isfinite(out["render"]).all())
-
-
-def test_a_view_with_more_pairs_than_the_earlier_views_promised_is_enqueued_again():
-    """The forward is enqueued against the pair count of earlier views of the same (P, H, W) + 25 %; a view that emits
-    more gets everything behind the storage scan enqueued a second time with the exact count.  Same bits as the view
-    rendered when the capacity is already large enough, same bits as counting first (GSR_SPECULATE=0 in a fresh size)."""
-    D = _hip()
-    from gsplat_attack.renderer import PipelineParams, render
-    dev, model, cams = _small_scene(n_views=2, P=50000, w=640, h=360)
-    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
-    gc = torch.randn(3, 360, 640, generator=torch.Generator().manual_seed(5)).to(dev)
-    pipe = PipelineParams(skip_objects=True)
-
-    def run(scale):
-        model.zero_grad()
-        out = render(cams[0], model, pipe, bg, scale)
-        out["render"].backward(gc)
-        torch.cuda.synchronize()
-        return (out["render"].detach().clone(), {n: getattr(model, n).grad.clone() for n in D.GradBucket.NAMES},
-                D.last_num_rendered(out["render"]))
-    img0, g0, n0 = run(1.0)                                # first view of this size: counts first, leaves n0 behind
-    img1, g1, n1 = run(4.0)                                # enqueued against 1.25 n0 + 64K: too small -> second pass
-    assert n1 > 1.25 * n0 + 65536 and bool(torch.isfinite(img1).all())
-    img2, g2, n2 = run(4.0)                                # now the capacity holds
-    assert n2 == n1 and torch.equal(img1, img2)
-    for n in g1:
-        assert torch.equal(g1[n], g2[n]), n
-    img3, g3, n3 = run(1.0)                                # and a smaller view under the larger capacity
-    assert n3 == n0 and torch.equal(img0, img3)
-    for n in g0:
-        assert torch.equal(g0[n], g3[n]), n
