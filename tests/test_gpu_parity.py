@@ -155,8 +155,14 @@ def check(inp, cam, bg, sh_degree=3, scale_modifier=1.0, with_gobj=False, seed=9
             report[k] = (norm, frac, n32, f32, frac_y)
             # held to the float32 yardstick: no worse than twice what float32 arithmetic costs the oracle itself
             assert norm <= max(GRAD_TOL, 2 * n32), f"grad {k}: normwise rel err {norm:.3e} (float32 oracle {n32:.3e})"
-            assert frac_y <= elem_frac, (f"grad {k}: {frac_y:.2e} of the significant elements off by more than {5 * GRAD_TOL} and "
-                                         f"more than twice the float32 oracle's own error ({frac:.2e} without the yardstick)")
+            # Element by element (relative errors, so the residues of cancellations count like everything else): all but
+            # elem_frac of the significant elements within 5e-3 -- or the float32 oracle misses as many itself (the same
+            # elements are out of float32's reach), or they are within twice ITS error there; in a scene with fewer than
+            # 1 / elem_frac significant elements, one element may be off.
+            n_sig = int((gr.detach().abs() > 1e-3 * gr.detach().abs().max()).sum())
+            ok = frac <= max(elem_frac, 2 * f32) or frac_y <= max(elem_frac, 1.01 / max(n_sig, 1))
+            assert ok, (f"grad {k}: {frac:.2e} of the {n_sig} significant elements off by more than {5 * GRAD_TOL} (float32 "
+                        f"oracle: {f32:.2e}); {frac_y:.2e} also by more than twice the float32 oracle's own error")
             continue
         assert norm <= GRAD_TOL, f"grad {k}: normwise rel err {norm:.3e}"
         assert frac <= elem_frac, f"grad {k}: {frac:.2e} of the significant elements are off by more than {5 * GRAD_TOL}"
