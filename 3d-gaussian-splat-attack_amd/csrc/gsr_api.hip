@@ -895,7 +895,6 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   const uint32_t N = c->nbound;
   void* part_blk = nullptr;
   void* pobj_blk = nullptr;
-  void* flag_blk = nullptr;
   float4* part = nullptr;
   float4* part_obj = nullptr;
   // K7 runs one wave per 16x(4*npx) part of a tile; each writes its own partial row per list entry (4 pixels per lane:
@@ -909,15 +908,14 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   if (N > 0) {
     part_blk = pool_alloc(dev, sizeof(float4) * PART_F4 * (size_t)N * nsub, st);
     if (obj) pobj_blk = pool_alloc(dev, sizeof(float4) * 4 * (size_t)N * nsub, st);
-    flag_blk = pool_alloc(dev, (size_t)N * nsub, st);            // one byte per partial row (never cleared, like the rows)
-    if (!part_blk || (obj && !pobj_blk) || !flag_blk) {
-      pool_free(dev, part_blk); pool_free(dev, pobj_blk); pool_free(dev, flag_blk);
+    if (!part_blk || (obj && !pobj_blk)) {
+      pool_free(dev, part_blk); pool_free(dev, pobj_blk);
       return set_err(GSR_ERR_NOMEM, "gsr_backward: partial-gradient buffer (N=%u) allocation failed", N);
     }
     part = static_cast<float4*>(part_blk);
     part_obj = static_cast<float4*>(pobj_blk);
   }
-  auto done = [&](int code) { pool_free(dev, part_blk); pool_free(dev, pobj_blk); pool_free(dev, flag_blk); return code; };
+  auto done = [&](int code) { pool_free(dev, part_blk); pool_free(dev, pobj_blk); return code; };
   // 64-bit tag of this call: K7 stamps it into every partial row it writes, K8/K9 ignores rows without it
   static std::atomic<uint64_t> tag_counter{0x243F6A8885A308D3ull};
   uint64_t z = tag_counter.fetch_add(0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
@@ -934,7 +932,6 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.wave_clock = g_wave_clock.load();
     ra.gridx = c->gridx; ra.ntiles = c->ntiles; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
     ra.grad_color = grad_color; ra.grad_objects = obj ? grad_objects : nullptr; ra.part = part; ra.part_obj = part_obj;
-    ra.rflag = static_cast<uint8_t*>(flag_blk);
     // split tiles: one extra work item per boundary record, in front of the per-tile items
     const bool segs = c->bnd != nullptr && !obj;
     ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->dv + DV_NREC;
@@ -969,7 +966,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     PreBwdArgs pa;
     pa.P = P; pa.g0 = 0; pa.K = c->K; pa.va = view_args(c->st);
     pa.offg = c->offg; pa.G0 = c->G0; pa.G1 = c->G1; pa.G2 = c->G2;
-    pa.part = part; pa.part_obj = obj ? part_obj : nullptr; pa.rflag = static_cast<const uint8_t*>(flag_blk);
+    pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
     pa.tag_lo = tag_lo; pa.tag_hi = tag_hi; pa.nsub = nsub;
     pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
     pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc; pa.D = c->D;

@@ -871,7 +871,6 @@ struct RenderBwdArgs {
   const float* grad_objects;  // [16,H,W] or null
   float4* part;               // [N][3]
   float4* part_obj;           // [N][4] or null
-  uint8_t* rflag;             // [N] one byte per row: the low byte of the tag of the call that wrote the row last
   // split tiles (see "Segments"): the first extra_blocks workgroups are the extra work items, one per boundary record
   const float4* bnd;          // null: no tile is split
   const uint32_t* segoff;
@@ -1168,10 +1167,6 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
             // words 9 and 10 carry this backward call's 64-bit tag: rows that no wave writes keep whatever the
             // workspace held and are recognised as stale by K8/K9, so the partial-row buffer is never cleared
             row[red_word] = red_word >= 9 ? red_tag : (red_last ? t : t4);
-            // one byte per row beside the rows: K8/K9 looks at it first and does not fetch the 48 bytes of a row this call
-            // never wrote (an entry behind saturated pixels, a pair the footprint test dropped); the 64-bit tag in the row
-            // itself still decides (a stale byte matches once in 256)
-            if (red_word == 9) a.rflag[sslot[jm]] = (uint8_t)a.tag_lo;
           }
         }
         red_n = 0;
@@ -1201,8 +1196,6 @@ struct PreBwdArgs {
   const float4* part;
   const float4* part_obj;
   uint32_t tag_lo, tag_hi;   // rows whose words 9,10 differ are stale (not written by this backward)
-  const uint8_t* rflag;      // [N * nsub] low byte of the tag of the call that wrote the row last (K7): rows whose byte
-                             // differs are not fetched at all
   uint32_t nsub;             // partial rows per (tile, Gaussian) pair: one per K7 wave of the tile
   const float* means;
   const float* scales;
@@ -1250,9 +1243,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   // only, which runs k_pre_bwd -- gsr_backward_raw_into)
   auto put = [](float* p, float v) { *p = v; };
   float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
-  const uint8_t tag8 = (uint8_t)a.tag_lo;
   for (uint32_t e = o0; e < o1; ++e) {
-    if (a.rflag[e] != tag8) continue;
     const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
     if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
     if (GEOM) { mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w; myy += p1.x; dop += p1.y; }
@@ -1264,7 +1255,6 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     for (int c = 0; c < NUM_OBJ; ++c) acc_o[c] = 0.f;
     if (a.part_obj) {
       for (uint32_t e = o0; e < o1; ++e) {
-        if (a.rflag[e] != tag8) continue;
         const float4 tg = a.part[(size_t)e * PART_F4 + 2];
         if (__float_as_uint(tg.y) != a.tag_lo || __float_as_uint(tg.z) != a.tag_hi) continue;
 #pragma unroll
@@ -1592,13 +1582,10 @@ template <bool RAW, bool GEOM, bool ACC = false>
 __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
   __shared__ float shand[PRE_WAVES * 64 * HAND_W];
-  __shared__ uint8_t sflag[PRE_WAVES * ROW_CHUNK];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gw0 = a.g0 + blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
   const int g = gw0 + lane;
   float4* wrow = &srow[wave * ROW_CHUNK * PART_F4];
-  uint8_t* wflag = &sflag[wave * ROW_CHUNK];
-  const uint8_t tag8 = (uint8_t)a.tag_lo;
   float* hand = &shand[wave * 64 * HAND_W];
   const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
   if (nw <= 0) return;
@@ -1625,25 +1612,13 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
     for (uint32_t c0 = S; c0 < E; c0 += (uint32_t)ROW_CHUNK) {
       const uint32_t rows = min((uint32_t)ROW_CHUNK, E - c0);
       const float4* src = a.part + (size_t)c0 * PART_F4;
-      // the rows' flag bytes first (1 byte per row against 48): only the rows this backward wrote are fetched
-      static_assert(ROW_CHUNK == 128, "two flag bytes per lane");
-      {
-        const uint32_t r0 = 2u * lane, r1 = 2u * lane + 1u;
-        const uint8_t f0 = r0 < rows ? a.rflag[c0 + r0] : (uint8_t)~tag8, f1 = r1 < rows ? a.rflag[c0 + r1] : (uint8_t)~tag8;
-        wflag[r0] = f0; wflag[r1] = f1;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (uint32_t i = lane; i < rows * PART_F4; i += 64)
-        if (wflag[(i * 43691u) >> 17] == tag8) wrow[i] = src[i];       // row of float4 i = i / 3 (exact for i < 98304)
+      for (uint32_t i = lane; i < rows * PART_F4; i += 64) wrow[i] = src[i];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (!big) {
         const uint32_t lo = max(o0, c0), hi = min(o1, c0 + rows);
         for (uint32_t e = lo; e < hi; ++e) {
-          if (wflag[e - c0] != tag8) continue;                          // not fetched: the LDS slot holds an older row
           const float4* r = &wrow[(e - c0) * PART_F4];
           const float4 p0 = r[0], p1 = r[1], p2 = r[2];
           if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
@@ -1663,7 +1638,6 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       double t2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       for (uint32_t e = b0 + lane; e < b1; e += 64) {
-        if (a.rflag[e] != tag8) continue;
         const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
         if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
         if (GEOM) { t2[3] += (double)p0.x; t2[4] += (double)p0.y; t2[0] += (double)p0.z; t2[1] += (double)p0.w; t2[2] += (double)p1.x; t[5] += p1.y; }
@@ -1705,7 +1679,6 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         for (int c = 0; c < NUM_OBJ; ++c) acc_o[c] = 0.f;
         if (a.part_obj) {
           for (uint32_t e = o0; e < o1; ++e) {
-            if (a.rflag[e] != tag8) continue;
             const float4 tg = a.part[(size_t)e * PART_F4 + 2];
             if (__float_as_uint(tg.y) != a.tag_lo || __float_as_uint(tg.z) != a.tag_hi) continue;
 #pragma unroll
