@@ -60,6 +60,7 @@ PY
 cp $OUT/stats/s_kernel_stats.csv $R/gpurun_out/r04_kernel_stats.csv
 cp $OUT/stats1/s_kernel_stats.csv $R/gpurun_out/r04_kernel_stats_1stream.csv
 cp $OUT/pmc_traffic.json $R/gpurun_out/r04_pmc_traffic.json
+cp $OUT/pmc_traffic.json $R/profiles/r04_pmc_traffic.json     # (on the box: the bench lines below quote it; same sources => same digest)
 cp $OUT/bench_stats.json $R/gpurun_out/r04_bench_under_rocprof.json
 cp $OUT/bench_stats1.json $R/gpurun_out/r04_bench_1stream_under_rocprof.json
 # bench lines without the profiler
