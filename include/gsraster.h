@@ -152,8 +152,11 @@ int gsr_backward_raw(GsrCtx* ctx, const float* grad_color, const float* grad_obj
                      float* dlog_scaling, float* drotation_raw, void* stream);
 
 /* gsr_backward_raw with a choice of what happens to the output buffers.  accumulate == 0: they are overwritten (zeros
- * for Gaussians without pairs), exactly gsr_backward_raw.  accumulate != 0: the gradients are ADDED to what the buffers
- * hold and Gaussians without pairs are not touched at all.  That is what a batch of views needs (reference
+ * for Gaussians without pairs), exactly gsr_backward_raw.  accumulate != 0: the 59 attribute gradients (dxyz, dfeatures_dc,
+ * dfeatures_rest, dopacity_logit, dlog_scaling, drotation_raw) are ADDED to what the buffers hold and Gaussians without
+ * pairs are not touched at all; dmeans2D and dobjects_dc, which belong to ONE view (the screen-space gradient the
+ * reference reads from viewspace_points.grad, the object-feature gradient), are overwritten in either mode, zeros for
+ * Gaussians without pairs included.  That is what a batch of views needs (reference
  * attack.py:476-494: the B renders' gradients add up in .grad): the first view of a PGD iteration overwrites a
  * caller-owned [P,59] bucket, the others add to it, and the per-view gradient buffer plus the framework's
  * read-modify-write accumulation of 236 bytes per Gaussian and view disappear.  Concurrent calls (views on different
