@@ -393,7 +393,7 @@ pgd_attack.last_successes = None
 
 def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5, max_iters: int = 20,
                success_fn: Callable[[torch.Tensor, int], bool], save_path: Optional[str] = None,
-               truncate: bool = True, **kw) -> dict:
+               truncate: bool = True, add_cams: int = 1, benign: bool = False, **kw) -> dict:
     """The batch schedule of the reference's run() (attack.py:463-475, 556-569), iteration for iteration: ONE global
     counter `it` runs over range(max_iters * num_batches); the pending views are attacked `batch_size` at a time; an
     iteration with (it + 1) % max_iters == 0 attacks nothing and DROPS the current batch (:470-475) -- so a batch that
@@ -402,7 +402,11 @@ def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5
     (:564-569), whether or not earlier batches were dropped.  truncate=False keeps the views beyond a multiple of
     batch_size as a smaller last batch instead of dropping them.  Perturbations accumulate across batches: every batch
     projects onto the eps-ball around the ORIGINAL attributes (attack.py:389-394 captures them once).
-    -> {"batches": [{"views", "iters", "success", "loss"}], "all_succeeded", "saved", "iterations"}."""
+    add_cams > 1: the yawed copies of the first camera join the views first (augment_cameras; attack.py:404-415).
+    benign: the benign pass runs in front of the loop and its boxes are returned under "gt_bboxes" (attack.py:434-461).
+    -> {"batches": [{"views", "iters", "success", "loss"}], "all_succeeded", "saved", "iterations"[, "gt_bboxes"]}."""
+    cameras = augment_cameras(cameras, add_cams)
+    gt_bboxes = benign_bboxes(model, cameras, kw.get("pipe")) if benign else None
     pending = list(range(len(cameras)))
     if truncate and len(pending) % batch_size:             # the reference drops the views beyond a multiple of B (:417-423)
         pending = pending[:len(pending) - len(pending) % batch_size]
@@ -436,8 +440,47 @@ def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5
                     model.save_ply(save_path)
                 saved = True
         # not ok: the window is exhausted; the next loop turn is its last slot and drops the batch
-    return {"batches": report, "all_succeeded": all(b["success"] for b in report) and not pending, "saved": saved,
-            "iterations": it}
+    out = {"batches": report, "all_succeeded": all(b["success"] for b in report) and not pending, "saved": saved,
+           "iterations": it}
+    if gt_bboxes is not None:
+        out["gt_bboxes"] = gt_bboxes
+    return out
+
+
+def augment_cameras(cameras: Sequence, add_cams: int = 1, yaw_step_deg: float = 7.0) -> list:
+    """The reference's view augmentation (attack.py:404-415; configs/config.yaml `add_cams`): add_cams - 1 deep copies of
+    the FIRST camera, copy i yawed by 7 i degrees (Camera.yaw: view and projection refreshed, camera_center kept -- SURVEY.md
+    section 3.1 quirk 4), appended behind the given cameras.  add_cams <= 1: the list unchanged."""
+    out = list(cameras)
+    for i in range(1, int(add_cams)):
+        cam = copy.deepcopy(out[0])
+        cam.yaw(yaw_step_deg * i)
+        out.append(cam)
+    return out
+
+
+def bbox_from_render(image: torch.Tensor, threshold: int = 20):
+    """The bounding box the reference takes from a benign render (attack.py:438-449): clamp to [0, 1], scale by 255 and
+    truncate to bytes, ITU-R 601-2 luma as PIL's convert('L') computes it (integer: (19595 R + 38470 G + 7471 B + 32768)
+    >> 16), pixels with luma > threshold are "object", getbbox() of those -- (left, upper, right, lower) with right /
+    lower exclusive, or None when nothing is above the threshold.  Tensor ops on the image's device; one small read-back."""
+    rgb = (torch.clamp(image.detach(), 0.0, 1.0) * 255.0).to(torch.uint8).to(torch.int32)
+    luma = (19595 * rgb[0] + 38470 * rgb[1] + 7471 * rgb[2] + 32768) >> 16
+    on = luma > int(threshold)
+    rows = torch.nonzero(on.any(dim=1)).flatten()
+    if rows.numel() == 0:
+        return None
+    cols = torch.nonzero(on.any(dim=0)).flatten()
+    return (int(cols[0]), int(rows[0]), int(cols[-1]) + 1, int(rows[-1]) + 1)
+
+
+@torch.no_grad()
+def benign_bboxes(model, cameras: Sequence, pipe: Optional[PipelineParams] = None, threshold: int = 20) -> list:
+    """The benign pass in front of the attack loop (attack.py:434-461): every view rendered on a BLACK background
+    (whatever the attack's background is) and turned into the ground-truth box the detector loss is given."""
+    pipe = pipe or PipelineParams(skip_objects=True)
+    black = torch.zeros(3, device=model.get_xyz.device)
+    return [bbox_from_render(render(cam, model, pipe, black)["render"], threshold) for cam in cameras]
 
 
 def combine_with_background(attacked, background):

@@ -280,3 +280,21 @@ def test_success_bookkeeping_stops_the_loop_and_saves_the_model(tmp_path):
     first.clear()
     rep = run_attack(target.clone(), cams, background=background, batch_size=2, max_iters=10, success_fn=success, streams=1)
     assert [b["views"] for b in rep["batches"]] == [[0, 1]] and rep["all_succeeded"]      # the third view is truncated
+
+
+def test_run_attack_with_yawed_views_and_benign_boxes():
+    """run_attack(add_cams=3, benign=True): the two yawed copies of view 0 join the batch (attack.py:404-415) and the benign
+    pass (black background, luma > 20, bounding box: attack.py:434-461) returns one box per view, equal to the box of a
+    direct black-background render."""
+    from gsplat_attack.attack import bbox_from_render, run_attack
+    from gsplat_attack.renderer import PipelineParams, render
+    model, cams, _ = _scene(n_views=1)
+    seen = []
+    rep = run_attack(model, cams, batch_size=3, max_iters=3, add_cams=3, benign=True, streams=1,
+                     bg=torch.ones(3, device="cuda"), success_fn=lambda im, i: (seen.append(i), True)[1])
+    assert sorted(set(seen)) == [0, 1, 2] and rep["all_succeeded"] and len(rep["gt_bboxes"]) == 3
+    want = bbox_from_render(render(cams[0], model, PipelineParams(skip_objects=True), torch.zeros(3, device="cuda"))["render"])
+    assert rep["gt_bboxes"][0] is not None
+    l, u, r, b = rep["gt_bboxes"][0]
+    assert 0 <= l < r <= cams[0].image_width and 0 <= u < b <= cams[0].image_height
+    assert len(set(rep["gt_bboxes"])) > 1                                  # the yawed views see the scene elsewhere

@@ -85,3 +85,56 @@ def test_importing_the_package_asks_for_eight_hardware_queues(monkeypatch):
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
     importlib.reload(gsplat_attack)
     assert os.environ.get("GPU_MAX_HW_QUEUES") == "2"
+
+
+def test_bbox_from_render_is_pils_luma_threshold_and_getbbox():
+    """attack.bbox_from_render == the reference's benign-pass rule (attack.py:438-449): clamp, x255, truncate to bytes,
+    PIL's convert('L'), p > 20, getbbox() -- on random images with a bright patch, on a dim one (None), at the borders."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from gsplat_attack.attack import bbox_from_render
+
+    def pil_rule(img):
+        np_img = (torch.clamp(img, min=0, max=1.0) * 255).byte().permute(1, 2, 0).contiguous().numpy()
+        bw = Image.fromarray(np_img).convert('L').point(lambda p: p > 20 and 255)
+        return bw.getbbox()
+    g = torch.Generator().manual_seed(0)
+    for case in range(40):
+        H, W = int(torch.randint(5, 70, (1,), generator=g)), int(torch.randint(5, 90, (1,), generator=g))
+        img = torch.rand(3, H, W, generator=g) * 0.16 - 0.04        # luma around the threshold (20/255 = 0.078), some < 0
+        if case % 4 != 3:
+            y0, x0 = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+            img[:, y0:y0 + 1 + case % 5, x0:x0 + 1 + case % 7] += 0.6 + 0.8 * torch.rand(1, generator=g)   # may exceed 1
+        if case == 5:
+            img = torch.zeros(3, H, W)
+        assert bbox_from_render(img) == pil_rule(img), case
+    assert bbox_from_render(torch.zeros(3, 8, 8)) is None
+    one = torch.zeros(3, 8, 9)
+    one[:, 7, 8] = 1.0
+    assert bbox_from_render(one) == (8, 7, 9, 8) == pil_rule(one)
+
+
+def test_augment_cameras_appends_yawed_copies_of_the_first_view():
+    """attack.augment_cameras == attack.py:404-415: add_cams - 1 deep copies of view 0, copy i yawed by 7 i degrees
+    (R' = Y(7 i deg) R, view and full projection refreshed, camera_center NOT -- the reference's quirk)."""
+    import numpy as np
+    import torch
+    from gsplat_attack.attack import augment_cameras
+    from gsplat_attack.cameras import look_at_camera, world_to_view
+    cams = [look_at_camera((2.0, 0.5, -1.0), (0, 0, 0), fovx=0.9, width=64, height=48),
+            look_at_camera((-1.0, 0.2, 2.5), (0, 0, 0), fovx=0.9, width=64, height=48)]
+    assert augment_cameras(cams, 1) == cams and augment_cameras(cams, 0) == cams
+    out = augment_cameras(cams, 4)
+    assert len(out) == 5 and out[:2] == cams
+    R0 = np.array(cams[0].R, dtype=np.float64)
+    for i, cam in enumerate(out[2:], start=1):
+        th = np.radians(7.0 * i)
+        Y = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        assert np.allclose(cam.R, Y @ R0, atol=1e-12) and np.array_equal(cam.T, cams[0].T)
+        want_v = torch.tensor(world_to_view(Y @ R0, cams[0].T, cam.trans, cam.scale)).transpose(0, 1)
+        assert torch.allclose(cam.world_view_transform, want_v.to(cam.world_view_transform.dtype), atol=1e-6)
+        assert torch.allclose(cam.full_proj_transform, cam.world_view_transform @ cam.projection_matrix, atol=1e-6)
+        assert torch.equal(cam.camera_center, cams[0].camera_center)           # stale by design (scene/cameras.py:60-69)
+        assert not torch.allclose(cam.world_view_transform, cams[0].world_view_transform)
+    assert np.array_equal(cams[0].R, R0)                                        # the original is untouched
