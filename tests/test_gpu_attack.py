@@ -289,12 +289,12 @@ def test_run_attack_with_yawed_views_and_benign_boxes():
     from gsplat_attack.attack import bbox_from_render, run_attack
     from gsplat_attack.renderer import PipelineParams, render
     model, cams, _ = _scene(n_views=1)
+    want = bbox_from_render(render(cams[0], model, PipelineParams(skip_objects=True), torch.zeros(3, device="cuda"))["render"])
     seen = []
     rep = run_attack(model, cams, batch_size=3, max_iters=3, add_cams=3, benign=True, streams=1,
                      bg=torch.ones(3, device="cuda"), success_fn=lambda im, i: (seen.append(i), True)[1])
     assert sorted(set(seen)) == [0, 1, 2] and rep["all_succeeded"] and len(rep["gt_bboxes"]) == 3
-    want = bbox_from_render(render(cams[0], model, PipelineParams(skip_objects=True), torch.zeros(3, device="cuda"))["render"])
-    assert rep["gt_bboxes"][0] is not None
+    assert rep["gt_bboxes"][0] is not None and rep["gt_bboxes"][0] == want    # taken before the first step
     l, u, r, b = rep["gt_bboxes"][0]
     assert 0 <= l < r <= cams[0].image_width and 0 <= u < b <= cams[0].image_height
     assert len(set(rep["gt_bboxes"])) > 1                                  # the yawed views see the scene elsewhere
