@@ -988,18 +988,13 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
       const int gb = std::min(ck * per, P), ge = (ck == nchunks - 1) ? P : std::min((ck + 1) * per, P);
       if (ge > gb) {
         pa.g0 = gb; pa.P = ge;
-        pa.nchunks_total = (ge - gb + PRE_BLOCK - 1) / PRE_BLOCK;
-        // GSR_K9_BLOCKS (experiment, round 4): a thinner grid that loops over the chunks (0 = one workgroup per chunk)
-        static const int k9_blocks = [] { const char* e = getenv("GSR_K9_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-        const bool k9_loop = k9_blocks > 0 && c->lanegroup && c->raw && !accumulate && geom && k9_blocks < pa.nchunks_total;
-        const dim3 gridK9((unsigned)(k9_loop ? k9_blocks : pa.nchunks_total));
+        const dim3 gridK9((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK));
         if (c->lanegroup) {
           if (c->raw && accumulate) {
             if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else hipLaunchKernelGGL((k_pre_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
           } else if (c->raw) {
-            if (k9_loop) hipLaunchKernelGGL((k_pre_bwd<true, true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
-            else if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
           } else {
             if (geom) hipLaunchKernelGGL((k_pre_bwd<false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);

@@ -1214,7 +1214,6 @@ struct PreBwdArgs {
   float* dscales;
   float* drots;
   float* dcov3d;
-  int nchunks_total;      // k_pre_bwd: 64-Gaussian chunks of this launch's range (the grid may be thinner and loop)
   int accumulate;         // != 0 (k_pre_bwd only): the 59 attribute gradients are ADDED to (Gaussians without pairs are
                           // left alone); dmeans2D and dsh_objs, which belong to one view, are overwritten regardless
 };
@@ -1579,10 +1578,12 @@ constexpr int HAND_W = 7;          // hand-over: unit direction (3) + clamped dL
 
 // ACC: the outputs are added to instead of overwritten (PreBwdArgs::accumulate) -- a template parameter so that the
 // overwriting kernel contains no loads of its outputs at all.
-template <bool RAW, bool GEOM, bool ACC>
-__device__ __forceinline__ void pre_bwd_chunk(const PreBwdArgs& a, const int chunk, float4* srow, float* shand) {
+template <bool RAW, bool GEOM, bool ACC = false>
+__global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
+  __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
+  __shared__ float shand[PRE_WAVES * 64 * HAND_W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw0 = a.g0 + chunk * PRE_BLOCK + wave * 64;         // first Gaussian of this wave
+  const int gw0 = a.g0 + blockIdx.x * PRE_BLOCK + wave * 64;    // first Gaussian of this wave
   const int g = gw0 + lane;
   float4* wrow = &srow[wave * ROW_CHUNK * PART_F4];
   float* hand = &shand[wave * 64 * HAND_W];
@@ -1794,26 +1795,6 @@ __device__ __forceinline__ void pre_bwd_chunk(const PreBwdArgs& a, const int chu
         store_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, out);
       }
     }
-  }
-}
-
-// The launch: one workgroup per 64-Gaussian chunk (LOOP = false), or a thinner grid whose workgroups loop over the chunks
-// (LOOP = true; experiment, round 4: an HBM-bound kernel needs only a few MB of loads in flight, not every wave slot --
-// the looping form needs 149 registers against 114, so it is its own instantiation).
-template <bool RAW, bool GEOM, bool ACC = false, bool LOOP = false>
-__global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
-  __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
-  __shared__ float shand[PRE_WAVES * 64 * HAND_W];
-  if (!LOOP) {
-    pre_bwd_chunk<RAW, GEOM, ACC>(a, (int)blockIdx.x, srow, shand);
-    return;
-  }
-#pragma unroll 1
-  for (int chunk = blockIdx.x; chunk < a.nchunks_total; chunk += gridDim.x) {
-    pre_bwd_chunk<RAW, GEOM, ACC>(a, chunk, srow, shand);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the LDS images are reused by the next chunk
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
