@@ -401,6 +401,17 @@ struct GsrCtx {
   float* final_T = nullptr;
   uint32_t* n_contrib = nullptr;
   uint32_t* dv = nullptr;         // device-side scalars of this forward (gsr_sort.hip.h: DV_*)
+  // what gsr_ctx_rerender needs beyond the above
+  bool async_count = false;       // the forward sized its pair buffers from a guess: K6 looks at dv[DV_OVF]
+  bool fwd_only = false;          // kept by gsr_forward_raw2_keep: re-renderable, not differentiable
+  bool has_b = false;             // two attribute segments (gsr_forward_raw2_keep): Gaussians >= P - segb.Pb read segb
+  struct {
+    int32_t Pb = 0;
+    const float *xyz = nullptr, *features_dc = nullptr, *features_rest = nullptr, *objects_dc = nullptr,
+                *opacity = nullptr, *scaling = nullptr, *rotation = nullptr;
+  } b;
+  bool objects_out = false;       // the forward composited the 16 object channels
+  bool D_stale = false;           // the last re-render skipped d colour / d direction: no geometry backward until the next
 };
 
 // Host copy of the forward's device-side scalars: waits for the (early) copy if it has not landed yet.
@@ -473,11 +484,61 @@ struct SegB {
               *opacity = nullptr, *scaling = nullptr, *rotation = nullptr;
 };
 
+// K6 of a context whose binning (pair list, tile ranges, schedule, boundary-record plan) and splat records are in place:
+// the last launch of a forward, and all that a re-render of a kept context needs behind the colour kernel.
+static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hipStream_t st) {
+  const GsrSettings* s = &c->st;
+  const int W = s->image_width, H = s->image_height, ntiles = c->ntiles;
+  const size_t HW = (size_t)H * W;
+  const float* sh_objs = out_objects ? c->sh_objs : nullptr;
+  RenderArgs ra;
+  ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->G0; ra.R1 = c->G1; ra.R2 = c->G2;
+  ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = c->gridx; ra.ntiles = ntiles;
+  ra.sh_objs_b = c->has_b ? c->b.objects_dc : nullptr; ra.Pa = c->has_b ? c->P - c->b.Pb : c->P;
+  ra.map_mode = flag_tile_map(s->flags);
+  ra.sched = c->sched;
+  ra.dv = c->async_count ? c->dv : nullptr;
+  ra.wave_clock = g_wave_clock_fwd.load();
+  ra.bnd = c->bnd; ra.segoff = c->bnd ? c->segoff : nullptr; ra.seg_shift = c->bnd ? c->seg_shift : 0u;
+  ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
+  const dim3 blkT(64);
+  // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
+  // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
+  const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : 2);
+  const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
+  // the tile's waves as one workgroup that stages every batch once (k_render_fwd's WPB): S-nyc-1M gathers 596 -> 367 MB
+  // but runs 0.197 -> 0.224 ms (two workgroup barriers per batch, and the waves of a tile wait for each other), so
+  // it is opt-in: GSR_FLAG_FWD_SHARED, or GSR_K6_SHARED=1 in the environment
+  static const int k6_env = [] { const char* e = getenv("GSR_K6_SHARED"); return e ? atoi(e) : 0; }();
+  const bool k6_shared = k6_env != 0 || (s->flags & GSR_FLAG_FWD_SHARED) != 0;
+  const dim3 gridS(render_grid(ntiles)), blkS2(128), blkS4(256);
+  if (out_objects && sh_objs) {
+    if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
+    else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<true, 2, 2>), gridS, blkS2, 0, st, ra);
+    else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<true, 2>), gridT, blkT, 0, st, ra);
+    else if (k6_shared) hipLaunchKernelGGL((k_render_fwd<true, 1, 4>), gridS, blkS4, 0, st, ra);
+    else hipLaunchKernelGGL((k_render_fwd<true, 1>), gridT, blkT, 0, st, ra);
+  } else {
+    if (out_objects) {
+      hipError_t e = hipMemsetAsync(out_objects, 0, sizeof(float) * NUM_OBJ * HW, st);
+      if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "objects: %s", hipGetErrorString(e));
+    }
+    if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<false, 4>), gridT, blkT, 0, st, ra);
+    else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 2, 2>), gridS, blkS2, 0, st, ra);
+    else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<false, 2>), gridT, blkT, 0, st, ra);
+    else if (k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 1, 4>), gridS, blkS4, 0, st, ra);
+    else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "render forward: launch failed: %s", hipGetErrorString(e));
+  return GSR_OK;
+}
+
 static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float* means3D, const float* shs,
                         const float* sh_dc, const float* sh_objs, const float* colors_precomp, const float* opacities,
                         const float* scales, const float* rotations, const float* cov3D_precomp, float* out_color,
                         float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream,
-                        bool raw, const SegB* segb = nullptr) {
+                        bool raw, const SegB* segb = nullptr, bool fwd_only = false) {
   if (ctx_out) *ctx_out = nullptr;
   if (!s || !out_color) return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / out_color");
   if (P < 0 || s->image_height <= 0 || s->image_width <= 0)
@@ -513,6 +574,12 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->means3D = means3D; c->shs = shs; c->sh_objs = sh_objs; c->colors = colors_precomp; c->opac = opacities;
   c->scales = scales; c->rots = rotations; c->cov3d = cov3D_precomp;
   c->raw = raw; c->sh_dc = sh_dc;
+  c->fwd_only = fwd_only; c->objects_out = out_objects != nullptr && sh_objs != nullptr;
+  if (segb) {
+    c->has_b = true;
+    c->b.Pb = segb->Pb; c->b.xyz = segb->xyz; c->b.features_dc = segb->features_dc; c->b.features_rest = segb->features_rest;
+    c->b.objects_dc = segb->objects_dc; c->b.opacity = segb->opacity; c->b.scaling = segb->scaling; c->b.rotation = segb->rotation;
+  }
 
   const size_t Pp = (size_t)std::max(P, 1);
   pending_harvest();
@@ -536,7 +603,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   kp.add<uint2>(ntiles); kp.add<float>(HW); kp.add<uint32_t>(HW); kp.add<uint32_t>(DV_WORDS); kp.add<uint32_t>(ntiles);
   // the SH layouts the reference uses (and precomputed colours) take the lane-group kernels
   c->lanegroup = raw || (shs && K == 16) || colors_precomp != nullptr;
-  const bool want_D = c->lanegroup && shs != nullptr && ctx_out != nullptr;
+  const bool want_D = c->lanegroup && shs != nullptr && ctx_out != nullptr && !fwd_only;
   if (want_D) kp.add<float>(9 * Pp);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
@@ -634,7 +701,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         PreArgs pa;
         pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
         pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
-        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt;
+        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt; pa.offg = nullptr;
         pa.Pa = segb ? P - segb->Pb : P;
         pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
         pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
@@ -698,6 +765,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     c->n_known = true;
   }
   c->nbound = nbound;
+  c->async_count = async_count;
   if (nbound == 0 && P > 0) F_TRY("init", hipMemsetAsync(c->off, 0, sizeof(uint32_t), st));
   if (nbound > 0) {
     const int rounds = radix_rounds_for(nbound);
@@ -755,21 +823,11 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   if (side_used) F_TRY("side stream", hipStreamWaitEvent(st, side.join, 0));   // the colours are in place from here on
   {
     StageTimer t(GSR_STAGE_RENDER_FWD, st);
-    RenderArgs ra;
-    ra.ranges = c->ranges; ra.pair_rank = c->pair_rank; ra.R0 = c->G0; ra.R1 = c->G1; ra.R2 = c->G2;
-    ra.sh_objs = sh_objs; ra.bg = s->bg; ra.W = W; ra.H = H; ra.gridx = gridx; ra.ntiles = ntiles;
-    ra.sh_objs_b = segb ? segb->objects_dc : nullptr; ra.Pa = segb ? P - segb->Pb : P;
-    const int map_mode_f = flag_tile_map(s->flags);
-    ra.map_mode = map_mode_f;
-    ra.sched = c->sched;
-    ra.dv = async_count ? c->dv : nullptr;
-    ra.wave_clock = g_wave_clock_fwd.load();
     // Long tile lists are split into segments for the backward (gsr_kernels.hip.h, "Segments"): the forward stores the
     // per-pixel (T, C) at the segment boundaries.  Not with object channels (their 16 running sums are not stored), not
     // for a forward-only call, not under GSR_FLAG_NO_SEGMENTS.
     static const int seg_shift_env = [] { const char* e = getenv("GSR_SEG_SHIFT"); int v = e ? atoi(e) : 8; return (v >= 6 && v <= 16) ? v : 8; }();
-    ra.bnd = nullptr; ra.segoff = nullptr; ra.seg_shift = 0;
-    if (nbound > 0 && ctx_out && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
+    if (nbound > 0 && ctx_out && !fwd_only && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
       const uint32_t per = nbound >> seg_shift_env;
       c->seg_shift = (uint32_t)seg_shift_env;
       // sum over split tiles of ceil(len / seg) <= N / seg + min(T, N / seg): every split tile's records always fit
@@ -781,38 +839,12 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       Slab gs{static_cast<char*>(c->seg_blk), gp.bytes + 256, 0};
       c->bnd = gs.take<float4>((size_t)c->rec_cap * PXL * 64); c->rec_item = gs.take<uint2>(c->rec_cap);
       c->segoff = gs.take<uint32_t>(ntiles);
-      ra.bnd = c->bnd; ra.segoff = c->segoff; ra.seg_shift = c->seg_shift;
     }
     // always: it also turns the empty spans the tile sort left untouched into (0, 0)
     hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift,
                          c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
-    ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
-    const dim3 blkT(64);
-    // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
-    // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
-    const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : 2);
-    const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
-    // the tile's waves as one workgroup that stages every batch once (k_render_fwd's WPB): S-nyc-1M gathers 596 -> 367 MB
-    // but runs 0.197 -> 0.224 ms (two workgroup barriers per batch, and the waves of a tile wait for each other), so
-    // it is opt-in: GSR_FLAG_FWD_SHARED, or GSR_K6_SHARED=1 in the environment
-    static const int k6_env = [] { const char* e = getenv("GSR_K6_SHARED"); return e ? atoi(e) : 0; }();
-    const bool k6_shared = k6_env != 0 || (s->flags & GSR_FLAG_FWD_SHARED) != 0;
-    const dim3 gridS(render_grid(ntiles)), blkS2(128), blkS4(256);
-    if (out_objects && sh_objs) {
-      if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<true, 4>), gridT, blkT, 0, st, ra);
-      else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<true, 2, 2>), gridS, blkS2, 0, st, ra);
-      else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<true, 2>), gridT, blkT, 0, st, ra);
-      else if (k6_shared) hipLaunchKernelGGL((k_render_fwd<true, 1, 4>), gridS, blkS4, 0, st, ra);
-      else hipLaunchKernelGGL((k_render_fwd<true, 1>), gridT, blkT, 0, st, ra);
-    } else {
-      if (out_objects) F_TRY("objects", hipMemsetAsync(out_objects, 0, sizeof(float) * NUM_OBJ * HW, st));
-      if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<false, 4>), gridT, blkT, 0, st, ra);
-      else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 2, 2>), gridS, blkS2, 0, st, ra);
-      else if (fwd_npx == 2) hipLaunchKernelGGL((k_render_fwd<false, 2>), gridT, blkT, 0, st, ra);
-      else if (k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 1, 4>), gridS, blkS4, 0, st, ra);
-      else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
-    }
-    F_LAUNCH("render forward");
+    const int rk6 = launch_render_fwd(c, out_color, out_objects, st);
+    if (rk6 != GSR_OK) return fail(rk6);
   }
   pool_free(dev, scratch_blk);
   if (num_rendered) *num_rendered = c->n_known ? (int64_t)c->n64 : (int64_t)-1;   // -1: not known yet (asynchronous count)
@@ -832,19 +864,22 @@ int gsr_forward(const GsrSettings* s, int32_t P, int32_t K, const float* means3D
                       cov3D_precomp, out_color, out_objects, radii, ctx_out, num_rendered, stream, false);
 }
 
-int gsr_forward_raw2(const GsrSettings* s, int32_t Pa, const float* xyz_a, const float* features_dc_a,
-                     const float* features_rest_a, const float* objects_dc_a, const float* opacity_logit_a,
-                     const float* log_scaling_a, const float* rotation_raw_a, int32_t Pb, const float* xyz_b,
-                     const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
-                     const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
-                     float* out_color, float* out_objects, int32_t* radii, int64_t* num_rendered, void* stream) {
+int gsr_forward_raw2_keep(const GsrSettings* s, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                          const float* features_rest_a, const float* objects_dc_a, const float* opacity_logit_a,
+                          const float* log_scaling_a, const float* rotation_raw_a, int32_t Pb, const float* xyz_b,
+                          const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
+                          const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
+                          float* out_color, float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered,
+                          void* stream) {
   if (Pa < 0 || Pb < 0 || (long long)Pa + Pb > 0x7FFFFFFFll) return set_err(GSR_ERR_INVALID, "gsr_forward_raw2: bad sizes Pa=%d Pb=%d", Pa, Pb);
   if (Pb == 0)
     return forward_impl(s, Pa, 16, xyz_a, features_rest_a, features_dc_a, objects_dc_a, nullptr, opacity_logit_a,
-                        log_scaling_a, rotation_raw_a, nullptr, out_color, out_objects, radii, nullptr, num_rendered, stream, true);
+                        log_scaling_a, rotation_raw_a, nullptr, out_color, out_objects, radii, ctx_out, num_rendered, stream, true,
+                        nullptr, true);
   if (Pa == 0)
     return forward_impl(s, Pb, 16, xyz_b, features_rest_b, features_dc_b, objects_dc_b, nullptr, opacity_logit_b,
-                        log_scaling_b, rotation_raw_b, nullptr, out_color, out_objects, radii, nullptr, num_rendered, stream, true);
+                        log_scaling_b, rotation_raw_b, nullptr, out_color, out_objects, radii, ctx_out, num_rendered, stream, true,
+                        nullptr, true);
   if (!xyz_a || !features_dc_a || !features_rest_a || !opacity_logit_a || !log_scaling_a || !rotation_raw_a || !xyz_b ||
       !features_dc_b || !features_rest_b || !opacity_logit_b || !log_scaling_b || !rotation_raw_b)
     return set_err(GSR_ERR_INVALID, "gsr_forward_raw2: null parameter tensor");
@@ -854,8 +889,19 @@ int gsr_forward_raw2(const GsrSettings* s, int32_t Pa, const float* xyz_a, const
   b.Pb = Pb; b.xyz = xyz_b; b.features_dc = features_dc_b; b.features_rest = features_rest_b; b.objects_dc = objects_dc_b;
   b.opacity = opacity_logit_b; b.scaling = log_scaling_b; b.rotation = rotation_raw_b;
   return forward_impl(s, Pa + Pb, 16, xyz_a, features_rest_a, features_dc_a, objects_dc_a, nullptr, opacity_logit_a,
-                      log_scaling_a, rotation_raw_a, nullptr, out_color, out_objects, radii, nullptr, num_rendered, stream,
-                      true, &b);
+                      log_scaling_a, rotation_raw_a, nullptr, out_color, out_objects, radii, ctx_out, num_rendered, stream,
+                      true, &b, true);
+}
+
+int gsr_forward_raw2(const GsrSettings* s, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                     const float* features_rest_a, const float* objects_dc_a, const float* opacity_logit_a,
+                     const float* log_scaling_a, const float* rotation_raw_a, int32_t Pb, const float* xyz_b,
+                     const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
+                     const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
+                     float* out_color, float* out_objects, int32_t* radii, int64_t* num_rendered, void* stream) {
+  return gsr_forward_raw2_keep(s, Pa, xyz_a, features_dc_a, features_rest_a, objects_dc_a, opacity_logit_a, log_scaling_a,
+                               rotation_raw_a, Pb, xyz_b, features_dc_b, features_rest_b, objects_dc_b, opacity_logit_b,
+                               log_scaling_b, rotation_raw_b, out_color, out_objects, radii, nullptr, num_rendered, stream);
 }
 
 int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const float* features_dc,
@@ -866,6 +912,54 @@ int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const flo
     return set_err(GSR_ERR_INVALID, "gsr_forward_raw: null features_dc / features_rest / log_scaling / rotation_raw");
   return forward_impl(s, P, 16, xyz, features_rest, features_dc, objects_dc, nullptr, opacity_logit, log_scaling,
                       rotation_raw, nullptr, out_color, out_objects, radii, ctx_out, num_rendered, stream, true);
+}
+
+// Re-render of a kept context whose colour inputs (SH coefficients) may have changed and nothing else has: the colour
+// half of K1 over the Gaussians that emit pairs, then K6 over the kept lists.  include/gsraster.h has the contract.
+int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_rest, const float* features_dc_b,
+                     const float* features_rest_b, const float* bg, float* out_color, float* out_objects, uint32_t flags,
+                     void* stream) {
+  if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_rerender: null context");
+  if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: out_color is null");
+  if (c->P > 0 && (!c->lanegroup || !c->shs))
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context was not rendered from SH coefficients (raw parameters, "
+                   "or shs with K = 16): there is no colour stage to run again");
+  if (out_objects && !c->objects_out)
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context's forward did not composite object features");
+  if (!c->raw && features_dc)
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: a gsr_forward context takes its [P,16,3] coefficients in `features_rest`");
+  if (!c->has_b && (features_dc_b || features_rest_b))
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context has one attribute segment");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ctx_resolve_count(c) != GSR_OK) return set_err(GSR_ERR_DEVICE, "gsr_ctx_rerender: reading the forward's pair count failed");
+  if (c->overflow)
+    return set_err(GSR_ERR_OVERFLOW, "gsr_ctx_rerender: the context's forward overflowed its pair capacity (%llu pairs, "
+                   "capacity %u): render again with gsr_forward", c->n64, c->nbound);
+  if (features_rest) c->shs = features_rest;
+  if (features_dc) c->sh_dc = features_dc;
+  if (features_rest_b) c->b.features_rest = features_rest_b;
+  if (features_dc_b) c->b.features_dc = features_dc_b;
+  if (bg) c->st.bg = bg;
+  if (c->P > 0) {
+    StageTimer t(GSR_STAGE_PREPROCESS, st);
+    PreArgs pa{};
+    pa.P = c->P; pa.va = view_args(c->st); pa.means = c->means3D; pa.sh = c->shs; pa.sh_dc = c->sh_dc;
+    pa.Pa = c->has_b ? c->P - c->b.Pb : c->P;
+    pa.means_b = c->has_b ? c->b.xyz : nullptr;
+    pa.sh_b = c->has_b ? c->b.features_rest : nullptr; pa.sh_dc_b = c->has_b ? c->b.features_dc : nullptr;
+    pa.G0 = c->G0; pa.G1 = c->G1; pa.G2 = c->G2;
+    const bool skip_D = (flags & GSR_RERENDER_COLOR_GRADS_ONLY) != 0u;
+    pa.D = skip_D ? nullptr : c->D;
+    c->D_stale = c->D != nullptr && skip_D;
+    pa.tcnt = nullptr; pa.offg = c->offg;
+    const dim3 gridC((unsigned)((c->P + PREF_BLOCK - 1) / PREF_BLOCK)), blkC(PREF_BLOCK);
+    if (c->raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkC, 0, st, pa);
+    else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkC, 0, st, pa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "rerender colours: launch failed: %s", hipGetErrorString(e));
+  }
+  StageTimer t(GSR_STAGE_RENDER_FWD, st);
+  return launch_render_fwd(c, out_color, out_objects, st);
 }
 
 }  // extern "C"
@@ -879,6 +973,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int dev = c->dev;
   const int P = c->P;
+  if (c->fwd_only)
+    return set_err(GSR_ERR_STATE, "gsr_backward: the context was kept by gsr_forward_raw2_keep (re-render only, no backward state)");
   if (P == 0) return GSR_OK;
   const bool obj = grad_objects != nullptr && c->sh_objs != nullptr;
   // Only colour-side gradients wanted (SH / precomputed colours / object features): K7 and K8+K9 drop the geometry
@@ -979,6 +1075,9 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
       return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
     if (c->lanegroup && c->shs && geom && !c->D)
       return done(set_err(GSR_ERR_STATE, "gsr_backward: the forward of this context was run without its backward state"));
+    if (c->lanegroup && c->shs && geom && c->D_stale)
+      return done(set_err(GSR_ERR_STATE, "gsr_backward: geometry gradients asked of a context whose last gsr_ctx_rerender was "
+                          "told GSR_RERENDER_COLOR_GRADS_ONLY"));
     // The per-Gaussian stage covers the Gaussians in `nchunks` ranges (multiples of 64), one launch each; after a
     // range's launch is enqueued the caller is told (chunk_done): its gradients are complete in stream order, so a
     // collective over that range can be issued while the next range is still being computed.

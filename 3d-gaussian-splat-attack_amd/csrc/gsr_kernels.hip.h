@@ -1409,6 +1409,8 @@ struct PreArgs {
   float* D;               // [P,9] d rgb_c / d dir_axis (before the clamp), or null: not wanted (no backward follows)
   uint32_t* dkey;         // float bits of the view depth; 0xFFFFFFFF for a Gaussian that emits no pair
   uint32_t* tcnt;         // tiles of the (tightened) rect
+  const uint32_t* offg;   // colour kernel with tcnt == null (re-render of a kept context): a Gaussian emits pairs iff
+                          // offg[g + 1] != offg[g] (the storage-order scan of tcnt, which the context keeps)
   int cull;               // != 0: shrink the rect to the alpha >= 1/255 footprint (tighten_rect)
   PreBlockOut bo;
 };
@@ -1495,7 +1497,7 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color(PreArgs a) {
   // chunks, so that it holds only a couple of waves per SIMD while the binning chain's short kernels come and go
   for (int chunk = blockIdx.x; chunk * PREF_BLOCK < a.P; chunk += gridDim.x) {
   const int g = chunk * PREF_BLOCK + wave * 64 + lane;
-  const bool ok = g < a.P && a.tcnt[g] != 0u;
+  const bool ok = g < a.P && (a.tcnt ? a.tcnt[g] != 0u : a.offg[g + 1] != a.offg[g]);
   const uint64_t live = __ballot(ok);
   const int nlive = __popcll(live);
   if (nlive == 0) continue;

@@ -125,6 +125,11 @@ def _load():
     lib.gsr_backward_raw_chunked.argtypes = [vp] * 11 + [i32, i32, _CHUNK_FN, vp, vp]
     lib.gsr_forward_raw2.restype = ctypes.c_int
     lib.gsr_forward_raw2.argtypes = [ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [i32] + [vp] * 7 + [vp, vp, vp, i64p, vp]
+    lib.gsr_forward_raw2_keep.restype = ctypes.c_int
+    lib.gsr_forward_raw2_keep.argtypes = ([ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [i32] + [vp] * 7
+                                          + [vp, vp, vp, ctypes.POINTER(vp), i64p, vp])
+    lib.gsr_ctx_rerender.restype = ctypes.c_int
+    lib.gsr_ctx_rerender.argtypes = [vp] * 8 + [ctypes.c_uint32, vp]
     lib.gsr_ctx_free.restype = None
     lib.gsr_ctx_free.argtypes = [vp]
     lib.gsr_mark_visible.restype = ctypes.c_int
@@ -406,6 +411,80 @@ class _RasterizeGaussians(torch.autograd.Function):
                 shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None, None)
 
 
+class _CacheEntry:
+    __slots__ = ("holder", "sig", "refs", "pack", "gen", "event", "stream", "nren")
+
+    def __init__(self, holder, sig, refs, pack, nren):
+        self.holder, self.sig, self.refs, self.pack, self.nren = holder, sig, refs, pack, nren
+        self.gen = 0          # bumped by every render through this entry: a backward belongs to ONE generation
+        self.event = None     # recorded after the entry's last use, on `stream`
+        self.stream = None
+
+
+class RenderCache:
+    """Kept rasteriser contexts for renders whose GEOMETRY does not change from call to call -- a colour attack
+    (reference attack.py:25-49: only _features_dc / _features_rest are stepped; BASELINE configs 2 and 3) renders the
+    same cameras iteration after iteration with the same means, scales, rotations and opacities.  The first render of a
+    key (one per camera) is an ordinary forward whose context is kept here; later renders of that key whose geometry
+    inputs are the SAME tensor objects at the SAME autograd versions, under the same camera tensors / image size /
+    scale modifier / SH degree / flags, run gsr_ctx_rerender: the colour half of K1 and the compositor K6 over the kept
+    lists -- projection, both sorts, the emission and the schedule are not redone.  Anything else (a stepped geometry
+    tensor, another camera behind the key, a non-dense input) silently takes the full forward and replaces the entry.
+    Image and gradients are bit for bit those of the uncached call (tests/test_gpu_rerender.py).
+
+    One context per key: a second render of a key overwrites the per-pixel state its backward reads, so the backward of
+    the previous render of that key must have run (or never will) -- a late one raises.  About 250 MB of HBM per entry
+    at 1 M Gaussians and 1080p; the least recently used entry goes when `max_entries` is exceeded."""
+
+    def __init__(self, max_entries: int = 64):
+        import collections
+        self.max_entries = int(max_entries)
+        self.entries = collections.OrderedDict()
+        self.hits = self.misses = 0
+
+    def clear(self):
+        self.entries.clear()
+
+    def _lookup(self, key, sig, tensors):
+        e = self.entries.get(key)
+        if e is None or e.sig != sig or any(r() is not t for r, t in zip(e.refs, tensors)):
+            self.misses += 1
+            return None
+        self.entries.move_to_end(key)
+        self.hits += 1
+        return e
+
+    def _store(self, key, entry):
+        self.entries[key] = entry
+        self.entries.move_to_end(key)
+        while len(self.entries) > self.max_entries:
+            self.entries.popitem(last=False)
+
+
+def _cache_sig(tensors, rs: "GaussianRasterizationSettings", extra=()):
+    """What must be unchanged for a kept context to be re-rendered: the geometry tensors (identity is checked through
+    weak references; here their storage and versions), the camera tensors, and the scalar settings."""
+    cam = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (rs.viewmatrix, rs.projmatrix, rs.campos))
+    geo = tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
+    return (geo, cam, int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+            float(rs.scale_modifier), int(rs.sh_degree), int(_FLAGS)) + tuple(extra)
+
+
+def _entry_enter(entry: _CacheEntry, device):
+    """Orders the current stream behind the entry's last use (a no-op on the same stream)."""
+    cur = torch.cuda.current_stream(device)
+    if entry.event is not None and entry.stream != cur.cuda_stream:
+        cur.wait_event(entry.event)
+
+
+def _entry_leave(entry: _CacheEntry, device):
+    cur = torch.cuda.current_stream(device)
+    if entry.event is None:
+        entry.event = torch.cuda.Event()
+    entry.event.record(cur)
+    entry.stream = cur.cuda_stream
+
+
 class GradBucket:
     """Caller-owned gradient bucket of a reference-style GaussianModel: ONE flat float32 buffer of 59 floats per Gaussian
     in the order xyz | f_dc | f_rest | opacity | scaling | rotation (the layout of the flat buffer the fused backward
@@ -473,9 +552,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation, raster_settings,
-                keep=True, bucket=None):
+                keep=True, bucket=None, cache_slot=None, color_only=False):
         lib = _load()
         ctx.bucket = bucket
+        ctx.entry = None
         if not xyz.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
                                f"{xyz.device}); there is no CPU path")
@@ -498,12 +578,29 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         radii = torch.empty(P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
+        entry = None
+        if cache_slot is not None and P > 0:
+            cache, key = cache_slot
+            geo = (xyz, opacity, scaling, rotation, objects_dc if obj is not None else None)
+            dense = all(a is None or a.data_ptr() == b.data_ptr() for a, b in zip(geo, (x, op, sc, ro, obj)))
+            sig = _cache_sig(geo, raster_settings) if dense else None
+            entry = cache._lookup(key, sig, geo) if dense else None
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
-                                     _ptr(ro), _ptr(color), _ptr(objects) if obj is not None else None, _ptr(radii),
-                                     ctypes.byref(handle) if keep else None,
-                                     ctypes.byref(nren), stream)
+            if entry is not None:
+                # the geometry of this key is what its kept context was built from: colour kernel + compositor only
+                _entry_enter(entry, device)
+                radii = entry.pack.radii.detach()      # geometry is unchanged: so are the radii of the key's first render
+                rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(dc), _ptr(rest), None, None, _ptr(pack.bg), _ptr(color),
+                                          _ptr(objects) if obj is not None else None, 1 if color_only else 0, stream)
+                entry.gen += 1
+                nren.value = entry.nren
+            else:
+                want_ctx = keep or (cache_slot is not None and P > 0 and sig is not None)
+                rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
+                                         _ptr(ro), _ptr(color), _ptr(objects) if obj is not None else None, _ptr(radii),
+                                         ctypes.byref(handle) if want_ctx else None,
+                                         ctypes.byref(nren), stream)
         if rc != 0:
             msg = _err(lib)
             if raster_settings.debug:
@@ -511,7 +608,20 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                             "scaling": sc, "rotation": ro, "settings": raster_settings._asdict()}, "snapshot_fw.dump")
                 msg += " (raw parameters saved to snapshot_fw.dump)"
             raise Exception(msg) if rc == 1 else RuntimeError(msg)
-        ctx.holder = _CtxHolder(lib, handle) if keep else None
+        if entry is not None:
+            ctx.holder = entry.holder
+        else:
+            ctx.holder = _CtxHolder(lib, handle) if handle.value else None
+            if cache_slot is not None and P > 0 and sig is not None and ctx.holder is not None:
+                pack.radii = radii         # the kept context does not recompute them: later renders of the key return these
+                entry = _CacheEntry(ctx.holder, sig, tuple(weakref.ref(t) if t is not None else (lambda: None) for t in geo),
+                                    pack, nren.value)
+                cache._store(key, entry)
+        if entry is not None:
+            _entry_leave(entry, device)
+            ctx.entry, ctx.entry_gen = entry, entry.gen
+        if not keep:
+            ctx.holder = None
         ctx.pack = pack
         ctx._nren = nren.value
         ctx.shapes = (xyz.shape, means2D.shape, features_dc.shape, features_rest.shape,
@@ -528,6 +638,11 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         _check_versions(ctx.kept, ctx.versions)
         x, dc, rest, obj, op, sc, ro = ctx.kept
         device = x.device
+        if ctx.entry is not None:
+            if ctx.entry.gen != ctx.entry_gen:
+                raise RuntimeError("diff_gaussian_rasterization: this render's kept context (RenderCache) was rendered again "
+                                   "before its backward ran; call backward() first, or render without the cache")
+            _entry_enter(ctx.entry, device)
         P = int(x.shape[0])
         H, W = ctx.pack.c.image_height, ctx.pack.c.image_width
         if grad_color is None:
@@ -593,17 +708,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                               _ptr(d_rest), _ptr(d_obj), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), stream)
             if rc != 0:
                 raise (PairCapacityExceeded if rc == 5 else RuntimeError)(_err(lib))
+        if ctx.entry is not None:
+            _entry_leave(ctx.entry, device)
         if bucket is not None:
             bucket.fresh, bucket.used = False, True
             s = ctx.shapes
             return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None,
-                    None if d_obj is None else d_obj.reshape(s[4]), None, None, None, None, None, None)
+                    None if d_obj is None else d_obj.reshape(s[4]), None, None, None, None, None, None, None, None)
         s = ctx.shapes
 
         def shaped(t, shape, wanted=True):
             return None if (t is None or not wanted) else t.reshape(shape)
         return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
-                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None, None)
+                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None, None, None, None)
 
 
 def _wants_backward(*tensors) -> bool:
@@ -613,17 +730,24 @@ def _wants_backward(*tensors) -> bool:
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
-                            raster_settings, grad_bucket: Optional["GradBucket"] = None):
+                            raster_settings, grad_bucket: Optional["GradBucket"] = None, cache: Optional["RenderCache"] = None,
+                            cache_key=None):
     """(color[3,H,W], radii[P], objects[16,H,W]) from the RAW parameters of a reference-style GaussianModel
     (_xyz, _features_dc, _features_rest, _objects_dc or None, _opacity, _scaling, _rotation): equal to the
     getters (scene/gaussian_model.py:97-124) followed by GaussianRasterizer.forward, in one fused pass."""
     keep = _wants_backward(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation)
+    # `cache` (a RenderCache) + `cache_key` (one per camera): a render whose geometry inputs are unchanged since the key's
+    # last render re-uses that render's binning (gsr_ctx_rerender)
+    slot = (cache, cache_key) if cache is not None else None
+    color_only = not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                       for t in (xyz, means2D, opacity, scaling, rotation)))
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
-                                        raster_settings, keep, grad_bucket)
+                                        raster_settings, keep, grad_bucket, slot, color_only)
 
 
 @torch.no_grad()
-def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool = True):
+def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool = True,
+                             cache: Optional["RenderCache"] = None, cache_key=None):
     """Forward-only render of two reference-style parameter sets as ONE scene -- `params_a` followed by `params_b`,
     each (xyz, features_dc, features_rest, objects_dc or None, opacity, scaling, rotation), RAW tensors -- without
     concatenating them (gsr_forward_raw2; reference attack.py:513-530 deep-copies the model and concatenates all seven
@@ -649,14 +773,44 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
     color = torch.empty(3, H, W, dtype=torch.float32, device=device)
     objs = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if with_obj
             else _zero_scalar(device).expand(NUM_OBJECTS, H, W))
-    radii = torch.empty(Pa + Pb, dtype=torch.int32, device=device)
     nren = ctypes.c_int64(0)
     if not with_obj:
         a[3] = b[3] = None
+    # cache: with both models' geometry unchanged since the key's last render, only the colour kernel and the compositor
+    # run (gsr_ctx_rerender on a context kept by gsr_forward_raw2_keep) -- the success re-render of a colour attack
+    entry = sig = None
+    geo = ()
+    if cache is not None and Pa > 0 and Pb > 0:
+        geo = tuple(params_a[i] for i in (0, 4, 5, 6)) + tuple(params_b[i] for i in (0, 4, 5, 6)) + \
+            ((params_a[3], params_b[3]) if with_obj else (None, None))
+        used = (a[0], a[4], a[5], a[6], b[0], b[4], b[5], b[6], a[3], b[3])
+        if all(t is None or t.data_ptr() == u.data_ptr() for t, u in zip(geo, used)):
+            sig = _cache_sig(geo, raster_settings, extra=("pair", with_obj))
+            entry = cache._lookup(cache_key, sig, geo)
     with torch.cuda.device(device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        rc = lib.gsr_forward_raw2(ctypes.byref(pack.c), Pa, *[_ptr(t) for t in a], Pb, *[_ptr(t) for t in b], _ptr(color),
-                                  _ptr(objs) if with_obj else None, _ptr(radii), ctypes.byref(nren), stream)
+        if entry is not None:
+            _entry_enter(entry, device)
+            radii = entry.pack.radii.detach()
+            rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(a[1]), _ptr(a[2]), _ptr(b[1]), _ptr(b[2]), _ptr(pack.bg),
+                                      _ptr(color), _ptr(objs) if with_obj else None, 1, stream)
+            entry.gen += 1
+            # the context reads the coefficient tensors of THIS call on the stream: they stay referenced until the next render
+            entry.pack.last_inputs = (a, b, pack)
+        else:
+            radii = torch.empty(Pa + Pb, dtype=torch.int32, device=device)
+            handle = ctypes.c_void_p(None)
+            rc = lib.gsr_forward_raw2_keep(ctypes.byref(pack.c), Pa, *[_ptr(t) for t in a], Pb, *[_ptr(t) for t in b],
+                                           _ptr(color), _ptr(objs) if with_obj else None, _ptr(radii),
+                                           ctypes.byref(handle) if sig is not None else None, ctypes.byref(nren), stream)
+            if rc == 0 and handle.value:
+                pack.radii = radii
+                pack.last_inputs = (a, b)
+                entry = _CacheEntry(_CtxHolder(lib, handle), sig,
+                                    tuple(weakref.ref(t) if t is not None else (lambda: None) for t in geo), pack, nren.value)
+                cache._store(cache_key, entry)
+        if entry is not None and rc == 0:
+            _entry_leave(entry, device)
     if rc != 0:
         raise (Exception if rc == 1 else RuntimeError)(_err(lib))
     return color, radii, objs

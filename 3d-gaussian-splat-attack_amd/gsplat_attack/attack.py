@@ -152,7 +152,8 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                batch_loss: bool = False, loss_reduction: str = "sum", background=None,
                success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
                originals: Optional[dict] = None, use_buckets: bool = True,
-               timer: Optional["PhaseTimer"] = None, overlap_success: bool = True) -> List[float]:
+               timer: Optional["PhaseTimer"] = None, overlap_success: bool = True,
+               cache_binning: bool = True) -> List[float]:
     """Runs up to `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
     initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
     pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order.
@@ -182,7 +183,14 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         to a side stream, the next forward is enqueued beside it, and the flags are read when that forward is
                         in the queue.  If the batch turns out to be done, the speculative forward is dropped -- nothing has
                         been differentiated, accumulated or stepped -- so the iteration count, the history and the saved
-                        model are those of the serial loop (off: strictly serial, what a PhaseTimer measures)."""
+                        model are those of the serial loop (off: strictly serial, what a PhaseTimer measures).
+      cache_binning     (default on; colour-only attacks on the device) the attack steps _features_dc / _features_rest and
+                        nothing else (attack.py:25-49), so every iteration renders the same cameras with the same means,
+                        scales, rotations and opacities: each camera's rasteriser context -- projection, depth and tile
+                        sorts, tile lists, schedule -- is kept in HBM after its first render (RenderCache, ~250 MB per camera
+                        at 1 M Gaussians) and later renders of it, the attack's and the success check's, run the colour
+                        kernel and the compositor only.  Losses, flags and the saved model are bit for bit those of the
+                        uncached loop (tests/test_gpu_rerender.py)."""
     groups = tuple(groups)
     assert all(g in GROUPS for g in groups) and norm in ("l2", "linf") and loss_reduction in ("sum", "mean")
     dev = model.get_xyz.device
@@ -207,6 +215,10 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             if p.requires_grad:
                 p.requires_grad_(False)
                 frozen.append(p)
+    if (cache_binning and groups == ("color",) and dev.type == "cuda" and getattr(pipe, "render_cache", None) is None
+            and takes_fused_path(model, pipe)):
+        from diff_gaussian_rasterization import RenderCache
+        pipe.render_cache = RenderCache(max_entries=4 * max(len(mine), 1) + 8)      # pipe is this call's own copy here
     reduce_names = ("_features_dc", "_features_rest") if frozen else gdist.ATTACK_PARAMS
     running = {}                                           # accumulate_grads with world > 1: the running sums
     try:
@@ -503,7 +515,11 @@ def render_combined(attacked, background, cameras: Sequence, bg: torch.Tensor, p
     concatenation of its seven tensors per PGD iteration.  background None: the target alone."""
     pipe = pipe or PipelineParams(skip_objects=True)
     if background is None:
-        return [render(cam, attacked, pipe, bg)["render"] for cam in cameras]
+        if getattr(pipe, "render_cache", None) is not None:
+            pipe = copy.copy(pipe)
+            pipe.cache_tag = "check"      # its own kept contexts: the attack's forward of the same camera may run beside it
+        with torch.no_grad():
+            return [render(cam, attacked, pipe, bg)["render"] for cam in cameras]
     return [render_pair(cam, attacked, background, pipe, bg)["render"] for cam in cameras]
 
 

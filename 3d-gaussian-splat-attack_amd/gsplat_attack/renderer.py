@@ -22,7 +22,7 @@ class PipelineParams:
 
     def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False,
                  skip_objects: bool = False, fused_activations: bool = True, viewspace_grad: bool = True,
-                 grad_bucket=None):
+                 grad_bucket=None, render_cache=None):
         self.convert_SHs_python = convert_SHs_python
         self.compute_cov3D_python = compute_cov3D_python
         self.debug = debug
@@ -40,6 +40,13 @@ class PipelineParams:
         # returning the bucket to use for this call (one per stream) -- that receives the 59 attribute gradients of the
         # fused path directly; see GradBucket
         self.grad_bucket = grad_bucket
+        # extension (default None = every render runs the whole forward): a diff_gaussian_rasterization.RenderCache.  A
+        # render of a camera whose geometry inputs (means, opacities, scales, rotations -- the same tensors at the same
+        # versions) and camera tensors are unchanged since the last render of that camera through this cache re-uses
+        # that render's projection, sorts and tile lists and runs the colour kernel and the compositor only: what every
+        # iteration after the first of a colour attack is (reference attack.py:25-49).  Same bits either way.
+        self.render_cache = render_cache
+        self.cache_tag = "view"       # namespace of this pipe's keys in the cache (the success check renders under its own)
 
 
 def _has_raw_layout(pc) -> bool:
@@ -170,7 +177,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             bucket = bucket()
         image, radii, objects = rasterize_gaussians_raw(
             pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, None if no_objects else pc._objects_dc,
-            pc._opacity, pc._scaling, pc._rotation, st, grad_bucket=bucket)
+            pc._opacity, pc._scaling, pc._rotation, st, grad_bucket=bucket,
+            cache=getattr(pipe, "render_cache", None), cache_key=(getattr(pipe, "cache_tag", "view"), id(viewpoint_camera)))
         return _result(image, screenspace_points, radii, objects)
 
     # classic surface: activated tensors through the keyword call of reference :86-95
@@ -206,5 +214,7 @@ def render_pair(viewpoint_camera, pc_a, pc_b, pipe, bg_color: torch.Tensor, scal
     def raw(pc):
         return (pc._xyz, pc._features_dc, pc._features_rest, pc._objects_dc, pc._opacity, pc._scaling, pc._rotation)
     image, radii, objects = rasterize_gaussians_raw2(raw(pc_a), raw(pc_b), st,
-                                                     objects=not bool(getattr(pipe, "skip_objects", False)))
+                                                     objects=not bool(getattr(pipe, "skip_objects", False)),
+                                                     cache=getattr(pipe, "render_cache", None),
+                                                     cache_key=("pair", id(viewpoint_camera)))
     return _result(image, None, radii, objects)

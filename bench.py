@@ -661,18 +661,42 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         col_steps(n_col)
         torch.cuda.synchronize()
         col_rate = n_col / (time.perf_counter() - t0)
+        # the same over the ring of cameras (what a batch of attack views is), without and with each camera's binning
+        # kept across renders (RenderCache -> gsr_ctx_rerender: the geometry is frozen, so only the colour kernel and the
+        # compositor run from a camera's second render on); bit-equal results (tests/test_gpu_rerender.py)
+        from diff_gaussian_rasterization import RenderCache
+        ring_rates = []
+        for cache_ in (None, RenderCache()):
+            pipe_r = PipelineParams(skip_objects=not args.objects, viewspace_grad=False, render_cache=cache_)
+
+            def ring_steps(n):
+                for i in range(n):
+                    ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
+                    with ctx_:
+                        model.zero_grad()
+                        render(cams[i % len(cams)], model, pipe_r, bg)["render"].backward(gc)
+            ring_steps(2 * len(cams))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ring_steps(n_col)
+            torch.cuda.synchronize()
+            ring_rates.append(n_col / (time.perf_counter() - t0))
+            del pipe_r, cache_
         for p_ in frozen:
             p_.requires_grad_(True)
     extras = {"fwd_only_views_per_s": round(fwd_rate, 1),
               "sh_grads_only_views_per_s": None if col_rate is None else round(col_rate, 1)}
+    if col_rate is not None:
+        extras["sh_grads_only_ring_views_per_s"] = round(ring_rates[0], 1)
+        extras["sh_grads_only_ring_binning_kept_views_per_s"] = round(ring_rates[1], 1)
 
     log("pgd: config 3 (colour L2, PGD-20, B = 1) and config 4 on one GPU (8 views, five groups) ...")
     det = SurrogateDetector().to(dev)
     never = lambda im, i: False                            # noqa: E731 -- the success check runs, the loop never stops on it
 
-    def measure(name, views, groups, iters, n_streams, rerender):
+    def measure(name, views, groups, iters, n_streams, rerender, cache_binning=True):
         m = model.clone()
-        kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0)
+        kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0, cache_binning=cache_binning)
         if rerender:
             kw.update(success_fn=never, background=None)
         pgd_attack(m, views, iters=3, **kw)                # warm-up
@@ -683,7 +707,10 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         per_it = sorted(r["seconds"] for r in recs)
         wall = per_it[len(per_it) // 2] * 1e3              # median iteration (each one ends with a synchronise)
         out = {"iteration_ms": round(wall, 3), "iteration_ms_all": [round(x * 1e3, 3) for x in per_it],
-               "views": len(views), "groups": list(groups), "streams": n_streams, "what": name}
+               "views": len(views), "groups": list(groups), "streams": n_streams, "what": name,
+               # colour-only attacks: each camera's rasteriser context (projection, sorts, tile lists) kept in HBM after its
+               # first render and re-used while the geometry tensors are untouched (gsr_ctx_rerender); same bits
+               "binning_kept": bool(cache_binning and tuple(groups) == ("color",))}
         if n_streams == 1:
             # phase split on one stream: HIP events at the phase boundaries + the library's own stage events
             tm = PhaseTimer()
@@ -711,7 +738,15 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         return out
     pgd = {
         "cfg3": measure("BASELINE config 3: DAGGER PGD-20, L2 on the SH colour only, ONE view per iteration, forward-only "
-                        "re-render after every step (attack.py:522-530), surrogate detector", cams[:1], ("color",), 20, 1, True),
+                        "re-render after every step (attack.py:522-530), surrogate detector; the camera's binning is kept "
+                        "across iterations (the geometry is frozen)", cams[:1], ("color",), 20, 1, True),
+        "cfg3_rebinned_every_render": measure("config 3 with every render running the whole forward (cache_binning=False): "
+                                              "what a rasteriser without kept contexts does", cams[:1], ("color",), 20, 1, True,
+                                              cache_binning=False),
+        "cfg3_8views": measure("config 3's colour attack on a batch of 8 views over 4 streams, binning kept", cams[:8],
+                               ("color",), 6, max(args.streams, 1), True),
+        "cfg3_8views_rebinned_every_render": measure("the same, every render the whole forward", cams[:8], ("color",), 6,
+                                                     max(args.streams, 1), True, cache_binning=False),
         "cfg4_one_gpu": measure("BASELINE config 4 on one GPU: 8 views per iteration, L2 on {colour, position, scaling, "
                                 "rotation, opacity}, one stream", cams[:8],
                                 ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 300 /* 0.3.0 */
+#define GSR_VERSION 400 /* 0.4.0 */
 #define GSR_NUM_OBJECTS 16 /* object-feature channels, reference scene/gaussian_model.py:52 */
 
 enum {
@@ -188,6 +188,47 @@ int gsr_forward_raw2(const GsrSettings* settings, int32_t Pa, const float* xyz_a
                      const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
                      const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
                      float* out_color, float* out_objects, int32_t* radii, int64_t* num_rendered, void* stream);
+
+/* gsr_forward_raw2 that can keep its context -- for gsr_ctx_rerender ONLY: the context holds the binning and the splat
+ * records but no backward state (gsr_backward* on it return GSR_ERR_STATE), as the reference never differentiates this
+ * render.  ctx_out == NULL: exactly gsr_forward_raw2. */
+int gsr_forward_raw2_keep(const GsrSettings* settings, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                          const float* features_rest_a, const float* objects_dc_a, const float* opacity_logit_a,
+                          const float* log_scaling_a, const float* rotation_raw_a, int32_t Pb, const float* xyz_b,
+                          const float* features_dc_b, const float* features_rest_b, const float* objects_dc_b,
+                          const float* opacity_logit_b, const float* log_scaling_b, const float* rotation_raw_b,
+                          float* out_color, float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered,
+                          void* stream);
+
+/* Re-render of a kept context after ONLY its colour inputs changed.  A colour attack (reference attack.py:25-49 steps
+ * _features_dc / _features_rest and nothing else; configs/config.yaml attack groups = ["color"]; BASELINE configs 2, 3)
+ * renders the same cameras iteration after iteration with the same means, scales, rotations and opacities: projection,
+ * tile rects, depth order, the sorted (tile, Gaussian) lists, the tile schedule and the geometric words of the splat
+ * records are then the same every time.  The reference's extension rebuilds them per call; a context kept in HBM
+ * (about 250 MB per camera at 1 M Gaussians / 1080p, of 288 GB) makes a render of such a view two kernels: the colour half
+ * of K1 (SH -> RGB over the Gaussians that emit pairs, into the colour words of the kept records) and the compositor K6
+ * over the kept lists.  Image, radii-independent outputs and every gradient of a following gsr_backward* are bit for bit
+ * those of a fresh gsr_forward* with the same inputs (tests/test_gpu_rerender.py).
+ *   ctx            from gsr_forward / gsr_forward_raw (SH input: raw parameters, or shs with K = 16) with ctx_out, or from
+ *                  gsr_forward_raw2_keep.  The CALLER guarantees that since that forward nothing but the SH coefficients
+ *                  and bg changed: same means / opacities / scales / rotations contents, same camera, sizes, flags.
+ *   features_dc, features_rest   the coefficients to render with ([P,1,3], [P,15,3]; a gsr_forward context: NULL and
+ *                  shs [P,16,3]); NULL = the pointers of the previous render (their CONTENTS may have changed).  The
+ *                  context re-reads them in gsr_backward*: keep them alive and unmodified until then, as after a forward.
+ *   features_*_b   the same for the second segment of a gsr_forward_raw2_keep context (else NULL)
+ *   bg             >= 3 floats, or NULL = the previous background pointer
+ *   out_color      [3,H,W]; out_objects [16,H,W] or NULL (only if the context's forward composited them)
+ *   flags          GSR_RERENDER_COLOR_GRADS_ONLY: the backward of this render will ask for colour-side gradients only
+ *                  (dfeatures_*, dcolors): the colour kernel then skips the 36 bytes per Gaussian of d colour / d view
+ *                  direction it leaves for dL/dmeans; a geometry backward on the context returns GSR_ERR_STATE until
+ *                  the next re-render without the flag.
+ * The per-pixel state the backward reads (final T, last contributor, segment-boundary records) is overwritten: a
+ * backward of the PREVIOUS render of this context must have been enqueued before, on the same stream or ordered
+ * before it by the caller. */
+#define GSR_RERENDER_COLOR_GRADS_ONLY 1u
+int gsr_ctx_rerender(GsrCtx* ctx, const float* features_dc, const float* features_rest, const float* features_dc_b,
+                     const float* features_rest_b, const float* bg, float* out_color, float* out_objects, uint32_t flags,
+                     void* stream);
 
 /* Releases the context's workspace back to the pool (stream-ordered: safe right after enqueueing backward). */
 void gsr_ctx_free(GsrCtx* ctx);
