@@ -162,6 +162,17 @@ void pool_free(int dev, void* p) {
     if (b.p == p) { b.used = false; return; }
 }
 
+// A live block is being used on another stream than the one it was taken for (a kept context re-rendered or
+// differentiated on stream `st`, ordered behind its earlier users by the caller): when it is freed, stream-ordered reuse
+// has to follow THAT stream.
+void pool_retag(int dev, void* p, hipStream_t st) {
+  if (!p) return;
+  Pool& pl = g_pool[dev];
+  std::lock_guard<std::mutex> lk(pl.mu);
+  for (Block& b : pl.blocks)
+    if (b.p == p) { b.stream = st; return; }
+}
+
 // a slab = one pool block carved into 256-byte aligned pieces
 struct Slab {
   char* base = nullptr;
@@ -935,6 +946,7 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
   if (c->overflow)
     return set_err(GSR_ERR_OVERFLOW, "gsr_ctx_rerender: the context's forward overflowed its pair capacity (%llu pairs, "
                    "capacity %u): render again with gsr_forward", c->n64, c->nbound);
+  pool_retag(c->dev, c->keep_blk, st); pool_retag(c->dev, c->rank_blk, st); pool_retag(c->dev, c->seg_blk, st);
   if (features_rest) c->shs = features_rest;
   if (features_dc) c->sh_dc = features_dc;
   if (features_rest_b) c->b.features_rest = features_rest_b;
@@ -989,6 +1001,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
                    "%u guessed from earlier views (GSR_FLAG_ASYNC_COUNT); its image was filled with NaN -- render again",
                    c->n64, c->nbound);
   const uint32_t N = c->nbound;
+  // the context's blocks are read here, on this stream: whoever takes them over after gsr_ctx_free orders behind it
+  pool_retag(dev, c->keep_blk, st); pool_retag(dev, c->rank_blk, st); pool_retag(dev, c->seg_blk, st);
   void* part_blk = nullptr;
   void* pobj_blk = nullptr;
   float4* part = nullptr;
