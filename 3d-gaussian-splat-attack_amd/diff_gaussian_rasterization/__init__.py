@@ -411,14 +411,28 @@ class _RasterizeGaussians(torch.autograd.Function):
                 shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), shaped(d_cov, s[8]), None, None)
 
 
+class _RenderToken:
+    """Held by the autograd node of a differentiable render through a kept context: while it is alive and not `done`,
+    that render's backward may still come and the context must not be rendered again."""
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
+
+
 class _CacheEntry:
-    __slots__ = ("holder", "sig", "refs", "pack", "gen", "event", "stream", "nren")
+    __slots__ = ("holder", "sig", "refs", "pack", "gen", "event", "stream", "nren", "token")
 
     def __init__(self, holder, sig, refs, pack, nren):
         self.holder, self.sig, self.refs, self.pack, self.nren = holder, sig, refs, pack, nren
         self.gen = 0          # bumped by every render through this entry: a backward belongs to ONE generation
         self.event = None     # recorded after the entry's last use, on `stream`
         self.stream = None
+        self.token = None     # weak reference to the _RenderToken of the entry's last differentiable render
+
+    def busy(self) -> bool:
+        t = self.token() if self.token is not None else None
+        return t is not None and not t.done
 
 
 class RenderCache:
@@ -432,27 +446,34 @@ class RenderCache:
     tensor, another camera behind the key, a non-dense input) silently takes the full forward and replaces the entry.
     Image and gradients are bit for bit those of the uncached call (tests/test_gpu_rerender.py).
 
-    One context per key: a second render of a key overwrites the per-pixel state its backward reads, so the backward of
-    the previous render of that key must have run (or never will) -- a late one raises.  About 250 MB of HBM per entry
+    One context per key: a render overwrites the per-pixel state the previous render's backward reads.  While the
+    previous differentiable render of a key is still waiting for its backward (its graph is alive and has not been
+    differentiated), another render of that key takes the full forward with a context of its own and leaves the entry
+    alone; a second backward through a graph whose context has been rendered again since (retain_graph) raises.
+    About 250 MB of HBM per entry
     at 1 M Gaussians and 1080p; the least recently used entry goes when `max_entries` is exceeded."""
 
     def __init__(self, max_entries: int = 64):
         import collections
         self.max_entries = int(max_entries)
         self.entries = collections.OrderedDict()
-        self.hits = self.misses = 0
+        self.hits = self.misses = self.bypassed = 0
 
     def clear(self):
         self.entries.clear()
 
     def _lookup(self, key, sig, tensors):
+        """-> (entry or None, may_store): a busy entry (see the class comment) is neither used nor replaced."""
         e = self.entries.get(key)
+        if e is not None and e.busy():
+            self.bypassed += 1
+            return None, False
         if e is None or e.sig != sig or any(r() is not t for r, t in zip(e.refs, tensors)):
             self.misses += 1
-            return None
+            return None, True
         self.entries.move_to_end(key)
         self.hits += 1
-        return e
+        return e, True
 
     def _store(self, key, entry):
         self.entries[key] = entry
@@ -584,7 +605,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             geo = (xyz, opacity, scaling, rotation, objects_dc if obj is not None else None)
             dense = all(a is None or a.data_ptr() == b.data_ptr() for a, b in zip(geo, (x, op, sc, ro, obj)))
             sig = _cache_sig(geo, raster_settings) if dense else None
-            entry = cache._lookup(key, sig, geo) if dense else None
+            if dense:
+                entry, may_store = cache._lookup(key, sig, geo)
+                if not may_store:
+                    sig = None                      # the key's context is waiting for a backward: plain forward, not stored
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             if entry is not None:
@@ -620,6 +644,9 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if entry is not None:
             _entry_leave(entry, device)
             ctx.entry, ctx.entry_gen = entry, entry.gen
+            if keep:
+                ctx.token = _RenderToken()
+                entry.token = weakref.ref(ctx.token)
         if not keep:
             ctx.holder = None
         ctx.pack = pack
@@ -710,6 +737,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 raise (PairCapacityExceeded if rc == 5 else RuntimeError)(_err(lib))
         if ctx.entry is not None:
             _entry_leave(ctx.entry, device)
+            ctx.token.done = True
         if bucket is not None:
             bucket.fresh, bucket.used = False, True
             s = ctx.shapes
@@ -786,7 +814,7 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
         used = (a[0], a[4], a[5], a[6], b[0], b[4], b[5], b[6], a[3], b[3])
         if all(t is None or t.data_ptr() == u.data_ptr() for t, u in zip(geo, used)):
             sig = _cache_sig(geo, raster_settings, extra=("pair", with_obj))
-            entry = cache._lookup(cache_key, sig, geo)
+            entry, _ = cache._lookup(cache_key, sig, geo)        # forward-only contexts are never busy
     with torch.cuda.device(device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         if entry is not None:

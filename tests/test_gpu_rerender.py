@@ -112,17 +112,36 @@ def test_changed_geometry_camera_or_settings_take_the_full_forward():
     assert same() and cache.hits == h
 
 
-def test_a_late_backward_on_a_rerendered_context_raises():
+def test_a_key_waiting_for_its_backward_is_left_alone():
+    """Two renders of one camera before either backward (a batched loss with a repeated view): the second takes the full
+    forward with a context of its own, both backwards give the uncached gradients.  Only a SECOND backward through a graph
+    whose context has been rendered again since raises."""
     from diff_gaussian_rasterization import RenderCache
     from gsplat_attack.renderer import PipelineParams, render
     dev, model, cams, bg = _scene(5000, 128, 96, n_views=1)
-    pipe = PipelineParams(skip_objects=True, render_cache=RenderCache())
+    cache = RenderCache()
+    plain, pipe = PipelineParams(skip_objects=True), PipelineParams(skip_objects=True, render_cache=cache)
+    gen = torch.Generator().manual_seed(2)
+    g1, g2 = (torch.randn(3, 96, 128, generator=gen).to(dev) for _ in range(2))
+    model.zero_grad()
+    render(cams[0], model, plain, bg)["render"].backward(g1 + g2)
+    want = _grads(model, ALL)
+    model.zero_grad()
     first = render(cams[0], model, pipe, bg)["render"]
     second = render(cams[0], model, pipe, bg)["render"]
+    assert cache.bypassed == 1 and cache.hits == 0
+    first.backward(g1)
+    second.backward(g2)
+    got = _grads(model, ALL)
+    for n in ALL:
+        scale = want[n].abs().max().item() + 1e-20
+        assert (want[n] - got[n]).abs().max().item() <= 2e-6 * scale, n      # (g1 + g2) vs two backwards: rounding only
+    third = render(cams[0], model, pipe, bg)["render"]          # both are differentiated: the kept context serves again
+    assert cache.hits == 1
+    third.sum().backward(retain_graph=True)
+    render(cams[0], model, pipe, bg)["render"].sum().backward()
     with pytest.raises(RuntimeError, match="rendered again"):
-        first.sum().backward()
-    second.sum().backward()                          # the latest render of the key is differentiable
-    assert model._features_dc.grad is not None
+        third.sum().backward()
 
 
 @pytest.mark.parametrize("objects", [False, True])
