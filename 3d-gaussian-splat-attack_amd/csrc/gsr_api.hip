@@ -952,6 +952,8 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
   if (features_rest_b) c->b.features_rest = features_rest_b;
   if (features_dc_b) c->b.features_dc = features_dc_b;
   if (bg) c->st.bg = bg;
+  if ((flags & GSR_RERENDER_FIRST_SEGMENT_ONLY) && (features_dc_b || features_rest_b))
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: GSR_RERENDER_FIRST_SEGMENT_ONLY with new second-segment coefficients");
   if (c->P > 0) {
     StageTimer t(GSR_STAGE_PREPROCESS, st);
     PreArgs pa{};
@@ -964,7 +966,9 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
     pa.D = skip_D ? nullptr : c->D;
     c->D_stale = c->D != nullptr && skip_D;
     pa.tcnt = nullptr; pa.offg = c->offg;
-    const dim3 gridC((unsigned)((c->P + PREF_BLOCK - 1) / PREF_BLOCK)), blkC(PREF_BLOCK);
+    // two segments, the second one's coefficients untouched since the last render: its colour words are still right
+    if (c->has_b && (flags & GSR_RERENDER_FIRST_SEGMENT_ONLY)) pa.P = pa.Pa;
+    const dim3 gridC((unsigned)((pa.P + PREF_BLOCK - 1) / PREF_BLOCK)), blkC(PREF_BLOCK);
     if (c->raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkC, 0, st, pa);
     else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkC, 0, st, pa);
     hipError_t e = hipGetLastError();

@@ -820,8 +820,19 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
         if entry is not None:
             _entry_enter(entry, device)
             radii = entry.pack.radii.detach()
-            rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(a[1]), _ptr(a[2]), _ptr(b[1]), _ptr(b[2]), _ptr(pack.bg),
-                                      _ptr(color), _ptr(objs) if with_obj else None, 1, stream)
+            # the second model is the frozen background (reference attack.py:513-530): while its coefficient tensors are the
+            # ones of the entry's last render, unmodified, the colour kernel runs over the first model's Gaussians only
+            b_sig = tuple((t.data_ptr(), t._version) for t in (params_b[1], params_b[2]))
+            b_same = (entry.pack.b_sig == b_sig and params_b[1].data_ptr() == b[1].data_ptr()
+                      and params_b[2].data_ptr() == b[2].data_ptr())
+            if b_same:
+                rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(a[1]), _ptr(a[2]), None, None, _ptr(pack.bg),
+                                          _ptr(color), _ptr(objs) if with_obj else None, 1 | 2, stream)
+            else:
+                rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(a[1]), _ptr(a[2]), _ptr(b[1]), _ptr(b[2]), _ptr(pack.bg),
+                                          _ptr(color), _ptr(objs) if with_obj else None, 1, stream)
+            entry.pack.b_sig = b_sig if (params_b[1].data_ptr() == b[1].data_ptr()
+                                         and params_b[2].data_ptr() == b[2].data_ptr()) else None
             entry.gen += 1
             # the context reads the coefficient tensors of THIS call on the stream: they stay referenced until the next render
             entry.pack.last_inputs = (a, b, pack)
@@ -834,6 +845,9 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
             if rc == 0 and handle.value:
                 pack.radii = radii
                 pack.last_inputs = (a, b)
+                pack.b_sig = (tuple((t.data_ptr(), t._version) for t in (params_b[1], params_b[2]))
+                              if (params_b[1].data_ptr() == b[1].data_ptr() and params_b[2].data_ptr() == b[2].data_ptr())
+                              else None)
                 entry = _CacheEntry(_CtxHolder(lib, handle), sig,
                                     tuple(weakref.ref(t) if t is not None else (lambda: None) for t in geo), pack, nren.value)
                 cache._store(cache_key, entry)

@@ -222,10 +222,14 @@ int gsr_forward_raw2_keep(const GsrSettings* settings, int32_t Pa, const float* 
  *                  (dfeatures_*, dcolors): the colour kernel then skips the 36 bytes per Gaussian of d colour / d view
  *                  direction it leaves for dL/dmeans; a geometry backward on the context returns GSR_ERR_STATE until
  *                  the next re-render without the flag.
+ *                  GSR_RERENDER_FIRST_SEGMENT_ONLY (two-segment contexts): the second segment's coefficients have not
+ *                  changed since the context's last render (the frozen background of reference attack.py:513-530): the
+ *                  colour kernel covers the first segment's Gaussians only; features_*_b must be NULL.
  * The per-pixel state the backward reads (final T, last contributor, segment-boundary records) is overwritten: a
  * backward of the PREVIOUS render of this context must have been enqueued before, on the same stream or ordered
  * before it by the caller. */
 #define GSR_RERENDER_COLOR_GRADS_ONLY 1u
+#define GSR_RERENDER_FIRST_SEGMENT_ONLY 2u
 int gsr_ctx_rerender(GsrCtx* ctx, const float* features_dc, const float* features_rest, const float* features_dc_b,
                      const float* features_rest_b, const float* bg, float* out_color, float* out_objects, uint32_t flags,
                      void* stream);
