@@ -852,8 +852,16 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       c->segoff = gs.take<uint32_t>(ntiles);
     }
     // always: it also turns the empty spans the tile sort left untouched into (0, 0)
-    hipLaunchKernelGGL(k_tile_schedule, dim3(1), dim3(1024), 0, st, ntiles, c->ranges, c->sched, c->seg_shift,
-                         c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
+    // (more than 64 KB of dynamic LDS at 4K: a single workgroup may use all of the CU's 160 KB on gfx950)
+    static const bool sched_attr = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * SCHED_LDS_TILES);
+      (void)hipGetLastError();
+      return true;
+    }();
+    (void)sched_attr;
+    hipLaunchKernelGGL(k_tile_schedule, dim3(c->segoff ? 2 : 1), dim3(1024), sched_lds_bytes(ntiles), st, ntiles, c->ranges, c->sched,
+                         c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
     const int rk6 = launch_render_fwd(c, out_color, out_objects, st);
     if (rk6 != GSR_OK) return fail(rk6);
   }

@@ -457,7 +457,7 @@ __device__ __forceinline__ int item_of_block(int b, int nitems, int mode) {
 // lists issue ahead of their SIMD's other waves.  Results do not depend on the schedule.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCHED_BINS = 4096;                      // one bin per list length (clamped): few same-bin LDS atomics
-constexpr int SCHED_LDS_TILES = 12288;               // 48 KB of list lengths (1080p has 8160 tiles)
+constexpr int SCHED_LDS_TILES = 65536;               // list lengths kept in LDS as 16-bit words (a 4K image has 32 400 tiles)
 constexpr uint32_t SCHED_TILE_MASK = (1u << 28) - 1u;
 __device__ __forceinline__ uint32_t wave_max_u32_fwd(uint32_t v) {
 #pragma unroll
@@ -489,6 +489,11 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* w
 // seg_shift = 0: no tile is split.  rec_cap: capacity of the boundary-record buffer (a tile whose records would not
 // fit stays unsplit); nrec_out receives the number of records in use.  Tiles whose span is still the empty
 // (0xFFFFFFFF, 0) the tile sort starts from are given (0, 0).
+// Dynamic LDS: 2 * min(ntiles, SCHED_LDS_TILES) bytes (sched_lds_bytes) -- the tiles' list lengths are read from HBM
+// once, eight loads in flight per thread, and kept as 16-bit words for the two passes behind the histogram (a length
+// of 65535 or more is stored as 0xFFFF and read again from `ranges` where its exact value matters).  Until round 4 the
+// lengths of images with more than 12288 tiles were re-read from HBM one dependent load at a time: 92 us at 4K.
+inline size_t sched_lds_bytes(int ntiles) { return 2u * (size_t)((std::min(ntiles, SCHED_LDS_TILES) + 7) & ~7); }
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
@@ -496,16 +501,27 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
-  // the tiles' list lengths are read from HBM once and kept in LDS for the passes below (up to SCHED_LDS_TILES
-  // tiles; beyond that -- 4K images -- the later passes read `ranges` again)
-  __shared__ uint32_t slen[SCHED_LDS_TILES];
+  extern __shared__ unsigned short slen[];
   const int t = threadIdx.x, lane = t & 63;
-  const bool in_lds = ntiles <= SCHED_LDS_TILES;
+  const int lds_tiles = min(ntiles, SCHED_LDS_TILES);
+  // list length of tile i, exact (segment plan) / clamped to 65535 (bins and priorities: both saturate far below)
   auto tile_len = [&](int i) -> uint32_t {
-    if (in_lds) return slen[i];
+    if (i < lds_tiles) {
+      const uint32_t v = slen[i];
+      if (v != 0xFFFFu) return v;
+    }
     const uint2 r = ranges[i];
     return r.y - r.x;
   };
+  auto tile_len_sat = [&](int i) -> uint32_t {
+    if (i < lds_tiles) return slen[i];
+    const uint2 r = ranges[i];
+    return min(r.y - r.x, 0xFFFFu);
+  };
+  // Two workgroups when tiles can be split (segoff != null): block 0 makes the schedule, block 1 the segment plan --
+  // both from the list lengths, which each reads for itself (two CUs instead of one workgroup's phases back to back).
+  const bool do_sched = blockIdx.x == 0;
+  const bool do_plan = segoff != nullptr && blockIdx.x == gridDim.x - 1;
 #pragma unroll
   for (int k = 0; k < SCHED_BINS / 1024; ++k) hist[t + k * 1024] = 0;
   if (t == 0) smax = 0;
@@ -520,7 +536,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
       r[k] = i < ntiles ? ranges[i] : make_uint2(0u, 0u);
       if (r[k].x > r[k].y) {                 // a tile without pairs still holds the empty span (0xFFFFFFFF, 0)
         r[k] = make_uint2(0u, 0u);
-        ranges[i] = r[k];
+        if (do_sched) ranges[i] = r[k];      // (the other block sees either form as an empty list)
       }
     }
 #pragma unroll
@@ -528,12 +544,13 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
       const int i = i0 + k * 1024;
       if (i < ntiles) {
         const uint32_t len = r[k].y - r[k].x;
-        if (in_lds) slen[i] = len;
-        atomicAdd(&hist[min(len, (uint32_t)SCHED_BINS - 1u)], 1u);
+        if (i < lds_tiles) slen[i] = (unsigned short)min(len, 0xFFFFu);
+        if (do_sched) atomicAdd(&hist[min(len, (uint32_t)SCHED_BINS - 1u)], 1u);
         mymax = max(mymax, len);
       }
     }
   }
+  if (do_sched) {
   mymax = wave_max_u32_fwd(mymax);
   if (lane == 0) atomicMax(&smax, mymax);
   __syncthreads();
@@ -550,15 +567,28 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
   }
   __syncthreads();
   const float prio_scale = 4.0f / (float)(smax + 1u);
-  for (int i = t; i < ntiles; i += 1024) {
-    const uint32_t len = tile_len(i);
-    const uint32_t p = atomicAdd(&hist[min(len, (uint32_t)SCHED_BINS - 1u)], 1u);
-    const uint32_t prio = min(3u, (uint32_t)((float)len * prio_scale));    // 0..3: length relative to the longest list
-    sched[p] = (uint32_t)i | (prio << 28);
+  for (int i0 = t; i0 < ntiles; i0 += 4 * 1024) {        // four independent cursor updates in flight per thread
+    uint32_t len[4], p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * 1024;
+      len[k] = i < ntiles ? tile_len_sat(i) : 0u;
+      p[k] = i < ntiles ? atomicAdd(&hist[min(len[k], (uint32_t)SCHED_BINS - 1u)], 1u) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k * 1024;
+      if (i < ntiles) {
+        const uint32_t prio = min(3u, (uint32_t)((float)len[k] * prio_scale));    // 0..3: length relative to the longest list
+        sched[p[k]] = (uint32_t)i | (prio << 28);
+      }
+    }
   }
+  }
+  if (!do_plan) return;
+  __syncthreads();                                         // slen[] of this block is complete
   // ---- boundary records of the split tiles: exclusive scan of nseg over the tiles, in tile order ------------------
   // thread t owns the consecutive tiles [t * tpt, (t + 1) * tpt): ONE block scan instead of one per 1024 tiles
-  if (segoff == nullptr) return;
   const uint32_t seg_len = 1u << seg_shift;
   const int tpt = (ntiles + 1023) / 1024;
   const int i_lo = t * tpt, i_hi = min(i_lo + tpt, ntiles);
