@@ -605,6 +605,9 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             geo = (xyz, opacity, scaling, rotation, objects_dc if obj is not None else None)
             dense = all(a is None or a.data_ptr() == b.data_ptr() for a, b in zip(geo, (x, op, sc, ro, obj)))
             sig = _cache_sig(geo, raster_settings) if dense else None
+            # identity (weak references) of the geometry AND the camera tensors: a new camera object that happens to get
+            # the id, the addresses and the versions of a dead one is never mistaken for it
+            geo = geo + (raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.campos)
             if dense:
                 entry, may_store = cache._lookup(key, sig, geo)
                 if not may_store:
@@ -814,6 +817,7 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
         used = (a[0], a[4], a[5], a[6], b[0], b[4], b[5], b[6], a[3], b[3])
         if all(t is None or t.data_ptr() == u.data_ptr() for t, u in zip(geo, used)):
             sig = _cache_sig(geo, raster_settings, extra=("pair", with_obj))
+            geo = geo + (raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.campos)
             entry, _ = cache._lookup(cache_key, sig, geo)        # forward-only contexts are never busy
     with torch.cuda.device(device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -110,6 +110,14 @@ def test_changed_geometry_camera_or_settings_take_the_full_forward():
         other.world_view_transform.clone(), other.full_proj_transform.clone(), other.camera_center.clone())
     h = cache.hits
     assert same() and cache.hits == h
+    assert same() and cache.hits == h + 1
+    # ... and edited in place (same objects, same storage, another version)
+    third = cams[0] if cams[0] is not cam else cams[1]
+    with torch.no_grad():
+        cam.world_view_transform.copy_(third.world_view_transform * 1.0)
+        cam.full_proj_transform.mul_(1.0)
+    h = cache.hits
+    assert same() and cache.hits == h
 
 
 def test_a_key_waiting_for_its_backward_is_left_alone():
