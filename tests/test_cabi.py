@@ -62,6 +62,10 @@ def test_version_and_argument_validation_without_device(lib):
     rc = lib.gsr_forward(ctypes.byref(st), 4, 9, one, one, None, None, one, one, one, None, one, None, one, None, None, None)
     assert rc == 1 and b"sh_degree" in lib.gsr_last_error()
     assert lib.gsr_backward(None, None, None, None, None, None, None, None, None, None, None, None, None) == 4
+    # re-render of a kept context: a null context is a state error, and the version says the entry point exists
+    assert out.value >= 400
+    assert lib.gsr_ctx_rerender(None, None, None, None, None, None, one, None, 0, None) == 4
+    assert b"null context" in lib.gsr_last_error()
 
 
 def test_package_has_no_cpu_path():
