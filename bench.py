@@ -373,14 +373,18 @@ def main():
     ar_events.clear()
     info = {}
     # pair / visible counts of every camera of the ring (the roofline figures use their means)
-    Ns, Vs = [], []
+    Ns, Vs, Es = [], [], []
     for c_ in (cams[:n_views] if not args.one_camera else [cam]):
         o_ = render(c_, model, pipe, bg, scale_mod[0])
         Ns.append(D.last_num_rendered(o_["render"]))
         Vs.append(int(D.export_state(o_["render"], "dv")[1].item()))
+        # (pixel, entry) evaluations of the reference's per-pixel walk: every pixel visits its tile's list up to its last
+        # contributor ("Flops (secondary)": E, measured here from the forward's n_contrib)
+        Es.append(int(D.export_state(o_["render"], "n_contrib").to(torch.int64).sum().item()))
         del o_
     info["N_per_camera"], info["V_per_camera"] = Ns, Vs
     info["N"], info["V"] = int(round(sum(Ns) / len(Ns))), int(round(sum(Vs) / len(Vs)))
+    info["E"] = int(round(sum(Es) / len(Es)))
     step_no[0] = 0
 
     def timed_regions(n_regions, use_streams=True, profile_stage=None):
@@ -550,6 +554,19 @@ def main():
         }
         if valu is not None:
             result["roofline"]["valu"] = valu
+        # SURVEY.md section 8d's secondary figure: the (pixel, entry) alpha evaluations E of the reference's walk (sum over
+        # pixels of the last contributor's list position, mean over the cameras) against the compositors' own durations,
+        # priced at the survey's 14 FMA + exp forward / 45 FMA + exp backward per evaluation (29 / 91 flop) -- what the
+        # kernels deliver in the reference's own unit of work, whatever strips and lanes they evaluate to get there
+        k6, k7 = per["render_fwd"]["avg_ms"], per["render_bwd"]["avg_ms"]
+        if k6 > 0 and k7 > 0 and info.get("E"):
+            E = info["E"]
+            result["roofline"]["alpha_evaluations"] = {
+                "per_view": E, "per_pixel": round(E / HW, 1),
+                "fwd_Geval_per_s": round(E / (k6 * 1e-3) / 1e9, 1), "bwd_Geval_per_s": round(E / (k7 * 1e-3) / 1e9, 1),
+                "fwd_TFLOPs_equiv": round(29 * E / (k6 * 1e-3) / 1e12, 1), "bwd_TFLOPs_equiv": round(91 * E / (k7 * 1e-3) / 1e12, 1),
+                "fp32_vector_peak_TFLOPs": 157.3,
+                "note": "render_fwd includes the tile-schedule kernel; one-stream stage durations of the untimed pass"}
         if seq is not None:
             result["sequential"] = seq
         if world > 1:
