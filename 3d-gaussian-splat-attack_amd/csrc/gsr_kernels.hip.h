@@ -731,21 +731,10 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
     // touches only the other waves' strips costs nothing here)
     uint64_t todo = __ballot(mine != 0u);
     if (todo != 0ull && alive) {
-    int j = __builtin_ctzll(todo);
-    float4 n0 = s0[jb + j], n1 = s1[jb + j];
-    float2 n2 = s2[jb + j];
-    while (alive) {
-      const float4 e0 = n0, e1 = n1;
-      const float2 e2 = n2;
-      const int jc = j;
-      // Next entry of the batch that reaches this wave (the scalar unit is shared by the CU's four SIMDs and this
-      // loop leans on it: three scalar instructions instead of the eight the compiler makes of the C expressions).
-      // After the last entry s_ff1 returns -1: the prefetch below then reads slot 63, which is never used.
-      int jraw;
-      asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
-      const bool more = jraw >= 0;
-      j = jraw & 63;                          // prefetch the next entry while this one is composited
-      n0 = s0[jb + j]; n1 = s1[jb + j]; n2 = s2[jb + j];
+    // One entry of the batch composited onto this wave's strips.  The walk below is unrolled by two with the entries in
+    // TWO register sets (a, b), each loaded while the other is composited: with one set rotated every iteration
+    // (`e = n; n = load`) the compiler ends every entry on seven register-to-register moves of the prefetched record.
+    auto composite = [&](const float4& e0, const float4& e1, const float2& e2, const int jc) {
       const uint32_t m = (__builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) >> (WPB > 1 ? sub * NPX : 0)) & alive;
       const uint32_t pos = base - rg.x + (uint32_t)(jb + jc) + 1;
       if (m != 0u) {
@@ -795,6 +784,28 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
         }
       }
       }
+    };
+    // Next entry of the batch that reaches this wave (the scalar unit is shared by the CU's four SIMDs and this
+    // loop leans on it: three scalar instructions instead of the eight the compiler makes of the C expressions).
+    // After the last entry s_ff1 returns -1: the prefetch then reads slot 63, which is never used.
+    int j = __builtin_ctzll(todo);
+    float4 a0 = s0[jb + j], a1 = s1[jb + j];
+    float2 a2 = s2[jb + j];
+    while (alive) {
+      int jc = j, jraw;
+      asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
+      bool more = jraw >= 0;
+      j = jraw & 63;                          // prefetch the next entry while this one is composited
+      const float4 b0 = s0[jb + j], b1 = s1[jb + j];
+      const float2 b2 = s2[jb + j];
+      composite(a0, a1, a2, jc);
+      if (!more || !alive) break;
+      jc = j;
+      asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
+      more = jraw >= 0;
+      j = jraw & 63;
+      a0 = s0[jb + j]; a1 = s1[jb + j]; a2 = s2[jb + j];
+      composite(b0, b1, b2, jc);
       if (!more) break;
     }
     }
