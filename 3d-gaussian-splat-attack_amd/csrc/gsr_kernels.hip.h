@@ -1085,13 +1085,10 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float4 n0 = s0[cnt - 1], n1 = s1[cnt - 1];
-    float2 n2 = s2[cnt - 1];
-    for (int j = cnt - 1; j >= 0; --j) {
-      const float4 e0 = n0, e1 = n1;
-      const float2 e2 = n2;
-      const int jn = max(j - 1, 0);           // prefetch the next entry while this one is processed
-      n0 = s0[jn]; n1 = s1[jn]; n2 = s2[jn];
+    // One list entry: its strips, the parking of its per-lane sums, and the transposed sum when the buffer is full.  The
+    // walk below is unrolled by two over TWO register sets (a, b), each loaded while the other is processed: with one set
+    // rotated every iteration the compiler ends every entry on five 64-bit register moves of the prefetched record.
+    auto entry = [&](const float4& e0, const float4& e1, const float2& e2, const int j) {
       const uint32_t pos = (uint32_t)(lo + j + 1);
       const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) & 0xFu;
       if (m != 0u) {
@@ -1215,6 +1212,18 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+    };
+    float4 a0 = s0[cnt - 1], a1 = s1[cnt - 1];
+    float2 a2 = s2[cnt - 1];
+    for (int j = cnt - 1; j >= 0; j -= 2) {
+      const int jb = max(j - 1, 0);           // prefetch the next entry while this one is processed
+      const float4 b0 = s0[jb], b1 = s1[jb];
+      const float2 b2 = s2[jb];
+      entry(a0, a1, a2, j);
+      if (j == 0) break;
+      const int ja = max(j - 2, 0);
+      a0 = s0[ja]; a1 = s1[ja]; a2 = s2[ja];
+      entry(b0, b1, b2, j - 1);
     }
     __builtin_amdgcn_wave_barrier();
   }
