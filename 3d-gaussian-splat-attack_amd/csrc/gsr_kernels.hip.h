@@ -652,7 +652,8 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
   constexpr int BATCH = 64 * WPB;
   __shared__ float4 s0[BATCH];
   __shared__ float4 s1[BATCH];
-  __shared__ float2 s2[BATCH];
+  __shared__ float4 s2[BATCH];                             // (blue, threshold | mask, -, -): 16-byte pitch like s0 / s1, so that
+                                                           // the three reads of an entry share ONE address register
   __shared__ float so[OBJ ? BATCH : 1][NUM_OBJ];
   __shared__ uint32_t salive[WPB];
   const int lane = threadIdx.x & 63;
@@ -706,7 +707,7 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
       // staged mask bits: this wave's strips (own workgroup) or all four strips of the tile (shared workgroup)
       mine = WPB > 1 ? (pv >> RANK_BITS) & 0xFu : ((pv >> RANK_BITS) >> (sub * NPX)) & ((1u << NPX) - 1u);
       const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
-      s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = sp.c;
+      s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = make_float4(sp.c.x, sp.c.y, 0.f, 0.f);
       if (OBJ) {
         const uint32_t og = r;                              // the pair's value IS the Gaussian's storage index
         const float4* src = reinterpret_cast<const float4*>(og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ
@@ -715,7 +716,7 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
       }
     } else if (WPB > 1) {
-      s2[slot] = make_float2(0.f, 0.f);                   // past the end of the list: reaches no strip
+      s2[slot] = make_float4(0.f, 0.f, 0.f, 0.f);         // past the end of the list: reaches no strip
     }
     if (WPB > 1) {
       __syncthreads();
@@ -729,20 +730,34 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
     if (WPB > 1) mine = (__float_as_uint(s2[jb + lane].y) >> (sub * NPX)) & ((1u << NPX) - 1u);
     // entries of the batch that reach this wave's strips: the walk visits only these (an entry of the tile that
     // touches only the other waves' strips costs nothing here)
-    uint64_t todo = __ballot(mine != 0u);
-    if (todo != 0ull && alive) {
+    // sb[k]: the batch entries that reach strip k while it is alive (one scalar bit test per entry and strip, no mask to
+    // fetch from the staged record); todo: their union.  A strip that finishes takes its entries out of both.
+    uint64_t sb[NPX], todo = 0ull;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      sb[k] = (alive >> k) & 1u ? __ballot(((mine >> k) & 1u) != 0u) : 0ull;
+      todo |= sb[k];
+    }
+    if (todo != 0ull) {
     // One entry of the batch composited onto this wave's strips.  The walk below is unrolled by two with the entries in
     // TWO register sets (a, b), each loaded while the other is composited: with one set rotated every iteration
     // (`e = n; n = load`) the compiler ends every entry on seven register-to-register moves of the prefetched record.
+    auto strip_done = [&](const int k) {
+      alive &= ~(1u << k);
+      sb[k] = 0ull;
+      uint64_t rest = 0ull;
+#pragma unroll
+      for (int q = 0; q < NPX; ++q) rest |= sb[q];
+      todo &= rest;
+    };
     auto composite = [&](const float4& e0, const float4& e1, const float2& e2, const int jc) {
-      const uint32_t m = (__builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) >> (WPB > 1 ? sub * NPX : 0)) & alive;
       const uint32_t pos = base - rg.x + (uint32_t)(jb + jc) + 1;
-      if (m != 0u) {
+      {
       const float dx = e0.x - pxf;
       const float qa = e0.z * dx * dx, bdx = e0.w * dx;
 #pragma unroll
       for (int k = 0; k < NPX; ++k) {
-        if (m & (1u << k)) {
+        if ((sb[k] >> jc) & 1ull) {
           const float dy = e0.y - pyf[k];
           const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
           const float G = __builtin_amdgcn_exp2f(p2);
@@ -776,10 +791,12 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
           pyf[k] = stop ? PX_OFF : pyf[k];
+          // (a strip that has just finished takes its entries out of `todo`; with the wave's last strip `todo` is empty:
+          // the walk's only exit test is "no entry left")
           if (NPX >= 2) {
-            if (sm != 0ull && __builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
+            if (sm != 0ull && __builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) strip_done(k);
           } else {
-            if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
+            if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) strip_done(k);
           }
         }
       }
@@ -790,23 +807,23 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
     // After the last entry s_ff1 returns -1: the prefetch then reads slot 63, which is never used.
     int j = __builtin_ctzll(todo);
     float4 a0 = s0[jb + j], a1 = s1[jb + j];
-    float2 a2 = s2[jb + j];
-    while (alive) {
+    float2 a2 = make_float2(s2[jb + j].x, s2[jb + j].y);
+    // (the entry behind the one on which the wave's last pixel finished has been fetched already: it is skipped on its
+    // empty strip mask, and the cleared `todo` ends the walk behind it)
+    while (true) {
       int jc = j, jraw;
       asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
-      bool more = jraw >= 0;
       j = jraw & 63;                          // prefetch the next entry while this one is composited
       const float4 b0 = s0[jb + j], b1 = s1[jb + j];
-      const float2 b2 = s2[jb + j];
+      const float2 b2 = make_float2(s2[jb + j].x, s2[jb + j].y);
       composite(a0, a1, a2, jc);
-      if (!more || !alive) break;
+      if (jraw < 0) break;
       jc = j;
       asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
-      more = jraw >= 0;
       j = jraw & 63;
-      a0 = s0[jb + j]; a1 = s1[jb + j]; a2 = s2[jb + j];
+      a0 = s0[jb + j]; a1 = s1[jb + j]; a2 = make_float2(s2[jb + j].x, s2[jb + j].y);
       composite(b0, b1, b2, jc);
-      if (!more) break;
+      if (jraw < 0) break;
     }
     }
     if (WPB == 1) __builtin_amdgcn_wave_barrier();
