@@ -646,7 +646,7 @@ constexpr float PX_OFF = 1.0e30f;   // y coordinate of a finished / out-of-image
 // tile's waves form ONE workgroup and stage each batch (64 entries per wave) once for all of them: the records are
 // gathered once per tile instead of once per wave, at the price of two workgroup barriers per batch.
 template <bool OBJ, int NPX, int WPB = 1>
-__global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
+__global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 1) k_render_fwd(RenderArgs a) {
   constexpr int NSUB = PXL / NPX;
   static_assert(WPB == 1 || WPB == NSUB, "a shared workgroup holds all the waves of a tile");
   constexpr int BATCH = 64 * WPB;
@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
   __shared__ float4 s1[BATCH];
   __shared__ float4 s2[BATCH];                             // (blue, threshold | mask, -, -): 16-byte pitch like s0 / s1, so that
                                                            // the three reads of an entry share ONE address register
-  __shared__ float so[OBJ ? BATCH : 1][NUM_OBJ];
+  __shared__ __attribute__((aligned(16))) float so[OBJ ? BATCH : 1][NUM_OBJ];   // read as four 16-byte words per entry
   __shared__ uint32_t salive[WPB];
   const int lane = threadIdx.x & 63;
   const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to be
@@ -730,6 +730,81 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
     if (WPB > 1) mine = (__float_as_uint(s2[jb + lane].y) >> (sub * NPX)) & ((1u << NPX) - 1u);
     // entries of the batch that reach this wave's strips: the walk visits only these (an entry of the tile that
     // touches only the other waves' strips costs nothing here)
+    if (OBJ) {
+    // With the 16 object channels composited the walk keeps its round-3 form (one rotating register set, the strip
+    // mask fetched from the staged record): the trimmed walk below, built for the two-strip kernel without them,
+    // left this one slower (K6 0.30 -> 0.33-0.36 ms: a wave per SIMD lost to the second register set, and the
+    // feature reads split into 4- and 8-byte pieces).
+    uint64_t todo = __ballot(mine != 0u);
+    if (todo != 0ull && alive) {
+    int j = __builtin_ctzll(todo);
+    float4 n0 = s0[jb + j], n1 = s1[jb + j];
+    float2 n2 = make_float2(s2[jb + j].x, s2[jb + j].y);
+    while (alive) {
+      const float4 e0 = n0, e1 = n1;
+      const float2 e2 = n2;
+      const int jc = j;
+      // Next entry of the batch that reaches this wave (the scalar unit is shared by the CU's four SIMDs and this
+      // loop leans on it: three scalar instructions instead of the eight the compiler makes of the C expressions).
+      // After the last entry s_ff1 returns -1: the prefetch below then reads slot 63, which is never used.
+      int jraw;
+      asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
+      const bool more = jraw >= 0;
+      j = jraw & 63;                          // prefetch the next entry while this one is composited
+      n0 = s0[jb + j]; n1 = s1[jb + j]; n2 = make_float2(s2[jb + j].x, s2[jb + j].y);
+      const uint32_t m = (__builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) >> (WPB > 1 ? sub * NPX : 0)) & alive;
+      const uint32_t pos = base - rg.x + (uint32_t)(jb + jc) + 1;
+      if (m != 0u) {
+      const float dx = e0.x - pxf;
+      const float qa = e0.z * dx * dx, bdx = e0.w * dx;
+#pragma unroll
+      for (int k = 0; k < NPX; ++k) {
+        if (m & (1u << k)) {
+          const float dy = e0.y - pyf[k];
+          const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
+          const float G = __builtin_amdgcn_exp2f(p2);
+          const float alpha = fminf(ALPHA_CAP, e1.y * G);
+          const float Tn = T[k] * (1.f - alpha);
+          // valid = the reference's alpha test (finished pixels: p2 = -inf, alpha = 0), stop = the pixel ends in front
+          // of this entry, contrib = the entry is blended.  With two or four strips per wave the lane masks are kept as
+          // scalars (s_and / s_andn2 of ballots, selects through inverse_ballot, instead of a second pair of vector
+          // compares): 72 -> 64 VGPRs at four strips, 0.203 -> 0.200 ms on S-nyc-1M; the one-strip kernel is 2 % faster
+          // with the plain form (S-hydrant-full 0.2095 vs 0.2140 ms).
+          bool stop, contrib;
+          uint64_t sm;
+          if (NPX >= 2) {
+            const uint64_t vm = __builtin_amdgcn_ballot_w64(p2 <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
+            const uint64_t lt = __builtin_amdgcn_ballot_w64(Tn < T_STOP);
+            sm = vm & lt;
+            stop = __builtin_amdgcn_inverse_ballot_w64(sm);
+            contrib = __builtin_amdgcn_inverse_ballot_w64(vm & ~lt);
+          } else {
+            const bool valid = (p2 <= 0.f) && (alpha >= ALPHA_MIN);
+            stop = valid && (Tn < T_STOP);
+            contrib = valid && !stop;
+            sm = 0;
+          }
+          const float w = contrib ? alpha * T[k] : 0.f;
+          C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
+          if (OBJ) {
+#pragma unroll
+            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[jb + jc][c], w, O[k][c]);
+          }
+          T[k] = contrib ? Tn : T[k];
+          last[k] = contrib ? pos : last[k];
+          pyf[k] = stop ? PX_OFF : pyf[k];
+          if (NPX >= 2) {
+            if (sm != 0ull && __builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
+          } else {
+            if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
+          }
+        }
+      }
+      }
+      if (!more) break;
+    }
+    }
+    } else {
     // sb[k]: the batch entries that reach strip k while it is alive (one scalar bit test per entry and strip, no mask to
     // fetch from the staged record); todo: their union.  A strip that finishes takes its entries out of both.
     uint64_t sb[NPX], todo = 0ull;
@@ -785,8 +860,15 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
           const float w = contrib ? alpha * T[k] : 0.f;
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
           if (OBJ) {
+            // the entry's 16 object features as four 16-byte LDS reads (left to itself the compiler pairs them for packed
+            // FMAs at odd offsets: one 12-byte read, six 2 x 4-byte reads and two singles per strip, K6 0.30 -> 0.36 ms)
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v* sp4 = reinterpret_cast<const f4v*>(&so[jb + jc][0]);
+            f4v q0 = sp4[0], q1 = sp4[1], q2 = sp4[2], q3 = sp4[3];
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));     // the four words stay four 128-bit registers
+            const float f[NUM_OBJ] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
-            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[jb + jc][c], w, O[k][c]);
+            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(f[c], w, O[k][c]);
           }
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
@@ -824,6 +906,7 @@ __global__ void __launch_bounds__(64 * WPB) k_render_fwd(RenderArgs a) {
       a0 = s0[jb + j]; a1 = s1[jb + j]; a2 = make_float2(s2[jb + j].x, s2[jb + j].y);
       composite(b0, b1, b2, jc);
       if (jraw < 0) break;
+    }
     }
     }
     if (WPB == 1) __builtin_amdgcn_wave_barrier();
@@ -967,7 +1050,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   __shared__ float4 s1[64];
   __shared__ float2 s2[64];
   __shared__ uint32_t sslot[64];
-  __shared__ float so[OBJ ? 64 : 1][NUM_OBJ];
+  __shared__ __attribute__((aligned(16))) float so[OBJ ? 64 : 1][NUM_OBJ];
   __shared__ __attribute__((aligned(16))) float sred[RB * RENTRY];
   const int lane = threadIdx.x;
   int item;
