@@ -965,7 +965,9 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
 // ------------------------------------------------------------------------------------------------
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+  // (quad permutations read no lane outside the row: bound_ctrl lets the compiler fold the move into the add that
+  // follows instead of clearing a destination register first)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, CTRL < 0x100));
 }
 __device__ __forceinline__ float wave_sum_to_hi(float v) {
   v += dpp_mov<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
@@ -1256,8 +1258,9 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         // afterwards leaves dg (summed over lanes l, l+32) in lanes < 32 and db in lanes >= 32.  (The clang builtin
         // returns a broken second result in ROCm 7.2, hence inline asm; the s_nop covers the VALU-write ->
         // permlane-read wait states, which hipcc does not insert around asm.)
-        float fa = dg, fb = db;
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(fa), "+v"(fb));
+        // (dg and db themselves: the entry is done with them, and swapping copies costs a register move)
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(dg), "+v"(db));
+        const float fa = dg, fb = db;
         float* w = &sred[red_n * RENTRY + red_wofs];
         if (GEOM) {
           const float a0 = sq * dx;
@@ -1273,7 +1276,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
           w[0] = dr;
           w[RED_REG] = fa + fb;
         }
-        red_j = lane == red_n ? j : red_j;
+        if (RB > 1) red_j = lane == red_n ? j : red_j;      // (one entry per sum: its index is the scalar j itself)
         ++red_n;
         if (OBJ) {
 #pragma unroll
@@ -1292,7 +1295,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int jm = __builtin_amdgcn_ds_bpermute(red_e << 2, red_j);
+        const int jm = RB > 1 ? __builtin_amdgcn_ds_bpermute(red_e << 2, red_j) : j;
         if (red_e < red_n) {
           const float4* ch = reinterpret_cast<const float4*>(&sred[RED_ROW * lane]);
           const float4 q0 = ch[0], q1 = ch[1];
