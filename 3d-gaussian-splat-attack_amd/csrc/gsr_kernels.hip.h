@@ -872,13 +872,12 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
           }
           T[k] = contrib ? Tn : T[k];
           last[k] = contrib ? pos : last[k];
-          pyf[k] = stop ? PX_OFF : pyf[k];
-          // (a strip that has just finished takes its entries out of `todo`; with the wave's last strip `todo` is empty:
-          // the walk's only exit test is "no entry left")
-          if (NPX >= 2) {
-            if (sm != 0ull && __builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) strip_done(k);
-          } else {
-            if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) strip_done(k);
+          // A pixel ends in front of an entry only now and then: its y moves off the image inside that rare branch.
+          // (A strip that has just finished takes its entries out of `todo`; with the wave's last strip `todo` is empty:
+          // the walk's only exit test is "no entry left".)
+          if (NPX >= 2 ? sm != 0ull : __ballot(stop) != 0ull) {
+            pyf[k] = stop ? PX_OFF : pyf[k];
+            if (__builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) strip_done(k);
           }
         }
       }
