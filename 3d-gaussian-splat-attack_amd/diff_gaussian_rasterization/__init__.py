@@ -444,7 +444,10 @@ class RenderCache:
     scale modifier / SH degree / flags, run gsr_ctx_rerender: the colour half of K1 and the compositor K6 over the kept
     lists -- projection, both sorts, the emission and the schedule are not redone.  Anything else (a stepped geometry
     tensor, another camera behind the key, a non-dense input) silently takes the full forward and replaces the entry.
-    Image and gradients are bit for bit those of the uncached call (tests/test_gpu_rerender.py).
+    Image and gradients are bit for bit those of the uncached call (tests/test_gpu_rerender.py).  "Unchanged" is what
+    autograd itself goes by: an edit that bypasses a tensor's version counter (through `.data`, or a kernel writing
+    through the raw pointer without bumping it) is not seen -- the reference's step functions (attack.py:25-173) and
+    this package's fused step both go through the counter.
 
     One context per key: a render overwrites the per-pixel state the previous render's backward reads.  While the
     previous differentiable render of a key is still waiting for its backward (its graph is alive and has not been
@@ -596,7 +599,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
         objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if obj is not None
                    else _zero_scalar(device).expand(NUM_OBJECTS, H, W))
-        radii = torch.empty(P, dtype=torch.int32, device=device)
+        radii = None
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
         entry = None
@@ -624,6 +627,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 nren.value = entry.nren
             else:
                 want_ctx = keep or (cache_slot is not None and P > 0 and sig is not None)
+                radii = torch.empty(P, dtype=torch.int32, device=device)
                 rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
                                          _ptr(ro), _ptr(color), _ptr(objects) if obj is not None else None, _ptr(radii),
                                          ctypes.byref(handle) if want_ctx else None,
