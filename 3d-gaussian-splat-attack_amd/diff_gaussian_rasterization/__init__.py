@@ -486,12 +486,22 @@ class RenderCache:
 
 
 def _cache_sig(tensors, rs: "GaussianRasterizationSettings", extra=()):
-    """What must be unchanged for a kept context to be re-rendered: the geometry tensors (identity is checked through
-    weak references; here their storage and versions), the camera tensors, and the scalar settings."""
-    cam = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (rs.viewmatrix, rs.projmatrix, rs.campos))
-    geo = tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors)
-    return (geo, cam, int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
-            float(rs.scale_modifier), int(rs.sh_degree), int(_FLAGS)) + tuple(extra)
+    """What must be unchanged for a kept context to be re-rendered: storage and autograd version of the geometry and
+    the camera tensors (their identity is checked through weak references besides: same object + same version means same
+    shape and contents), and the scalar settings.  One flat tuple: this runs on every cached render."""
+    sig = [int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier),
+           int(rs.sh_degree), _FLAGS]
+    for t in tensors:
+        if t is None:
+            sig.append(None)
+        else:
+            sig.append(t.data_ptr())
+            sig.append(t._version)
+    for t in (rs.viewmatrix, rs.projmatrix, rs.campos):
+        sig.append(t.data_ptr())
+        sig.append(t._version)
+    sig.extend(extra)
+    return tuple(sig)
 
 
 def _entry_enter(entry: _CacheEntry, device):
