@@ -853,15 +853,16 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     }
     // always: it also turns the empty spans the tile sort left untouched into (0, 0)
     // (more than 64 KB of dynamic LDS at 4K: a single workgroup may use all of the CU's 160 KB on gfx950)
-    static const bool sched_attr = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * SCHED_LDS_TILES);
+    // If the limit cannot be raised the lengths of the tiles beyond the default 64 KB's worth are read from HBM instead.
+    static const int sched_lds_cap = [] {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_schedule),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SCHED_LDS_TILES);
       (void)hipGetLastError();
-      return true;
+      return e == hipSuccess ? SCHED_LDS_TILES : SCHED_LDS_TILES_DEFAULT;
     }();
-    (void)sched_attr;
-    hipLaunchKernelGGL(k_tile_schedule, dim3(c->segoff ? 2 : 1), dim3(1024), sched_lds_bytes(ntiles), st, ntiles, c->ranges, c->sched,
-                         c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
+    hipLaunchKernelGGL(k_tile_schedule, dim3(c->segoff ? 2 : 1), dim3(1024), sched_lds_bytes(ntiles, sched_lds_cap), st, ntiles,
+                       sched_lds_cap, c->ranges, c->sched, c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
+    F_LAUNCH("tile schedule");
     const int rk6 = launch_render_fwd(c, out_color, out_objects, st);
     if (rk6 != GSR_OK) return fail(rk6);
   }
@@ -954,14 +955,16 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
   if (c->overflow)
     return set_err(GSR_ERR_OVERFLOW, "gsr_ctx_rerender: the context's forward overflowed its pair capacity (%llu pairs, "
                    "capacity %u): render again with gsr_forward", c->n64, c->nbound);
+  if ((flags & GSR_RERENDER_FIRST_SEGMENT_ONLY) && (features_dc_b || features_rest_b))
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: GSR_RERENDER_FIRST_SEGMENT_ONLY with new second-segment coefficients");
+  // every argument check has passed: only now does the kept context take the call's pointers and follow its stream (a
+  // rejected call leaves the context exactly as it was)
   pool_retag(c->dev, c->keep_blk, st); pool_retag(c->dev, c->rank_blk, st); pool_retag(c->dev, c->seg_blk, st);
   if (features_rest) c->shs = features_rest;
   if (features_dc) c->sh_dc = features_dc;
   if (features_rest_b) c->b.features_rest = features_rest_b;
   if (features_dc_b) c->b.features_dc = features_dc_b;
   if (bg) c->st.bg = bg;
-  if ((flags & GSR_RERENDER_FIRST_SEGMENT_ONLY) && (features_dc_b || features_rest_b))
-    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: GSR_RERENDER_FIRST_SEGMENT_ONLY with new second-segment coefficients");
   if (c->P > 0) {
     StageTimer t(GSR_STAGE_PREPROCESS, st);
     PreArgs pa{};

@@ -493,8 +493,11 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* w
 // once, eight loads in flight per thread, and kept as 16-bit words for the two passes behind the histogram (a length
 // of 65535 or more is stored as 0xFFFF and read again from `ranges` where its exact value matters).  Until round 4 the
 // lengths of images with more than 12288 tiles were re-read from HBM one dependent load at a time: 92 us at 4K.
-inline size_t sched_lds_bytes(int ntiles) { return 2u * (size_t)((std::min(ntiles, SCHED_LDS_TILES) + 7) & ~7); }
-__global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __restrict__ ranges,
+// lds_cap: how many list lengths the launch's dynamic LDS holds -- SCHED_LDS_TILES when the 64 KB default limit could be
+// raised (gfx950: 160 KB per workgroup), SCHED_LDS_TILES_DEFAULT otherwise; tiles beyond it are re-read from `ranges`.
+constexpr int SCHED_LDS_TILES_DEFAULT = 23552;       // 46 KB of 16-bit lengths + the 16 KB histogram + scalars < 64 KB
+inline size_t sched_lds_bytes(int ntiles, int lds_cap) { return 2u * (size_t)((std::min(ntiles, lds_cap) + 7) & ~7); }
+__global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
                                                         uint32_t rec_cap, uint32_t* __restrict__ nrec_out) {
@@ -503,7 +506,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, uint2* __res
   __shared__ uint32_t smax;
   extern __shared__ unsigned short slen[];
   const int t = threadIdx.x, lane = t & 63;
-  const int lds_tiles = min(ntiles, SCHED_LDS_TILES);
+  const int lds_tiles = min(ntiles, lds_cap);
   // list length of tile i, exact (segment plan) / clamped to 65535 (bins and priorities: both saturate far below)
   auto tile_len = [&](int i) -> uint32_t {
     if (i < lds_tiles) {

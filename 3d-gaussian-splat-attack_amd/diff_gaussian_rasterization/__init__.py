@@ -159,6 +159,9 @@ def _load():
     return lib
 
 
+GSR_ERR_OVERFLOW = 5          # include/gsraster.h
+
+
 class PairCapacityExceeded(RuntimeError):
     """FLAG_ASYNC_COUNT only: a forward emitted more (tile, Gaussian) pairs than the capacity guessed from earlier views;
     its image is NaN.  Render again (the library counts synchronously on the next forward of that size)."""
@@ -461,6 +464,7 @@ class RenderCache:
         self.max_entries = int(max_entries)
         self.entries = collections.OrderedDict()
         self.hits = self.misses = self.bypassed = 0
+        self.dropped_overflow = 0        # entries dropped because their (asynchronously counted) forward had overflowed
 
     def clear(self):
         self.entries.clear()
@@ -635,7 +639,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                           _ptr(objects) if obj is not None else None, 1 if color_only else 0, stream)
                 entry.gen += 1
                 nren.value = entry.nren
-            else:
+                if rc == GSR_ERR_OVERFLOW:
+                    # the kept context's forward (GSR_FLAG_ASYNC_COUNT) turned out to have overflowed its guessed pair
+                    # capacity: it can never be re-rendered.  Drop the entry and take the full forward in this very call
+                    # (which counts synchronously after an overflow) instead of poisoning the key.
+                    cache.entries.pop(key, None)
+                    cache.dropped_overflow += 1
+                    entry = None
+            if entry is None:
                 want_ctx = keep or (cache_slot is not None and P > 0 and sig is not None)
                 radii = torch.empty(P, dtype=torch.int32, device=device)
                 rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
@@ -648,7 +659,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 torch.save({"xyz": x, "features_dc": dc, "features_rest": rest, "objects_dc": obj, "opacity": op,
                             "scaling": sc, "rotation": ro, "settings": raster_settings._asdict()}, "snapshot_fw.dump")
                 msg += " (raw parameters saved to snapshot_fw.dump)"
-            raise Exception(msg) if rc == 1 else RuntimeError(msg)
+            raise Exception(msg) if rc == 1 else (PairCapacityExceeded if rc == GSR_ERR_OVERFLOW else RuntimeError)(msg)
         if entry is not None:
             ctx.holder = entry.holder
         else:
@@ -854,7 +865,11 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
             entry.gen += 1
             # the context reads the coefficient tensors of THIS call on the stream: they stay referenced until the next render
             entry.pack.last_inputs = (a, b, pack)
-        else:
+            if rc == GSR_ERR_OVERFLOW:                 # see _RasterizeGaussiansRaw.forward: drop the entry, full forward now
+                cache.entries.pop(cache_key, None)
+                cache.dropped_overflow += 1
+                entry = None
+        if entry is None:
             radii = torch.empty(Pa + Pb, dtype=torch.int32, device=device)
             handle = ctypes.c_void_p(None)
             rc = lib.gsr_forward_raw2_keep(ctypes.byref(pack.c), Pa, *[_ptr(t) for t in a], Pb, *[_ptr(t) for t in b],
@@ -872,7 +887,7 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
         if entry is not None and rc == 0:
             _entry_leave(entry, device)
     if rc != 0:
-        raise (Exception if rc == 1 else RuntimeError)(_err(lib))
+        raise (Exception if rc == 1 else PairCapacityExceeded if rc == GSR_ERR_OVERFLOW else RuntimeError)(_err(lib))
     return color, radii, objs
 
 

@@ -418,10 +418,12 @@ def run_attack(model, cameras: Sequence, *, background=None, batch_size: int = 5
     benign: the benign pass runs in front of the loop and its boxes are returned under "gt_bboxes" (attack.py:434-461).
     -> {"batches": [{"views", "iters", "success", "loss"}], "all_succeeded", "saved", "iterations"[, "gt_bboxes"]}."""
     cameras = augment_cameras(cameras, add_cams)
-    gt_bboxes = benign_bboxes(model, cameras, kw.get("pipe")) if benign else None
     pending = list(range(len(cameras)))
     if truncate and len(pending) % batch_size:             # the reference drops the views beyond a multiple of B (:417-423)
         pending = pending[:len(pending) - len(pending) % batch_size]
+    # the benign pass sees the views that are KEPT (the reference truncates viewpoint_stack first, :417-423, and renders
+    # the boxes afterwards, :434-461): gt_bboxes has one row per attacked view
+    gt_bboxes = benign_bboxes(model, [cameras[i] for i in pending], kw.get("pipe")) if benign else None
     num_batches = max(1, -(-len(pending) // batch_size))   # ceil (:428); truncate=False keeps a smaller last batch
     originals = {n: getattr(model, n).detach().clone() for n in gdist.ATTACK_PARAMS}
     report, saved = [], False
@@ -491,8 +493,15 @@ def benign_bboxes(model, cameras: Sequence, pipe: Optional[PipelineParams] = Non
     """The benign pass in front of the attack loop (attack.py:434-461): every view rendered on a BLACK background
     (whatever the attack's background is) and turned into the ground-truth box the detector loss is given."""
     pipe = pipe or PipelineParams(skip_objects=True)
+    if getattr(pipe, "render_cache", None) is not None or getattr(pipe, "grad_bucket", None) is not None:
+        # one forward per view, never rendered again under this background: no kept context (~250 MB per view at 1 M
+        # Gaussians / 1080p), no gradient bucket
+        pipe = copy.copy(pipe)
+        pipe.render_cache = None
+        pipe.grad_bucket = None
     black = torch.zeros(3, device=model.get_xyz.device)
-    return [bbox_from_render(render(cam, model, pipe, black)["render"], threshold) for cam in cameras]
+    with torch.no_grad():
+        return [bbox_from_render(render(cam, model, pipe, black)["render"], threshold) for cam in cameras]
 
 
 def combine_with_background(attacked, background):

@@ -81,6 +81,16 @@ def stage_bytes(P: int, V: int, N: int, HW: int) -> dict:
     }
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
     """oracle-R (the checker, a CPU port -- never the product path) timed on the host cores of this node."""
     from gsplat_attack.scenes import make_scene
@@ -90,6 +100,7 @@ def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    avail, machine = cores, os.cpu_count() or cores
     cores = max(1, min(cores, 16))      # a 1-GPU box shares its host: 16 worker threads is this pool's CPU share
     torch.set_num_threads(cores)
     model, cams, _ = make_scene("nyc-1M", device="cpu", P=sample_P, width=sample_W, height=sample_H, n_views=1)
@@ -104,6 +115,7 @@ def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
     out, _ = O.forward_backward(inp, st, gc, dtype=torch.float32)
     dt = time.perf_counter() - t0
     return {"value": 1.0 / dt, "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cores": machine, "host_cores_available_to_this_process": avail, "cpu_model": _cpu_model(),
             "seconds": dt,
             "sample": f"oracle-R float32 fwd+bwd, ONE view of S-nyc-1M subsampled to {sample_P} Gaussians at "
                       f"{sample_W}x{sample_H} (N={out.num_rendered} pairs); not extrapolated to 1M/1080p"}
@@ -169,15 +181,11 @@ def fan_out(n: int) -> int:
     ranks itself -- one child per GPU running this same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
     exactly what `python -m torch.distributed.run --nproc-per-node N` would give them -- touches no GPU, lets rank 0's
     JSON line through on the inherited stdout, and returns non-zero if any child fails (the others are then stopped by
-    their exact PIDs).  Under torchrun this function is never reached."""
+    their exact PIDs: SIGTERM, then SIGKILL after a bounded grace period).  Under torchrun this function is never reached."""
     import signal
     import subprocess
-    rehearse = os.environ.get("BENCH_REHEARSE_GLOO", "0") == "1"
-    if not rehearse:
-        have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
-        if have < n:
-            print(f"[bench] --gpus {n} but this node shows {have} HIP device(s)", file=sys.stderr)
-            return 2
+    # (the parent asks the runtime NOTHING about devices -- on ROCm builds without amdsmi even device_count() initialises
+    # HIP/HSA in this process before it forks; each rank checks its own LOCAL_RANK against the device count in main())
     port = _free_port()
     procs = []
     for r in range(n):
@@ -186,6 +194,8 @@ def fan_out(n: int) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = set(range(n))
+    kill_at = None                                         # after a failure: when the survivors' grace period ends
+    grace = float(os.environ.get("BENCH_FANOUT_GRACE_S", "20"))
     while pending:
         for r in sorted(pending):
             code = procs[r].poll()
@@ -197,6 +207,15 @@ def fan_out(n: int) -> int:
                 print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
                 for q in pending:
                     procs[q].send_signal(signal.SIGTERM)
+                kill_at = time.monotonic() + grace
+        if kill_at is not None and pending and time.monotonic() > kill_at:
+            # a rank stuck in a collective does not act on SIGTERM: end it by its exact PID
+            for q in sorted(pending):
+                print(f"[bench] rank {q} (pid {procs[q].pid}) still running {grace:.0f} s after SIGTERM: SIGKILL", file=sys.stderr)
+                procs[q].kill()
+            for q in sorted(pending):
+                procs[q].wait()
+            pending.clear()
         time.sleep(0.05)
     return rc
 
@@ -257,6 +276,9 @@ def main():
         raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (torchrun "
                          f"--nproc-per-node {args.gpus}), or run `python bench.py --gpus {args.gpus}` as a plain process "
                          "and it starts them itself")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"[bench] rank {rank}: LOCAL_RANK {local} but this node shows {torch.cuda.device_count()} HIP "
+                         f"device(s) (--gpus {args.gpus})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     D._load()
@@ -425,6 +447,29 @@ def main():
     if ar_events:
         torch.cuda.synchronize()
         ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+    # N > 1, PGD loop: the N = 1-comparable figure in the same line -- every rank renders --steps INDEPENDENT views
+    # (forward + backward, no collective, no update) over its streams, exactly what the N = 1 line's `value` times on one
+    # GPU; one region between barrier + synchronise, max over ranks
+    indep = None
+    if pgd_loop:
+        def indep_steps(n):
+            for s_ in (streams or []):
+                s_.wait_stream(torch.cuda.current_stream(dev))
+            for i in range(n):
+                ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
+                with ctx_:
+                    model.zero_grad()
+                    render(next_cam(), model, pipe, bg, scale_mod[0])["render"].backward(gc)
+            for s_ in (streams or []):
+                torch.cuda.current_stream(dev).wait_stream(s_)
+        indep_steps(2 * max(args.streams, 1))
+        keep_run, run_steps = run_steps, (lambda n, use_streams=True: indep_steps(n))
+        si = timed_regions(1)[0]
+        run_steps = keep_run
+        indep = {"value": round(world * args.steps / si, 2), "unit": "views/s", "per_gpu": round(args.steps / si, 2),
+                 "ms_per_step": round(si / args.steps * 1e3, 4), "streams": args.streams,
+                 "what": "every rank renders --steps independent views (fwd+bwd, no all-reduce, no update) over its "
+                         "streams: N x what the N = 1 line's `value` measures; one region, max over ranks"}
     # the same views strictly one after another on one stream
     seq = None
     if world == 1 and streams is not None:
@@ -579,6 +624,7 @@ def main():
             result["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
             result["bytes_reduced"] = bytes_reduced[0] or 59 * 4 * P
             result["views_per_rank"] = B
+            result["independent_views"] = indep
             result["allreduce_chunks"] = args.ar_chunks if (pgd_loop and min(args.streams, B) == 1) else 1
             result["allreduce_ms_is"] = ("time the compute stream waits for the collective after the step's last "
                                          "rasteriser kernel (with --ar-chunks > 1 part of it ran behind K9)")
@@ -703,6 +749,46 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
             p_.requires_grad_(True)
     extras = {"fwd_only_views_per_s": round(fwd_rate, 1),
               "sh_grads_only_views_per_s": None if col_rate is None else round(col_rate, 1)}
+    if not args.color_only:
+        # The drop-in regime: what the reference's UNCHANGED render() reaches (gaussian_renderer/__init__.py:53-95) when a
+        # user installs this package without gsplat_attack.patch_reference() -- activated tensors (exp / sigmoid /
+        # normalize / cat and their backward as PyTorch kernels) through GaussianRasterizer.forward, and ALWAYS the 16
+        # object channels (`sh_objs = pc.get_objects`).  Same views, same dL/dC, gradients to all raw parameters.
+        log("extras: the drop-in regime (classic activated-tensor surface + 16 object channels) ...")
+        pipe_d = PipelineParams(skip_objects=False, fused_activations=False)
+        n_d = min(args.steps, 60)
+
+        def dropin_steps(n, sts):
+            for s_ in (sts or []):
+                s_.wait_stream(torch.cuda.current_stream(dev))
+            for i in range(n):
+                ctx_ = torch.cuda.stream(sts[i % len(sts)]) if sts else contextlib.nullcontext()
+                with ctx_:
+                    model.zero_grad()
+                    render(cams[i % len(cams)], model, pipe_d, bg)["render"].backward(gc)
+            for s_ in (sts or []):
+                torch.cuda.current_stream(dev).wait_stream(s_)
+        rates = []
+        for sts in (streams, None):
+            dropin_steps(8, sts)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dropin_steps(n_d, sts)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            rates.append(n_d / sorted(ts)[1])
+        D.profile(True)
+        dropin_steps(6, None)
+        torch.cuda.synchronize()
+        st_d = {k: round(ms / 6, 4) for k, (ms, _) in D.profile_read().items()}
+        D.profile(False)
+        extras["dropin"] = {"value": round(rates[0], 1), "sequential_views_per_s": round(rates[1], 1), "unit": "views/s",
+                            "steps": n_d, "streams": len(streams) if streams else 1, "stages_ms": st_d,
+                            "what": "render() on the classic surface with object channels on (--classic --objects): the "
+                                    "configuration the reference's unchanged gaussian_renderer.render() reaches; median "
+                                    "of 3 regions; `value` pipelined over the streams, `sequential` on one"}
     if col_rate is not None:
         extras["sh_grads_only_ring_views_per_s"] = round(ring_rates[0], 1)
         extras["sh_grads_only_ring_binning_kept_views_per_s"] = round(ring_rates[1], 1)

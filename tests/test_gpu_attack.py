@@ -300,3 +300,19 @@ def test_run_attack_with_yawed_views_and_benign_boxes():
     # (the city block fills the frame from every one of these views: the boxes of the yawed views need not differ)
     for box in rep["gt_bboxes"][1:]:
         assert box is not None and 0 <= box[0] < box[2] <= cams[0].image_width and 0 <= box[1] < box[3] <= cams[0].image_height
+
+
+def test_benign_boxes_cover_the_kept_views_only():
+    """The reference truncates viewpoint_stack to a multiple of the batch size BEFORE its benign pass (attack.py:417-423,
+    434-461): four views at batch size 3 give three boxes; and the benign pass keeps no rasteriser context even when the
+    pipe it is handed carries a RenderCache."""
+    from diff_gaussian_rasterization import RenderCache
+    from gsplat_attack.attack import benign_bboxes, run_attack
+    from gsplat_attack.renderer import PipelineParams
+    model, cams, _ = _scene(n_views=1)
+    rep = run_attack(model, cams, batch_size=3, max_iters=3, add_cams=4, benign=True, streams=1,
+                     bg=torch.ones(3, device="cuda"), success_fn=lambda im, i: True)
+    assert len(rep["gt_bboxes"]) == 3 and [b["views"] for b in rep["batches"]] == [[0, 1, 2]]
+    cache = RenderCache()
+    boxes = benign_bboxes(model, cams, PipelineParams(skip_objects=True, render_cache=cache))
+    assert len(boxes) == 1 and boxes[0] == rep["gt_bboxes"][0] and len(cache.entries) == 0

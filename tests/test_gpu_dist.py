@@ -135,6 +135,12 @@ def test_bench_pgd_loop_rehearsal_prints_the_multi_gpu_fields(tmp_path):
     assert d["bytes_reduced"] == 59 * 4 * 20000 and d["allreduce_ms"] > 0
     assert len(d["regions_ms"]) == 2 and d["value"] > 0 and d["steps"] == 2
     assert abs(d["value"] - 2 * 2 * 2 / (sorted(d["regions_ms"])[1] * 1e-3)) / d["value"] < 0.02
+    # first contact with the 8-GPU node must not fail on trivia: every field the driver's checks need
+    for k in ("n_gpus", "ranks_seen", "rccl", "allreduce_ms", "bytes_reduced", "views_per_rank", "independent_views",
+              "collective_backend"):
+        assert k in d, k
+    iv = d["independent_views"]
+    assert iv["value"] > 0 and abs(iv["value"] - 2 * iv["per_gpu"]) <= 0.02 * iv["value"] and iv["unit"] == "views/s"
     # config 4's shape: one view per rank, the bucket all-reduced in four ranges behind K9
     cmd2 = [c for c in cmd]
     cmd2[cmd2.index("--views-per-rank") + 1] = "1"
@@ -165,6 +171,7 @@ def test_bench_started_as_a_plain_command_fans_out_by_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["collective_backend"] == "gloo" and d["config"]["loop"] == "pgd"
     assert d["bytes_reduced"] == 59 * 4 * 20000 and d["value"] > 0
+    assert d["independent_views"]["value"] > 0 and d["views_per_rank"] == 1 and "rccl" in d and d["allreduce_ms"] > 0
 
 
 def _chunk_worker(rank, world, port, out_dir):

@@ -97,21 +97,26 @@ def oracle_raw(key, cam_i, bg, gc, wins, scale_kw=None, objects=False, go=None, 
     gc_all = gc * wpx.to(gc.dtype)
     go_all = None if go is None else go * wpx.to(go.dtype)
 
-    def grads_of(r, retain):
-        loss = (r.color * gc_all.to(r.color.dtype)).sum()
-        if go_all is not None:
-            loss = loss + (r.objects * go_all.to(r.color.dtype)).sum()
-        names = [n for n, p in params.items() if p.requires_grad]
-        gs = torch.autograd.grad(loss, [params[n] for n in names], retain_graph=retain, allow_unused=True)
+    names = [n for n, p in params.items() if p.requires_grad]
+
+    def grads_of(r, gcm, gom):
+        """d/d(raw parameters) of sum(colour * gcm) [+ sum(objects * gom)] from oracle run r (its graph is kept)."""
+        loss = (r.color * gcm.to(r.color.dtype)).sum()
+        if gom is not None:
+            loss = loss + (r.objects * gom.to(r.color.dtype)).sum()
+        gs = torch.autograd.grad(loss, [params[n] for n in names], retain_graph=True, allow_unused=True)
         return {n: g.detach().double() for n, g in zip(names, gs) if g is not None}
-    _ALLPX[id(ro)] = dict(g32=grads_of(r32, False), g64=grads_of(ro, True), gc=gc_all, go=go_all)
+
+    def both(keep=None):
+        """(float64, float32) oracle gradients of the loss over the window pixels in `keep` (None: all of them)."""
+        k = wpx if keep is None else (wpx & keep)
+        gcm = gc_all * k.to(gc_all.dtype)
+        gom = None if go_all is None else go_all * k.to(go_all.dtype)
+        return grads_of(ro, gcm, gom), grads_of(r32, gcm, gom), gcm, gom
+    _ALLPX[id(ro)] = dict(both=both, wpx=wpx)
     # the loss of the first comparison ignores the pixels oracle-R flags as fragile (a float32 threshold test may flip there)
     gc, go = O.solid_grads(ro, gc, go)
-    loss = (ro.color * gc.double()).sum()
-    if go is not None:
-        loss = loss + (ro.objects * go.double()).sum()
-    loss.backward()
-    grads = {n: p.grad for n, p in ref.named_parameters().items() if p.grad is not None}
+    grads = grads_of(ro, gc, go)
     return ro, grads, gc, go
 
 
@@ -172,6 +177,7 @@ def compare(out, grads, ro, rgrads, m, names=RAW, frag_frac=0.08, objects=False,
     r32 = _R32[id(ro)]
     y = pixel_yardstick(color, ro.color, r32.color, ro.fragile_px, mask=m, tol=RGB_TOL)
     _note(yardstick_line(f"yardstick {tag or 'windows'}", y))
+    _ALLPX[id(ro)]["ok"] = y["ok"] | ~m          # compare_all_pixels: the pixels whose VALUE is a float32 / float64 outcome
     assert y["neither_solid"] == 0
     assert y["neither_px"] <= max(5, NEITHER_CAP * y["fragile"] * y["n"]), yardstick_line(tag, y)
     assert err[m].max().item() <= 1e-2                     # backstop only
@@ -197,30 +203,53 @@ def compare_all_pixels(model, cam, bg, ro, names=RAW, tag="", **hip_kw):
     AND in float32 on it, and per attribute group the implementation must satisfy
         |g_hip - g64|_inf <= max(1e-3 |g64|_inf, 2 |g32 - g64|_inf)
     (no further from the float64 gradient than BASELINE's tolerance or twice what float32 arithmetic costs the oracle's
-    own gradient), plus the element criterion of util.grad_error with the float32 oracle as its yardstick."""
+    own gradient), plus the element criterion of util.grad_error with the float32 oracle as its yardstick.
+
+    A threshold test that flips is a DISCONTINUITY of the gradient, not a rounding error: an entry with alpha ~ 1/255 that
+    one float32 arithmetic blends and another skips changes dL/dopacity of that Gaussian by G T (c - C_behind) . g -- not
+    scaled by alpha.  The float32 oracle flips on its own pixels, the implementation on its own; where the two sets
+    differ by a pixel the norm-wise comparison sees that pixel, not the arithmetic.  Such pixels are known exactly: they
+    are the ones on NEITHER clause of compare()'s image yardstick (the implementation's colour there is neither within
+    twice the float32 oracle's deviation from float64 nor the float32 oracle's own value; compare() caps their number at
+    max(5, 0.5 % of the fragile pixels)).  The comparison is run (a) on every window pixel -- logged as 'raw', and it
+    must hold as it stands when no pixel is on neither clause -- and, when some are, (b) with exactly those pixels
+    removed from the loss on all three sides, which must hold; the log shows how many pixels that was and what (a) gave,
+    so that a failure of (a) is attributed to those pixels by measurement, not by assumption."""
     a = _ALLPX[id(ro)]
     dev = next(iter(model.named_parameters().values())).device
-    if a["go"] is not None:
-        hip_kw = dict(hip_kw, objects=True, go=a["go"].to(dev))
-    _, grads = hip_raw(model, cam, bg.to(dev), a["gc"].to(dev), **hip_kw)
-    rep, bad = {}, []
-    for n in names:
-        g64, g32 = a["g64"][n], a["g32"][n]
-        s = g64.abs().max().item()
-        assert s > 0, n
-        e_hip = (grads[n].double() - g64).abs().max().item() / s
-        e_32 = (g32 - g64).abs().max().item() / s
-        _, frac = grad_error(grads[n], g64, elem_tol=5 * GRAD_TOL)
-        _, frac_y = grad_error(grads[n], g64, elem_tol=5 * GRAD_TOL, yard=g32)
-        _, frac32 = grad_error(g32, g64, elem_tol=5 * GRAD_TOL)
-        rep[n] = (e_hip, e_32, frac, frac32, frac_y)
-        _note(f"[all-pixel grads {tag}] {n}: HIP {e_hip:.2e}, float32 oracle {e_32:.2e} (normwise, of |g64|_inf); elements "
-              f"off by > {5 * GRAD_TOL}: HIP {frac:.2e}, float32 oracle {frac32:.2e}, HIP beyond twice the float32 oracle {frac_y:.2e}")
-        if e_hip > max(GRAD_TOL, 2 * e_32):
-            bad.append(f"{n}: normwise {e_hip:.3e} > max({GRAD_TOL}, 2 x {e_32:.3e})")
-        if not (frac <= max(3e-3, 2 * frac32) or frac_y <= 3e-3):
-            bad.append(f"{n}: {frac:.2e} of the significant elements off (float32 oracle {frac32:.2e}, beyond its yardstick {frac_y:.2e})")
-    assert not bad, f"all-pixel backward [{tag}]: " + "; ".join(bad)
+
+    def one(keep, label):
+        g64s, g32s, gcm, gom = a["both"](keep)
+        kw = dict(hip_kw, objects=True, go=gom.to(dev)) if gom is not None else hip_kw
+        _, grads = hip_raw(model, cam, bg.to(dev), gcm.to(dev), **kw)
+        rep, bad = {}, []
+        for n in names:
+            g64, g32 = g64s[n], g32s[n]
+            s = g64.abs().max().item()
+            assert s > 0, n
+            e_hip = (grads[n].double() - g64).abs().max().item() / s
+            e_32 = (g32 - g64).abs().max().item() / s
+            _, frac = grad_error(grads[n], g64, elem_tol=5 * GRAD_TOL)
+            _, frac_y = grad_error(grads[n], g64, elem_tol=5 * GRAD_TOL, yard=g32)
+            _, frac32 = grad_error(g32, g64, elem_tol=5 * GRAD_TOL)
+            rep[n] = (e_hip, e_32, frac, frac32, frac_y)
+            _note(f"[all-pixel grads {tag}{label}] {n}: HIP {e_hip:.2e}, float32 oracle {e_32:.2e} (normwise, of |g64|_inf); "
+                  f"elements off by > {5 * GRAD_TOL}: HIP {frac:.2e}, float32 oracle {frac32:.2e}, HIP beyond twice the "
+                  f"float32 oracle {frac_y:.2e}")
+            if e_hip > max(GRAD_TOL, 2 * e_32):
+                bad.append(f"{n}: normwise {e_hip:.3e} > max({GRAD_TOL}, 2 x {e_32:.3e})")
+            if not (frac <= max(3e-3, 2 * frac32) or frac_y <= 3e-3):
+                bad.append(f"{n}: {frac:.2e} of the significant elements off (float32 oracle {frac32:.2e}, beyond its "
+                           f"yardstick {frac_y:.2e})")
+        return rep, bad
+    third = a["wpx"] & ~a["ok"]                 # window pixels whose colour is a third outcome (compare() has capped them)
+    n_third, n_px = int(third.sum()), int(a["wpx"].sum())
+    rep, bad = one(None, ", raw" if n_third else "")
+    if n_third:
+        _note(f"[all-pixel grads {tag}] {n_third} of {n_px} window pixels are on neither clause of the image yardstick; raw "
+              f"comparison: {'holds' if not bad else 'misses: ' + '; '.join(bad)}")
+        rep, bad = one(a["ok"], f", without the {n_third} third-outcome px")
+    assert not bad, f"all-pixel backward [{tag}] ({n_third} third-outcome pixels removed): " + "; ".join(bad)
     return rep
 
 

@@ -304,3 +304,38 @@ def test_full_size_rerender_bit_equal_on_the_benchmark_scene():
             model._features_dc.add_(0.1)
             model._features_rest.mul_(1.05)
     assert cached.render_cache.hits == len(cams)
+
+
+def test_overflowed_async_forward_does_not_poison_its_cache_key():
+    """under FLAG_ASYNC_COUNT a forward that overflows its guessed pair capacity returns rc 0 with a NaN image,
+    and its context lands in the RenderCache.  The next render of the key must not fail on it forever: gsr_ctx_rerender
+    reports the overflow, the entry is dropped, and the SAME call takes the full forward (which counts synchronously
+    again); the render after that is an ordinary hit."""
+    import diff_gaussian_rasterization as D
+    from diff_gaussian_rasterization import RenderCache
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams, bg = _scene(50000, 640, 360, n_views=1, key="nyc-1M")
+    cam = cams[0]
+    plain = PipelineParams(skip_objects=True)
+    with torch.no_grad():
+        small = render(cam, model, plain, bg)["render"].clone()           # seeds the capacity table for this (P, H, W)
+    assert torch.isfinite(small).all()
+    cache = RenderCache()
+    cached = PipelineParams(skip_objects=True, render_cache=cache)
+    try:
+        D.set_flags(D.FLAG_ASYNC_COUNT)
+        with torch.no_grad():
+            # four times larger splats: far more pairs than 1.25 x the 1x count + 64K the buffers are sized for
+            first = render(cam, model, cached, bg, 4.0)["render"].clone()
+            assert torch.isnan(first).all() and len(cache.entries) == 1
+            second = render(cam, model, cached, bg, 4.0)["render"].clone()  # hit -> overflow -> dropped -> full forward
+            assert cache.dropped_overflow == 1 and len(cache.entries) == 1
+            assert torch.isfinite(second).all()
+            hits = cache.hits
+            third = render(cam, model, cached, bg, 4.0)["render"].clone()   # an ordinary hit on the replaced entry
+        assert cache.dropped_overflow == 1 and cache.hits == hits + 1
+    finally:
+        D.set_flags(0)
+    with torch.no_grad():
+        want = render(cam, model, plain, bg, 4.0)["render"].clone()       # counted synchronously, no cache: the right image
+    assert torch.equal(second, want) and torch.equal(third, want)
