@@ -313,6 +313,65 @@ bool side_stream_for(int dev, hipStream_t main, SideStream& out) {
   return true;
 }
 
+// EXPERIMENT (GSR_COMP_CUMASK=w0,w1,... hex words): the two VALU-bound compositors K6 / K7 of a caller
+// stream run on a companion stream restricted to the given compute units (hipExtStreamCreateWithCUMask), so that the
+// HBM- and latency-bound kernels of OTHER views' streams always find the remaining CUs free of compositor waves.
+// Two event hops per compositor launch.  Off unless the variable is set.
+struct CompStream { int dev; hipStream_t main, comp; hipEvent_t in, out; };
+std::mutex g_comp_mu;
+std::vector<CompStream> g_comps;
+static const std::vector<uint32_t>& comp_mask_env() {
+  static const std::vector<uint32_t> m = [] {
+    std::vector<uint32_t> v;
+    const char* e = getenv("GSR_COMP_CUMASK");
+    if (e) {
+      const char* p = e;
+      while (*p) {
+        char* end = nullptr;
+        const unsigned long w = strtoul(p, &end, 16);
+        if (end == p) break;
+        v.push_back((uint32_t)w);
+        p = (*end == ',') ? end + 1 : end;
+      }
+    }
+    return v;
+  }();
+  return m;
+}
+bool comp_stream_for(int dev, hipStream_t main, CompStream& out) {
+  const std::vector<uint32_t>& mask = comp_mask_env();
+  if (mask.empty()) return false;
+  std::lock_guard<std::mutex> lk(g_comp_mu);
+  for (const CompStream& s : g_comps)
+    if (s.dev == dev && s.main == main) { out = s; return true; }
+  CompStream s{dev, main, nullptr, nullptr, nullptr};
+  if (hipExtStreamCreateWithCUMask(&s.comp, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
+      hipEventCreateWithFlags(&s.in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s.out, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  g_comps.push_back(s);
+  out = s;
+  return true;
+}
+// hop onto the compositor stream (returns the stream to launch on) and back
+static hipStream_t comp_enter(int dev, hipStream_t st, CompStream& cs, bool& used) {
+  used = comp_stream_for(dev, st, cs);
+  if (!used) return st;
+  if (hipEventRecord(cs.in, st) != hipSuccess || hipStreamWaitEvent(cs.comp, cs.in, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    used = false;
+    return st;
+  }
+  return cs.comp;
+}
+static void comp_leave(hipStream_t st, const CompStream& cs, bool used) {
+  if (!used) return;
+  (void)hipEventRecord(cs.out, cs.comp);
+  (void)hipStreamWaitEvent(st, cs.out, 0);
+}
+
 // Count slots of forwards whose context was released before the copy landed (forward-only calls with an asynchronous
 // count): harvested, without blocking, at the start of later forwards.
 struct PendingSlot { CountSlot slot; CapKey key; };
@@ -497,8 +556,11 @@ struct SegB {
 
 // K6 of a context whose binning (pair list, tile ranges, schedule, boundary-record plan) and splat records are in place:
 // the last launch of a forward, and all that a re-render of a kept context needs behind the colour kernel.
-static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hipStream_t st) {
+static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hipStream_t st_main) {
   const GsrSettings* s = &c->st;
+  CompStream comp_s{};
+  bool comp_used = false;
+  hipStream_t st = comp_enter(c->dev, st_main, comp_s, comp_used);
   const int W = s->image_width, H = s->image_height, ntiles = c->ntiles;
   const size_t HW = (size_t)H * W;
   const float* sh_objs = out_objects ? c->sh_objs : nullptr;
@@ -541,6 +603,7 @@ static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hi
     else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
   }
   hipError_t e = hipGetLastError();
+  comp_leave(st_main, comp_s, comp_used);
   if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "render forward: launch failed: %s", hipGetErrorString(e));
   return GSR_OK;
 }
@@ -1062,10 +1125,13 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->dv + DV_NREC;
     ra.seg_shift = c->seg_shift; ra.extra_blocks = segs ? c->rec_cap * nsub : 0u;
     const dim3 gridT(ra.extra_blocks + (unsigned)render_grid(c->ntiles * (int)nsub)), blk(64);
+    CompStream comp_s{};
+    bool comp_used = false;
+    hipStream_t st7 = comp_enter(dev, st, comp_s, comp_used);
 #define LAUNCH_K7(kern)                                                                      \
   do {                                                                                       \
-    if (t.on) hipExtLaunchKernelGGL(kern, gridT, blk, 0, st, t.a, t.b, 0, ra);               \
-    else hipLaunchKernelGGL(kern, gridT, blk, 0, st, ra);                                    \
+    if (t.on) hipExtLaunchKernelGGL(kern, gridT, blk, 0, st7, t.a, t.b, 0, ra);              \
+    else hipLaunchKernelGGL(kern, gridT, blk, 0, st7, ra);                                   \
   } while (0)
     if (obj) {
       if (geom) {
@@ -1084,6 +1150,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     }
 #undef LAUNCH_K7
     hipError_t e = hipGetLastError();
+    comp_leave(st, comp_s, comp_used);
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "render backward: launch failed: %s", hipGetErrorString(e)));
   }
   {

@@ -648,16 +648,18 @@ constexpr float PX_OFF = 1.0e30f;   // y coordinate of a finished / out-of-image
 // WPB = waves per workgroup: 1 -> every wave is its own workgroup and stages the tile's list for itself; NSUB -> the
 // tile's waves form ONE workgroup and stage each batch (64 entries per wave) once for all of them: the records are
 // gathered once per tile instead of once per wave, at the price of two workgroup barriers per batch.
+#ifndef GSR_K6_OBJ_WAVES
+#define GSR_K6_OBJ_WAVES 5          // waves per SIMD the two-strip object variant is compiled for
+#endif
 template <bool OBJ, int NPX, int WPB = 1>
-__global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 1) k_render_fwd(RenderArgs a) {
+__global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_K6_OBJ_WAVES : 1) k_render_fwd(RenderArgs a) {
   constexpr int NSUB = PXL / NPX;
   static_assert(WPB == 1 || WPB == NSUB, "a shared workgroup holds all the waves of a tile");
   constexpr int BATCH = 64 * WPB;
   __shared__ float4 s0[BATCH];
   __shared__ float4 s1[BATCH];
-  __shared__ float4 s2[BATCH];                             // (blue, threshold | mask, -, -): 16-byte pitch like s0 / s1, so that
-                                                           // the three reads of an entry share ONE address register
-  __shared__ __attribute__((aligned(16))) float so[OBJ ? BATCH : 1][NUM_OBJ];   // read as four 16-byte words per entry
+  __shared__ float4 s2[BATCH];                             // (blue, threshold | mask, Gaussian index, -): 16-byte pitch like s0 /
+                                                           // s1, so that the three reads of an entry share ONE address register
   __shared__ uint32_t salive[WPB];
   const int lane = threadIdx.x & 63;
   const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to be
@@ -703,6 +705,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
     const int slot = (int)threadIdx.x;                    // the batch entry this thread stages
     const uint32_t i = base + (uint32_t)slot;
     uint32_t mine = 0;
+    uint32_t rown = 0;                                    // the staged entry's Gaussian (0 past the end of the list: a valid row)
     if (i < rg.y) {
       const uint32_t pv = a.pair_rank[i];
       const uint32_t r = pv & RANK_MASK;
@@ -710,14 +713,8 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
       // staged mask bits: this wave's strips (own workgroup) or all four strips of the tile (shared workgroup)
       mine = WPB > 1 ? (pv >> RANK_BITS) & 0xFu : ((pv >> RANK_BITS) >> (sub * NPX)) & ((1u << NPX) - 1u);
       const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
-      s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = make_float4(sp.c.x, sp.c.y, 0.f, 0.f);
-      if (OBJ) {
-        const uint32_t og = r;                              // the pair's value IS the Gaussian's storage index
-        const float4* src = reinterpret_cast<const float4*>(og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ
-                                                                                  : a.sh_objs + (size_t)og * NUM_OBJ);
-        float4* dst = reinterpret_cast<float4*>(&so[slot][0]);
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-      }
+      rown = r;                                           // the pair's value IS the Gaussian's storage index
+      s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = make_float4(sp.c.x, sp.c.y, __uint_as_float(r), 0.f);
     } else if (WPB > 1) {
       s2[slot] = make_float4(0.f, 0.f, 0.f, 0.f);         // past the end of the list: reaches no strip
     }
@@ -733,81 +730,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
     if (WPB > 1) mine = (__float_as_uint(s2[jb + lane].y) >> (sub * NPX)) & ((1u << NPX) - 1u);
     // entries of the batch that reach this wave's strips: the walk visits only these (an entry of the tile that
     // touches only the other waves' strips costs nothing here)
-    if (OBJ) {
-    // With the 16 object channels composited the walk keeps its round-3 form (one rotating register set, the strip
-    // mask fetched from the staged record): the trimmed walk below, built for the two-strip kernel without them,
-    // left this one slower (K6 0.30 -> 0.33-0.36 ms: a wave per SIMD lost to the second register set, and the
-    // feature reads split into 4- and 8-byte pieces).
-    uint64_t todo = __ballot(mine != 0u);
-    if (todo != 0ull && alive) {
-    int j = __builtin_ctzll(todo);
-    float4 n0 = s0[jb + j], n1 = s1[jb + j];
-    float2 n2 = make_float2(s2[jb + j].x, s2[jb + j].y);
-    while (alive) {
-      const float4 e0 = n0, e1 = n1;
-      const float2 e2 = n2;
-      const int jc = j;
-      // Next entry of the batch that reaches this wave (the scalar unit is shared by the CU's four SIMDs and this
-      // loop leans on it: three scalar instructions instead of the eight the compiler makes of the C expressions).
-      // After the last entry s_ff1 returns -1: the prefetch below then reads slot 63, which is never used.
-      int jraw;
-      asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
-      const bool more = jraw >= 0;
-      j = jraw & 63;                          // prefetch the next entry while this one is composited
-      n0 = s0[jb + j]; n1 = s1[jb + j]; n2 = make_float2(s2[jb + j].x, s2[jb + j].y);
-      const uint32_t m = (__builtin_amdgcn_readfirstlane(__float_as_uint(e2.y)) >> (WPB > 1 ? sub * NPX : 0)) & alive;
-      const uint32_t pos = base - rg.x + (uint32_t)(jb + jc) + 1;
-      if (m != 0u) {
-      const float dx = e0.x - pxf;
-      const float qa = e0.z * dx * dx, bdx = e0.w * dx;
-#pragma unroll
-      for (int k = 0; k < NPX; ++k) {
-        if (m & (1u << k)) {
-          const float dy = e0.y - pyf[k];
-          const float p2 = fmaf(dy, fmaf(e1.x, dy, bdx), qa);
-          const float G = __builtin_amdgcn_exp2f(p2);
-          const float alpha = fminf(ALPHA_CAP, e1.y * G);
-          const float Tn = T[k] * (1.f - alpha);
-          // valid = the reference's alpha test (finished pixels: p2 = -inf, alpha = 0), stop = the pixel ends in front
-          // of this entry, contrib = the entry is blended.  With two or four strips per wave the lane masks are kept as
-          // scalars (s_and / s_andn2 of ballots, selects through inverse_ballot, instead of a second pair of vector
-          // compares): 72 -> 64 VGPRs at four strips, 0.203 -> 0.200 ms on S-nyc-1M; the one-strip kernel is 2 % faster
-          // with the plain form (S-hydrant-full 0.2095 vs 0.2140 ms).
-          bool stop, contrib;
-          uint64_t sm;
-          if (NPX >= 2) {
-            const uint64_t vm = __builtin_amdgcn_ballot_w64(p2 <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= ALPHA_MIN);
-            const uint64_t lt = __builtin_amdgcn_ballot_w64(Tn < T_STOP);
-            sm = vm & lt;
-            stop = __builtin_amdgcn_inverse_ballot_w64(sm);
-            contrib = __builtin_amdgcn_inverse_ballot_w64(vm & ~lt);
-          } else {
-            const bool valid = (p2 <= 0.f) && (alpha >= ALPHA_MIN);
-            stop = valid && (Tn < T_STOP);
-            contrib = valid && !stop;
-            sm = 0;
-          }
-          const float w = contrib ? alpha * T[k] : 0.f;
-          C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
-          if (OBJ) {
-#pragma unroll
-            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(so[jb + jc][c], w, O[k][c]);
-          }
-          T[k] = contrib ? Tn : T[k];
-          last[k] = contrib ? pos : last[k];
-          pyf[k] = stop ? PX_OFF : pyf[k];
-          if (NPX >= 2) {
-            if (sm != 0ull && __builtin_amdgcn_ballot_w64(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
-          } else {
-            if (__ballot(stop) != 0ull && __ballot(pyf[k] < PX_OFF) == 0ull) alive &= ~(1u << k);
-          }
-        }
-      }
-      }
-      if (!more) break;
-    }
-    }
-    } else {
+    {
     // sb[k]: the batch entries that reach strip k while it is alive (one scalar bit test per entry and strip, no mask to
     // fetch from the staged record); todo: their union.  A strip that finishes takes its entries out of both.
     uint64_t sb[NPX], todo = 0ull;
@@ -828,7 +751,31 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
       for (int q = 0; q < NPX; ++q) rest |= sb[q];
       todo &= rest;
     };
-    auto composite = [&](const float4& e0, const float4& e1, const float2& e2, const int jc) {
+    // The 16 object features of an entry are the same for all 64 lanes: they are fetched with SCALAR loads (one
+    // s_load_dwordx16 from the feature table, issued one entry ahead like the staged record) into scalar registers and
+    // enter the sixteen accumulations as scalar operands.  Rounds 1-4 staged them through LDS and read them back as four
+    // 16-byte vector words per strip: 16 vector registers per register set, which is what kept the object variant on the
+    // round-3 walk (the trimmed walk's second register set cost it a wave per SIMD: K6 0.30 -> 0.36 ms).
+    struct Feat { float4 q[4]; };
+    const uint32_t rvec = OBJ ? (WPB > 1 ? __float_as_uint(s2[jb + lane].z) : rown) : 0u;   // lane l: Gaussian of entry jb + l
+    auto load_feat = [&](const int j) -> Feat {
+      Feat f;
+      if (OBJ) {
+        const uint32_t og = __builtin_amdgcn_readlane(rvec, j);
+        const float* row = og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ : a.sh_objs + (size_t)og * NUM_OBJ;
+        // (the feature table is read-only for the whole launch: read through the constant address space, a uniform address
+        // there is a scalar load; left in the global address space the compiler issues vector loads into 16 VGPRs)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef const f4v __attribute__((address_space(4))) * const_f4p;
+        const const_f4p src = (const_f4p)(uintptr_t)row;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f4v v = src[q]; f.q[q] = make_float4(v.x, v.y, v.z, v.w); }
+      } else {
+        f.q[0] = f.q[1] = f.q[2] = f.q[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return f;
+    };
+    auto composite = [&](const float4& e0, const float4& e1, const float2& e2, const Feat& fe, const int jc) {
       const uint32_t pos = base - rg.x + (uint32_t)(jb + jc) + 1;
       {
       const float dx = e0.x - pxf;
@@ -863,13 +810,8 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
           const float w = contrib ? alpha * T[k] : 0.f;
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
           if (OBJ) {
-            // the entry's 16 object features as four 16-byte LDS reads (left to itself the compiler pairs them for packed
-            // FMAs at odd offsets: one 12-byte read, six 2 x 4-byte reads and two singles per strip, K6 0.30 -> 0.36 ms)
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            const f4v* sp4 = reinterpret_cast<const f4v*>(&so[jb + jc][0]);
-            f4v q0 = sp4[0], q1 = sp4[1], q2 = sp4[2], q3 = sp4[3];
-            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));     // the four words stay four 128-bit registers
-            const float f[NUM_OBJ] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const float f[NUM_OBJ] = {fe.q[0].x, fe.q[0].y, fe.q[0].z, fe.q[0].w, fe.q[1].x, fe.q[1].y, fe.q[1].z, fe.q[1].w,
+                                      fe.q[2].x, fe.q[2].y, fe.q[2].z, fe.q[2].w, fe.q[3].x, fe.q[3].y, fe.q[3].z, fe.q[3].w};
 #pragma unroll
             for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(f[c], w, O[k][c]);
           }
@@ -892,6 +834,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
     int j = __builtin_ctzll(todo);
     float4 a0 = s0[jb + j], a1 = s1[jb + j];
     float2 a2 = make_float2(s2[jb + j].x, s2[jb + j].y);
+    Feat fa = load_feat(j);
     // (the entry behind the one on which the wave's last pixel finished has been fetched already: it is skipped on its
     // empty strip mask, and the cleared `todo` ends the walk behind it)
     while (true) {
@@ -900,13 +843,15 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? 5 : 
       j = jraw & 63;                          // prefetch the next entry while this one is composited
       const float4 b0 = s0[jb + j], b1 = s1[jb + j];
       const float2 b2 = make_float2(s2[jb + j].x, s2[jb + j].y);
-      composite(a0, a1, a2, jc);
+      const Feat fb = load_feat(j);
+      composite(a0, a1, a2, fa, jc);
       if (jraw < 0) break;
       jc = j;
       asm volatile("s_bitset0_b64 %0, %2\n\ts_ff1_i32_b64 %1, %0" : "+s"(todo), "=s"(jraw) : "s"(jc));
       j = jraw & 63;
       a0 = s0[jb + j]; a1 = s1[jb + j]; a2 = make_float2(s2[jb + j].x, s2[jb + j].y);
-      composite(b0, b1, b2, jc);
+      fa = load_feat(j);
+      composite(b0, b1, b2, fb, jc);
       if (jraw < 0) break;
     }
     }
@@ -997,8 +942,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // contributing entry the wave sums them TRANSPOSED: lane L adds the 8 floats of chunk L with plain v_add (2
 // ds_read_b128), three DPP adds join the eight chunks of a value, and the lanes store their row words directly.
 // ------------------------------------------------------------------------------------------------
-constexpr int RED_ROW = 12;       // an 8-float chunk padded to 3 float4: ds_read_b128 at an odd float4 stride is conflict free
-constexpr int RED_REG = 8 * RED_ROW;      // one parked register: eight 8-lane chunks
+// Layout of one parked register (round 5): 64 floats = 256 bytes, so that the eight registers of an entry sit at
+// ds_write2st64 offsets 0..7 of ONE address register (the 96-float pitch of rounds 2-4 needed three more, formed per
+// entry).  Chunk c (8 floats) lies at position pos(c) = 4 (c & 1) + (c >> 1): the even chunks -- written by lanes 0..31,
+// element e of chunk 2q by lane 8q + e -- fill floats 0..31 and the odd ones -- lanes 32..63 -- floats 32..63, each half-wave
+// pass of a ds_write_b32 touching every bank exactly once; the odd chunks store their two 16-byte halves swapped (element
+// e at e ^ 4), and the transposed sum reads them in that order: the eight lanes of a ds_read_b128 pass then cover the 32
+// banks exactly once as well (positions p and p + 4 start 128 bytes apart: without the swap they would share banks).
+constexpr int RED_REG = 64;
 struct RenderBwdArgs {
   const uint2* ranges;
   const uint32_t* pair_rank;
@@ -1096,7 +1047,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   // Where this lane parks its partials: a register is eight 8-float chunks at a stride of 12 floats (bank starts
   // 0,12,24,4,16,28,8,20): the even chunks cover the 32 banks exactly once and so do the odd ones, so lanes 0..31 fill
   // the even chunks and lanes 32..63 the odd ones -- each half-wave pass of a ds_write_b32 is conflict free.
-  const int red_wofs = (2 * ((lane & 31) >> 3) + (lane >> 5)) * RED_ROW + (lane & 7);
+  const int red_wofs = ((lane >> 5) * 4 + ((lane & 31) >> 3)) * 8 + ((lane & 7) ^ ((lane >> 5) << 2));
   // transposed-sum roles: lane = (entry e, register rr, chunk ch of 8 floats).  The joins leave in chunks >= 4 first
   // the total of the chunks of the same parity, then the total of all eight.  Row word this lane stores: chunk 4 of
   // register rr stores value rr (the colour sums keep their words 6..8 without the geometry sums); the folded last
@@ -1299,9 +1250,15 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int jm = RB > 1 ? __builtin_amdgcn_ds_bpermute(red_e << 2, red_j) : j;
         if (red_e < red_n) {
-          const float4* ch = reinterpret_cast<const float4*>(&sred[RED_ROW * lane]);
-          const float4 q0 = ch[0], q1 = ch[1];
-          float t = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+          // chunk red_ch of register red_rr of parked entry red_e; the odd chunks' halves are stored swapped
+          const float* chp = &sred[red_e * RENTRY + red_rr * RED_REG + ((red_ch & 1) * 4 + (red_ch >> 1)) * 8];
+          const float4 q0 = *reinterpret_cast<const float4*>(chp + ((red_ch & 1) << 2));
+          const float4 q1 = *reinterpret_cast<const float4*>(chp + (((red_ch & 1) ^ 1) << 2));
+          // three packed adds + one (v_pk_add_f32) instead of seven scalar ones
+          typedef float f2v __attribute__((ext_vector_type(2)));
+          const f2v h0 = f2v{q0.x, q0.y} + f2v{q0.z, q0.w}, h1 = f2v{q1.x, q1.y} + f2v{q1.z, q1.w};
+          const f2v hs = h0 + h1;
+          float t = hs.x + hs.y;
           t += dpp_mov<0x4E, 0xF>(t);                    // quad_perm [2,3,0,1]: chunks c, c ^ 2
           t += dpp_mov<0x114, 0xF>(t);                   // row_shr:4: chunks >= 4 now hold their parity's total
           const float t4 = t + dpp_mov<0xB1, 0xF>(t);    // quad_perm [1,0,3,2]: both parities, an unfolded register's value
@@ -1371,7 +1328,26 @@ struct PreBwdArgs {
   float* dcov3d;
   int accumulate;         // != 0 (k_pre_bwd only): the 59 attribute gradients are ADDED to (Gaussians without pairs are
                           // left alone); dmeans2D and dsh_objs, which belong to one view, are overwritten regardless
+  float* sumsq;           // k_pre_bwd<RAW = true, ., ACC = false> only, or null: [workgroups][SUMSQ_W] per-workgroup sums of
+                          // squares of the gradients this launch writes, per attribute tensor (SUMSQ_* below)
 };
+// Slots of PreBwdArgs::sumsq / gsr_ctx_request_sumsq: the six tensors the reference's L2 steps normalise over (attack.py:
+// 53-119, 138-173: a global norm per tensor, _features_dc and _features_rest separately).
+enum { SUMSQ_XYZ = 0, SUMSQ_DC = 1, SUMSQ_REST = 2, SUMSQ_OPACITY = 3, SUMSQ_SCALING = 4, SUMSQ_ROTATION = 5, SUMSQ_W = 8 };
+
+// The gradient's sum of squares per tensor from the per-workgroup partials k_pre_bwd leaves (fixed summation order:
+// reproducible): block k sums slot k over all workgroups in double.
+__global__ void __launch_bounds__(256) k_sumsq_reduce(const float* __restrict__ part, int nblocks, double* __restrict__ out) {
+  __shared__ double wsum[4];
+  const int k = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += (double)part[(size_t)i * SUMSQ_W + k];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[k] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
 
 // Generic form (any K): one thread per Gaussian walks its own partial rows and its own SH row.
 // GEOM = false: the rows carry the three colour sums only (K7 without the geometry sums) and only the SH / colour /
@@ -1814,6 +1790,20 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   }
   // ---- phase A: chain rule per Gaussian ------------------------------------------------------------------------------
   float hdir[3] = {0.f, 0.f, 0.f}, hrgb[3] = {0.f, 0.f, 0.f};
+  // squares of what this lane writes, per attribute tensor (PreBwdArgs::sumsq): the L2 step's global norms come out of
+  // the kernel that produces the gradients instead of a second pass over them (a Gaussian without pairs writes zeros)
+  float ssq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_ss = RAW && !ACC && a.sumsq != nullptr;
+  auto flush_sumsq = [&]() {
+    if (!want_ss) return;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ssq[k] = wave_sum_to_hi(ssq[k]);
+    if (lane == 63) {
+      float* dst = a.sumsq + (size_t)(blockIdx.x * PRE_WAVES + wave) * SUMSQ_W;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = ssq[k];
+    }
+  };
   if (g < a.P) {
     if (o1 == o0 && acc) {
       // nothing to add to the caller's bucket for a Gaussian without pairs; the two per-VIEW outputs (screen-space
@@ -1856,7 +1846,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
       const float dndcy = (float)(-((double)B * mx + (double)C * my) * (0.5 * (double)v.H));
       const double dA = -0.5 * mxx, dB = -mxy, dC = -0.5 * myy;
       if (GEOM && a.dmeans2D) { a.dmeans2D[3 * g] = dndcx; a.dmeans2D[3 * g + 1] = dndcy; a.dmeans2D[3 * g + 2] = 0.f; }   // per view
-      if (GEOM && a.dopac) put(&a.dopac[g], RAW ? dop * e1.y * (1.f - e1.y) : dop);   // e1.y = sigmoid(raw opacity)
+      if (GEOM && a.dopac) {
+        const float dov = RAW ? dop * e1.y * (1.f - e1.y) : dop;                       // e1.y = sigmoid(raw opacity)
+        put(&a.dopac[g], dov);
+        ssq[SUMSQ_OPACITY] = dov * dov;
+      }
       float dp[3] = {0.f, 0.f, 0.f};
       if (a.dcolors) { put(&a.dcolors[3 * g], dr); put(&a.dcolors[3 * g + 1], dg); put(&a.dcolors[3 * g + 2], db); }
       if (a.sh) {
@@ -1896,7 +1890,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         }
         float dc6[6];
         project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
-        if (a.dmeans3D) { put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]); }
+        if (a.dmeans3D) {
+          put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]);
+          ssq[SUMSQ_XYZ] = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+        }
         if (a.cov3d) {
           if (a.dcov3d) for (int i = 0; i < 6; ++i) put(&a.dcov3d[6 * g + i], dc6[i]);
         } else if (a.dscales || a.drots) {
@@ -1906,13 +1903,19 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
             ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2];     // d exp(x) = exp(x)
             act_normalize4_bwd(q, inv_qn, dq, dq);
           }
-          if (a.dscales) { put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]); }
-          if (a.drots) { put(&a.drots[4 * g], dq[0]); put(&a.drots[4 * g + 1], dq[1]); put(&a.drots[4 * g + 2], dq[2]); put(&a.drots[4 * g + 3], dq[3]); }
+          if (a.dscales) {
+            put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]);
+            ssq[SUMSQ_SCALING] = ds[0] * ds[0] + ds[1] * ds[1] + ds[2] * ds[2];
+          }
+          if (a.drots) {
+            put(&a.drots[4 * g], dq[0]); put(&a.drots[4 * g + 1], dq[1]); put(&a.drots[4 * g + 2], dq[2]); put(&a.drots[4 * g + 3], dq[3]);
+            ssq[SUMSQ_ROTATION] = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3];
+          }
         }
       }
     }
   }
-  if (a.dsh == nullptr) return;
+  if (a.dsh == nullptr) { flush_sumsq(); return; }
   // ---- phase B: four lanes per Gaussian write dL/dSH = basis(dir) x dL/drgb, 48 floats per Gaussian, coalesced -------
   {
     float* h = hand + HAND_W * lane;
@@ -1950,9 +1953,19 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         }
       } else {
         store_sh12<RAW>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), q, out);
+        if (want_ss) {
+          // lane q = 0 holds coefficient 0 (= _features_dc) in out[0..2]; everything else is _features_rest
+          const float head = out[0] * out[0] + out[1] * out[1] + out[2] * out[2];
+          float rest = 0.f;
+#pragma unroll
+          for (int j = 3; j < 12; ++j) rest = fmaf(out[j], out[j], rest);
+          ssq[SUMSQ_DC] += q == 0 ? head : 0.f;
+          ssq[SUMSQ_REST] += q == 0 ? rest : rest + head;
+        }
       }
     }
   }
+  flush_sumsq();
 }
 
 }  // namespace gsr

@@ -220,6 +220,24 @@ def fan_out(n: int) -> int:
     return rc
 
 
+def masked_streams(dev, spec: str):
+    """HIP streams restricted to sets of compute units (hipExtStreamCreateWithCUMask), wrapped for torch."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    with torch.cuda.device(dev):
+        torch.cuda.current_stream(dev).synchronize()       # the runtime is initialised
+        for m in spec.split(";"):
+            words = [int(w, 16) for w in m.split(",") if w.strip()]
+            arr = (ctypes.c_uint32 * len(words))(*words)
+            h = ctypes.c_void_p(None)
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(words)), arr)
+            if rc != 0 or not h.value:
+                raise SystemExit(f"hipExtStreamCreateWithCUMask failed ({rc}) for mask {m}")
+            out.append(torch.cuda.ExternalStream(h.value, device=dev))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +272,9 @@ def main():
     ap.add_argument("--dense-pairs", type=float, default=10e6,
                     help="target pair count of the second, denser data point (scale_modifier is searched for it); 0 = skip")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
+    ap.add_argument("--cu-masks", default=None,
+                    help="experiment: one CU mask per view stream, ';'-separated, each a ','-separated list of 32-bit hex "
+                         "words (hipExtStreamCreateWithCUMask); replaces --streams")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -323,6 +344,10 @@ def main():
         return out
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+    if args.cu_masks:
+        # experiment: the view streams as hipExtStreamCreateWithCUMask streams, one mask per stream
+        streams = masked_streams(dev, args.cu_masks)
+        args.streams = len(streams)
 
     def run_steps(n, use_streams=True):
         sts = streams if use_streams else None
