@@ -482,6 +482,7 @@ struct GsrCtx {
   } b;
   bool objects_out = false;       // the forward composited the 16 object channels
   bool D_stale = false;           // the last re-render skipped d colour / d direction: no geometry backward until the next
+  double* sumsq_out = nullptr;    // gsr_ctx_request_sumsq: where the next overwrite-mode raw backward leaves its six sums of squares
 };
 
 // Host copy of the forward's device-side scalars: waits for the (early) copy if it has not landed yet.
@@ -1179,6 +1180,20 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     // collective over that range can be issued while the next range is still being computed.
     nchunks = std::max(1, std::min(nchunks, (P + 63) / 64));
     const int per = (((P + nchunks - 1) / nchunks) + 63) / 64 * 64;
+    // gsr_ctx_request_sumsq (one-shot): the overwriting raw-parameter kernel also leaves per-workgroup sums of squares of
+    // what it writes; one small launch behind it adds them up per tensor (fixed order) into the caller's six doubles
+    double* ss_out = c->sumsq_out;
+    c->sumsq_out = nullptr;
+    void* ss_blk = nullptr;
+    const int ss_blocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    pa.sumsq = nullptr;
+    if (ss_out) {
+      if (!(c->lanegroup && c->raw) || accumulate || nchunks != 1)
+        return done(set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: served by an overwriting gsr_backward_raw* over one range only"));
+      ss_blk = pool_alloc(dev, sizeof(float) * SUMSQ_W * (size_t)ss_blocks * PRE_WAVES, st);
+      if (!ss_blk) return done(set_err(GSR_ERR_NOMEM, "gsr_backward_raw: sum-of-squares partials allocation failed"));
+      pa.sumsq = static_cast<float*>(ss_blk);
+    }
     for (int ck = 0; ck < nchunks; ++ck) {
       const int gb = std::min(ck * per, P), ge = (ck == nchunks - 1) ? P : std::min((ck + 1) * per, P);
       if (ge > gb) {
@@ -1201,6 +1216,10 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
         }
       }
       if (chunk_done) chunk_done(chunk_user, ck, (int64_t)gb, (int64_t)ge);
+    }
+    if (ss_out) {
+      hipLaunchKernelGGL(k_sumsq_reduce, dim3(6), dim3(256), 0, st, pa.sumsq, ss_blocks * PRE_WAVES, ss_out);
+      pool_free(dev, ss_blk);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "preprocess backward: launch failed: %s", hipGetErrorString(e)));
@@ -1328,6 +1347,27 @@ void gsr_trim_pool(void) {
     else { (void)hipFree(b.p); pl.total -= b.bytes; }
   }
   pl.blocks.swap(keep);
+}
+
+int gsr_ctx_request_sumsq(GsrCtx* c, double* out6) {
+  if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_request_sumsq: null context");
+  if (!c->raw || !c->lanegroup)
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: only contexts of gsr_forward_raw (raw parameters) produce the sums");
+  c->sumsq_out = out6;
+  return GSR_OK;
+}
+
+int gsr_pgd_step_normed(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,
+                        const double* sumsq, void* stream) {
+  if (rows < 0 || cols < 1 || cols > PGD_MAX_COLS)
+    return set_err(GSR_ERR_INVALID, "gsr_pgd_step_normed: rows=%lld cols=%d (1..%d columns)", (long long)rows, cols, PGD_MAX_COLS);
+  if (rows == 0) return GSR_OK;
+  if (!x || !grad || !x0 || !sumsq) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_normed: null argument");
+  hipLaunchKernelGGL((k_pgd_step<true>), dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), x, grad,
+                     x0, (size_t)rows, cols, alpha, epsilon, sumsq, 1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_pgd_step_normed: launch failed: %s", hipGetErrorString(e));
+  return GSR_OK;
 }
 
 int gsr_pgd_step(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,

@@ -651,6 +651,13 @@ constexpr float PX_OFF = 1.0e30f;   // y coordinate of a finished / out-of-image
 #ifndef GSR_K6_OBJ_WAVES
 #define GSR_K6_OBJ_WAVES 5          // waves per SIMD the two-strip object variant is compiled for
 #endif
+#ifndef GSR_K6_OBJ_STAGE_ALL
+#define GSR_K6_OBJ_STAGE_ALL 0      // 1: stage the object features of every list entry (rounds 1-4); 0: only of the entries
+#endif                              // that reach this wave's strips
+#ifndef GSR_K6_OBJ_SCALAR
+#define GSR_K6_OBJ_SCALAR 0         // 0: object features staged through LDS; 1: fetched by scalar loads into SGPRs (measured
+                                    // slower on S-nyc-1M: K6 0.353 ms against 0.304 -- EXPERIMENTS.md, round 5)
+#endif
 template <bool OBJ, int NPX, int WPB = 1>
 __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_K6_OBJ_WAVES : 1) k_render_fwd(RenderArgs a) {
   constexpr int NSUB = PXL / NPX;
@@ -660,6 +667,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
   __shared__ float4 s1[BATCH];
   __shared__ float4 s2[BATCH];                             // (blue, threshold | mask, Gaussian index, -): 16-byte pitch like s0 /
                                                            // s1, so that the three reads of an entry share ONE address register
+  __shared__ __attribute__((aligned(16))) float so[(OBJ && !GSR_K6_OBJ_SCALAR) ? BATCH : 1][NUM_OBJ];
   __shared__ uint32_t salive[WPB];
   const int lane = threadIdx.x & 63;
   const int wv = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // wave-uniform, and known to be
@@ -715,6 +723,12 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
       const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
       rown = r;                                           // the pair's value IS the Gaussian's storage index
       s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = make_float4(sp.c.x, sp.c.y, __uint_as_float(r), 0.f);
+      if (OBJ && !GSR_K6_OBJ_SCALAR && (GSR_K6_OBJ_STAGE_ALL || mine != 0u)) {   // (an entry no strip of this wave reaches is never read)
+        const float4* src = reinterpret_cast<const float4*>(r >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(r - (uint32_t)a.Pa) * NUM_OBJ
+                                                                                 : a.sh_objs + (size_t)r * NUM_OBJ);
+        float4* dst = reinterpret_cast<float4*>(&so[slot][0]);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+      }
     } else if (WPB > 1) {
       s2[slot] = make_float4(0.f, 0.f, 0.f, 0.f);         // past the end of the list: reaches no strip
     }
@@ -760,7 +774,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
     const uint32_t rvec = OBJ ? (WPB > 1 ? __float_as_uint(s2[jb + lane].z) : rown) : 0u;   // lane l: Gaussian of entry jb + l
     auto load_feat = [&](const int j) -> Feat {
       Feat f;
-      if (OBJ) {
+      if (OBJ && GSR_K6_OBJ_SCALAR) {
         const uint32_t og = __builtin_amdgcn_readlane(rvec, j);
         const float* row = og >= (uint32_t)a.Pa ? a.sh_objs_b + (size_t)(og - (uint32_t)a.Pa) * NUM_OBJ : a.sh_objs + (size_t)og * NUM_OBJ;
         // (the feature table is read-only for the whole launch: read through the constant address space, a uniform address
@@ -809,9 +823,19 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
           }
           const float w = contrib ? alpha * T[k] : 0.f;
           C[k][0] = fmaf(e1.z, w, C[k][0]); C[k][1] = fmaf(e1.w, w, C[k][1]); C[k][2] = fmaf(e2.x, w, C[k][2]);
-          if (OBJ) {
+          if (OBJ && GSR_K6_OBJ_SCALAR) {
             const float f[NUM_OBJ] = {fe.q[0].x, fe.q[0].y, fe.q[0].z, fe.q[0].w, fe.q[1].x, fe.q[1].y, fe.q[1].z, fe.q[1].w,
                                       fe.q[2].x, fe.q[2].y, fe.q[2].z, fe.q[2].w, fe.q[3].x, fe.q[3].y, fe.q[3].z, fe.q[3].w};
+#pragma unroll
+            for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(f[c], w, O[k][c]);
+          } else if (OBJ) {
+            // the entry's 16 object features as four 16-byte LDS reads, right in front of their use (left to itself the
+            // compiler pairs them for packed FMAs at odd offsets: one 12-byte read, six 2 x 4-byte reads and two singles)
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v* sp4 = reinterpret_cast<const f4v*>(&so[jb + jc][0]);
+            f4v q0 = sp4[0], q1 = sp4[1], q2 = sp4[2], q3 = sp4[3];
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));     // the four words stay four 128-bit registers
+            const float f[NUM_OBJ] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
             for (int c = 0; c < NUM_OBJ; ++c) O[k][c] = fmaf(f[c], w, O[k][c]);
           }

@@ -146,6 +146,11 @@ def _load():
     lib.gsr_profile.argtypes = [i32]
     lib.gsr_profile_read.restype = ctypes.c_int
     lib.gsr_profile_read.argtypes = [ctypes.POINTER(ctypes.c_float), i64p]
+    if hasattr(lib, "gsr_ctx_request_sumsq"):              # (absent from older builds selected through GSR_LIBRARY for A/B runs)
+        lib.gsr_ctx_request_sumsq.restype = ctypes.c_int
+        lib.gsr_ctx_request_sumsq.argtypes = [vp, vp]
+        lib.gsr_pgd_step_normed.restype = ctypes.c_int
+        lib.gsr_pgd_step_normed.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float, vp, vp]
     lib.gsr_pgd_step.restype = ctypes.c_int
     lib.gsr_pgd_step.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_int32, vp]
@@ -523,6 +528,34 @@ def _entry_leave(entry: _CacheEntry, device):
     entry.stream = cur.cuda_stream
 
 
+class GradNorms:
+    """The six sums of squares the reference's L2 steps divide by (attack.py:53-119, 138-173: one global norm per raw
+    attribute tensor, _features_dc and _features_rest separately), taken from the raster backward that WRITES the
+    gradients instead of from a second pass over 236 MB of them (gsr_ctx_request_sumsq).  A rasterise call that is given
+    one arms its backward when that backward overwrites its outputs; `sumsq_of(name)` hands the step the device scalar
+    only while exactly ONE backward has contributed since begin() -- a second view's gradients added on top (autograd
+    accumulation, a GradBucket in add mode, a folded or all-reduced bucket) make the sums stale, and the caller falls
+    back to summing the gradient itself."""
+    NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+    def __init__(self, device):
+        self.sumsq = torch.zeros(6, dtype=torch.float64, device=device)
+        self.writes = 0            # backwards that contributed since begin()
+        self.names = ()            # tensors whose sums the one arming backward wrote
+
+    def begin(self):
+        self.writes, self.names = 0, ()
+
+    def invalidate(self):
+        self.writes = 2
+
+    def sumsq_of(self, name: str):
+        if self.writes != 1 or name not in self.names:
+            return None
+        i = self.NAMES.index(name)
+        return self.sumsq[i:i + 1]
+
+
 class GradBucket:
     """Caller-owned gradient bucket of a reference-style GaussianModel: ONE flat float32 buffer of 59 floats per Gaussian
     in the order xyz | f_dc | f_rest | opacity | scaling | rotation (the layout of the flat buffer the fused backward
@@ -590,9 +623,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation, raster_settings,
-                keep=True, bucket=None, cache_slot=None, color_only=False):
+                keep=True, bucket=None, cache_slot=None, color_only=False, norms=None):
         lib = _load()
         ctx.bucket = bucket
+        ctx.norms = norms
         ctx.entry = None
         if not xyz.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
@@ -734,6 +768,16 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             d_ro = out(need[7], P, 4)
         d_m2 = out(need[1], P, 3)
         d_obj = out(need[4] and obj is not None, P, NUM_OBJECTS)
+        norms = getattr(ctx, "norms", None)
+        if norms is not None:
+            norms.writes += 1
+            overwrites = (bucket is None or bucket.fresh) and not (bucket is not None and bucket.chunks > 1)
+            if norms.writes == 1 and overwrites and P > 0:
+                if lib.gsr_ctx_request_sumsq(ctx.holder.handle, ctypes.c_void_p(norms.sumsq.data_ptr())) != 0:
+                    raise RuntimeError(_err(lib))
+                norms.names = tuple(n for n, w in zip(GradNorms.NAMES, (need[0], want_sh, want_sh, need[5], need[6], need[7])) if w)
+            elif not overwrites:
+                norms.invalidate()
         if P > 0:
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -770,13 +814,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             bucket.fresh, bucket.used = False, True
             s = ctx.shapes
             return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None,
-                    None if d_obj is None else d_obj.reshape(s[4]), None, None, None, None, None, None, None, None)
+                    None if d_obj is None else d_obj.reshape(s[4]), None, None, None, None, None, None, None, None, None)
         s = ctx.shapes
 
         def shaped(t, shape, wanted=True):
             return None if (t is None or not wanted) else t.reshape(shape)
         return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
-                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None, None, None, None)
+                shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None, None, None, None, None)
 
 
 def _wants_backward(*tensors) -> bool:
@@ -787,7 +831,7 @@ def _wants_backward(*tensors) -> bool:
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
                             raster_settings, grad_bucket: Optional["GradBucket"] = None, cache: Optional["RenderCache"] = None,
-                            cache_key=None):
+                            cache_key=None, grad_norms: Optional["GradNorms"] = None):
     """(color[3,H,W], radii[P], objects[16,H,W]) from the RAW parameters of a reference-style GaussianModel
     (_xyz, _features_dc, _features_rest, _objects_dc or None, _opacity, _scaling, _rotation): equal to the
     getters (scene/gaussian_model.py:97-124) followed by GaussianRasterizer.forward, in one fused pass."""
@@ -798,7 +842,7 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, objects_dc
     color_only = not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
                                                        for t in (xyz, means2D, opacity, scaling, rotation)))
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, objects_dc, opacity, scaling, rotation,
-                                        raster_settings, keep, grad_bucket, slot, color_only)
+                                        raster_settings, keep, grad_bucket, slot, color_only, grad_norms)
 
 
 @torch.no_grad()
@@ -1002,6 +1046,6 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "rasterize_gaussians_raw2", "PairCapacityExceeded", "GradBucket",
+           "rasterize_gaussians_raw2", "PairCapacityExceeded", "GradBucket", "GradNorms",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

@@ -56,7 +56,18 @@ class SurrogateDetector(nn.Module):
         return self.net(renders.clamp(0.0, 1.0))[:, 0].mean()
 
 
-def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsilon: float) -> None:
+def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsilon: float, norms=None) -> None:
+    """norms: a diff_gaussian_rasterization.GradNorms whose sums of squares -- when still valid for this iteration's
+    gradients -- spare the L2 rules their own pass over the gradient (same rule, attack.py:53-119, 138-173)."""
+    if norm == "l2" and norms is not None:
+        attrs = {"color": ("_features_rest", "_features_dc"), "position": ("_xyz",), "scaling": ("_scaling",),
+                 "rotation": ("_rotation",), "opacity": ("_opacity",)}
+        todo = [a for g in groups for a in attrs[g]]
+        if all(norms.sumsq_of(a) is not None and getattr(model, a).grad is not None for a in todo):
+            for a in todo:
+                t = getattr(model, a)
+                pgd.l2_step_(t, t.grad, alpha, epsilon, originals[a], sumsq=norms.sumsq_of(a))
+            return
     fn = {("color", "l2"): lambda: pgd.gaussian_color_l2_attack(model, alpha, epsilon, originals["_features_rest"],
                                                                   originals["_features_dc"]),
           ("color", "linf"): lambda: pgd.gaussian_color_linf_attack(model, alpha, epsilon, originals["_features_rest"],
@@ -153,7 +164,7 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
                originals: Optional[dict] = None, use_buckets: bool = True,
                timer: Optional["PhaseTimer"] = None, overlap_success: bool = True,
-               cache_binning: bool = True) -> List[float]:
+               cache_binning: bool = True, fused_norms: bool = True) -> List[float]:
     """Runs up to `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
     initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
     pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order.
@@ -190,7 +201,12 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         sorts, tile lists, schedule -- is kept in HBM after its first render (RenderCache, ~250 MB per camera
                         at 1 M Gaussians) and later renders of it, the attack's and the success check's, run the colour
                         kernel and the compositor only.  Losses, flags and the saved model are bit for bit those of the
-                        uncached loop (tests/test_gpu_rerender.py)."""
+                        uncached loop (tests/test_gpu_rerender.py).
+      fused_norms       (default on; L2 steps on one GPU, one view per iteration) the step's global gradient norms are the
+                        sums of squares the raster backward leaves next to the gradients it writes (GradNorms /
+                        gsr_ctx_request_sumsq): one launch per tensor and one read of the gradient instead of two.  With
+                        more than one view per iteration, several ranks or accumulate_grads the sums do not describe the
+                        gradient the step uses and the step sums it itself, as before."""
     groups = tuple(groups)
     assert all(g in GROUPS for g in groups) and norm in ("l2", "linf") and loss_reduction in ("sum", "mean")
     dev = model.get_xyz.device
@@ -239,6 +255,15 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             buckets = [GradBucket(P, dev) for _ in range(ring.n if ring is not None else 1)]
             pipe = copy.copy(pipe)
             pipe.grad_bucket = (lambda: buckets[ring.current]) if ring is not None else buckets[0]
+        # L2 steps: the global norms come out of the raster backward (GradNorms) while one backward per iteration writes the
+        # gradients the step uses -- one view per iteration on one GPU without the running-sum quirk (BASELINE config 3)
+        norms = None
+        if (fused_norms and norm == "l2" and dev.type == "cuda" and world == 1 and not accumulate_grads and takes_fused_path(model, pipe)
+                and getattr(pipe, "grad_norms", None) is None):
+            from diff_gaussian_rasterization import GradNorms
+            norms = GradNorms(dev)
+            pipe = copy.copy(pipe)
+            pipe.grad_norms = norms
         run_flat = None                                    # accumulate_grads with buckets: the running sum
         overlap = (overlap_success and success_fn is not None and dev.type == "cuda" and not batch_loss and timer is None)
         check_stream = _check_stream(dev) if overlap else None
@@ -281,6 +306,8 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                 if stopped:
                     break
             def clear_gradients():
+                if norms is not None:
+                    norms.begin()
                 if buckets is not None:
                     for b in buckets:
                         b.reset()
@@ -368,7 +395,7 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         p.grad = running[n]
             if timer is not None:
                 timer.lap("reduce")
-            _step(model, originals, groups, norm, alpha, epsilon)
+            _step(model, originals, groups, norm, alpha, epsilon, norms)
             if timer is not None:
                 timer.lap("step")
             history.append(float(total))

@@ -18,7 +18,7 @@ import torch
 _WARNED = set()
 
 
-def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Tensor, l2: bool) -> bool:
+def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Tensor, l2: bool, sumsq=None) -> bool:
     """Device tensors the fused HIP update can take -- contiguous float32 [rows, <= 48 columns], which is every tensor
     the reference attacks -- take it (libgsraster.so: gsr_pgd_step, two launches per tensor) and True is returned.
     False = the caller runs the tensor formulation below: host tensors (the CPU statement the golden fixtures pin),
@@ -52,9 +52,17 @@ def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Ten
     lib = D._load()
     with torch.cuda.device(x.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.gsr_pgd_step(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(grad.data_ptr()), ctypes.c_void_p(x0.data_ptr()),
-                              ctypes.c_int64(rows), ctypes.c_int32(cols), ctypes.c_float(alpha), ctypes.c_float(epsilon),
-                              ctypes.c_int32(1 if l2 else 0), stream)
+        if l2 and sumsq is not None:
+            # ||grad||^2 is already on the device (left by the raster backward that wrote `grad`: GradNorms): one launch,
+            # one read of the gradient
+            assert sumsq.dtype == torch.float64 and sumsq.is_cuda and sumsq.numel() == 1
+            rc = lib.gsr_pgd_step_normed(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(grad.data_ptr()),
+                                         ctypes.c_void_p(x0.data_ptr()), ctypes.c_int64(rows), ctypes.c_int32(cols),
+                                         ctypes.c_float(alpha), ctypes.c_float(epsilon), ctypes.c_void_p(sumsq.data_ptr()), stream)
+        else:
+            rc = lib.gsr_pgd_step(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(grad.data_ptr()), ctypes.c_void_p(x0.data_ptr()),
+                                  ctypes.c_int64(rows), ctypes.c_int32(cols), ctypes.c_float(alpha), ctypes.c_float(epsilon),
+                                  ctypes.c_int32(1 if l2 else 0), stream)
     if rc != 0:
         raise RuntimeError(lib.gsr_last_error().decode())
     # the kernel wrote through the raw pointer: tell autograd (a rasteriser forward that saved this tensor and has not
@@ -73,8 +81,10 @@ def linf_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float
         x.sub_(x0).clamp_(-epsilon, epsilon).add_(x0)
 
 
-def l2_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
-    if _hip_step(x.detach(), grad, alpha, epsilon, x0, True):
+def l2_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor, sumsq=None) -> None:
+    """sumsq (device tensors only): a one-element float64 device tensor holding ||grad||^2, when the caller already has
+    it (diff_gaussian_rasterization.GradNorms); None: the norm is summed here."""
+    if _hip_step(x.detach(), grad, alpha, epsilon, x0, True, sumsq=sumsq if grad is not None else None):
         return
     if grad is None:
         grad = torch.zeros_like(x)

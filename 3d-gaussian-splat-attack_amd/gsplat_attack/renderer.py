@@ -22,7 +22,7 @@ class PipelineParams:
 
     def __init__(self, convert_SHs_python: bool = False, compute_cov3D_python: bool = False, debug: bool = False,
                  skip_objects: bool = False, fused_activations: bool = True, viewspace_grad: bool = True,
-                 grad_bucket=None, render_cache=None):
+                 grad_bucket=None, render_cache=None, grad_norms=None):
         self.convert_SHs_python = convert_SHs_python
         self.compute_cov3D_python = compute_cov3D_python
         self.debug = debug
@@ -47,6 +47,9 @@ class PipelineParams:
         # iteration after the first of a colour attack is (reference attack.py:25-49).  Same bits either way.
         self.render_cache = render_cache
         self.cache_tag = "view"       # namespace of this pipe's keys in the cache (the success check renders under its own)
+        # extension (default None): a diff_gaussian_rasterization.GradNorms -- the fused path's backward leaves the sums of
+        # squares of the gradients it writes there, for the L2 step rules (no second pass over the gradient)
+        self.grad_norms = grad_norms
 
 
 def _has_raw_layout(pc) -> bool:
@@ -178,7 +181,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         image, radii, objects = rasterize_gaussians_raw(
             pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, None if no_objects else pc._objects_dc,
             pc._opacity, pc._scaling, pc._rotation, st, grad_bucket=bucket,
-            cache=getattr(pipe, "render_cache", None), cache_key=(getattr(pipe, "cache_tag", "view"), id(viewpoint_camera)))
+            cache=getattr(pipe, "render_cache", None), cache_key=(getattr(pipe, "cache_tag", "view"), id(viewpoint_camera)),
+            grad_norms=getattr(pipe, "grad_norms", None))
         return _result(image, screenspace_points, radii, objects)
 
     # classic surface: activated tensors through the keyword call of reference :86-95

@@ -272,6 +272,8 @@ def main():
     ap.add_argument("--dense-pairs", type=float, default=10e6,
                     help="target pair count of the second, denser data point (scale_modifier is searched for it); 0 = skip")
     ap.add_argument("--cpu-sample", default="100000,1920,1080")
+    ap.add_argument("--flags", type=lambda v: int(v, 0), default=0,
+                    help="extra GsrSettings.flags for every call (launch overrides: diff_gaussian_rasterization.flag_*)")
     ap.add_argument("--cu-masks", default=None,
                     help="experiment: one CU mask per view stream, ';'-separated, each a ','-separated list of 32-bit hex "
                          "words (hipExtStreamCreateWithCUMask); replaces --streams")
@@ -279,6 +281,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(fan_out(args.gpus))              # before anything touches a GPU in this (parent) process
+    if os.environ.get("BENCH_TEST_HANG_RANK") == os.environ.get("RANK", "-"):
+        # test hook (tests/test_dist_cpu.py): this rank behaves like one stuck in a collective -- it ignores SIGTERM
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(3600)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the raster path has no CPU fallback")
     from gsplat_attack import dist as gdist
@@ -303,8 +310,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     D._load()
-    if args.no_cull:
-        D.set_flags(D.FLAG_NO_CULL)
+    if args.no_cull or args.flags:
+        D.set_flags((D.FLAG_NO_CULL if args.no_cull else 0) | args.flags)
 
     n_views = max(8, world * max(args.views_per_rank, 1))
     if rank == 0:

@@ -250,6 +250,21 @@ int gsr_mark_visible(const GsrSettings* settings, int32_t P, const float* means3
 int gsr_pgd_step(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,
                  int32_t l2, void* stream);
 
+/*
+ * The L2 rules' global norm without a second pass over the gradient (round 5).  gsr_ctx_request_sumsq arms the NEXT
+ * overwrite-mode gsr_backward_raw / gsr_backward_raw_into (accumulate == 0, not chunked) of this context: besides the
+ * gradients it leaves, in out6 (DEVICE memory, 6 doubles, written in stream order), the sums of squares of the gradients
+ * it writes for xyz, features_dc, features_rest, opacity_logit, log_scaling, rotation_raw -- the quantities whose roots
+ * reference attack.py:61-62,70-71,...,145-146,154-155 divide by (a tensor whose gradient pointer is NULL gets 0).  The
+ * sums are those of THAT launch's output: a caller that adds other views' gradients to the buffers afterwards must not
+ * use them.  One-shot: the request is consumed by the backward it serves.
+ * gsr_pgd_step_normed is gsr_pgd_step's L2 rule with ||grad||^2 read from `sumsq` (device, one double) instead of being
+ * summed by a launch of its own: one launch per tensor, one read of the gradient.
+ */
+int gsr_ctx_request_sumsq(GsrCtx* ctx, double* out6);
+int gsr_pgd_step_normed(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,
+                        const double* sumsq, void* stream);
+
 /* Mean squared distance of every point to its 3 nearest other points (exact): replaces the reference's second native
  * import, simple_knn._C.distCUDA2 (reference scene/gaussian_model.py:17, called at :144 to seed the initial scales).
  * points [P,3] float32 device, mean_dist2 [P] float32 device.  Synchronises the stream once (scene set-up routine, not

@@ -246,8 +246,16 @@ def test_bench_fan_out_parent_reports_a_failing_rank():
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "needs a HIP device" in out.stderr and "stopping the other ranks" in out.stderr or out.stderr.count("needs a HIP device") == 2
-    # and without the rehearsal switch the parent itself refuses: fewer devices than ranks
+    # without the rehearsal switch: the parent asks the runtime nothing (even counting devices may initialise
+    # HIP before the fork); the ranks find out themselves and the parent hands their failure on
     env.pop("BENCH_REHEARSE_GLOO")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                          text=True, timeout=300)
-    assert out.returncode == 2 and "HIP device" in out.stderr
+    assert out.returncode != 0 and "HIP device" in out.stderr
+    # a rank that does not act on SIGTERM (stuck in a collective) is ended by its exact PID after a bounded grace period
+    import time
+    env.update(BENCH_REHEARSE_GLOO="1", BENCH_FANOUT_GRACE_S="2", BENCH_TEST_HANG_RANK="1")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode != 0 and "SIGKILL" in out.stderr and time.monotonic() - t0 < 60

@@ -1,0 +1,103 @@
+"""Round 5: the L2 step's global norms out of the raster backward (gsr_ctx_request_sumsq / GradNorms / gsr_pgd_step_normed),
+reference attack.py:53-119, 138-173."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def _scene(P=40000, W=320, H=192, n_views=2):
+    from gsplat_attack.scenes import make_scene
+    dev = torch.device("cuda:0")
+    model, cams, _ = make_scene("nyc-1M", device=dev, P=P, width=W, height=H, n_views=n_views)
+    return dev, model, cams
+
+
+@pytest.mark.parametrize("color_only", [False, True])
+@pytest.mark.parametrize("bucket", [False, True])
+def test_backward_leaves_the_sums_of_squares_of_the_gradients_it_writes(color_only, bucket):
+    from diff_gaussian_rasterization import GradBucket, GradNorms
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams = _scene()
+    if color_only and bucket:
+        pytest.skip("a bucket takes all 59 floats")
+    if color_only:
+        for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+            getattr(model, n).requires_grad_(False)
+    P = model.get_xyz.shape[0]
+    norms = GradNorms(dev)
+    b = GradBucket(P, dev) if bucket else None
+    pipe = PipelineParams(skip_objects=True, viewspace_grad=not color_only, grad_norms=norms, grad_bucket=b)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    gc = torch.randn(3, 192, 320, generator=torch.Generator().manual_seed(3)).to(dev)
+    norms.begin()
+    model.zero_grad()
+    render(cams[0], model, pipe, bg)["render"].backward(gc)
+    if b is not None:
+        b.assign_to(model)
+    torch.cuda.synchronize()
+    want = ("_features_dc", "_features_rest") if color_only else NAMES
+    assert norms.writes == 1 and set(norms.names) == set(want)
+    for n in want:
+        g = getattr(model, n).grad
+        ref = float((g.double() ** 2).sum())
+        got = float(norms.sumsq_of(n))
+        assert ref > 0 and abs(got - ref) <= 2e-6 * ref, (n, got, ref)
+    for n in set(NAMES) - set(want):
+        assert norms.sumsq_of(n) is None
+    # a second view's gradients on top: the sums no longer describe what .grad holds
+    render(cams[1], model, pipe, bg)["render"].backward(gc)
+    assert norms.writes == 2 and norms.sumsq_of("_features_dc") is None
+    # a new iteration: valid again, and equal to the new gradient's
+    norms.begin()
+    if b is not None:
+        b.reset()
+    model.zero_grad()
+    render(cams[1], model, pipe, bg)["render"].backward(gc)
+    if b is not None:
+        b.assign_to(model)
+    g = model._features_rest.grad
+    ref = float((g.double() ** 2).sum())
+    assert abs(float(norms.sumsq_of("_features_rest")) - ref) <= 2e-6 * ref
+
+
+def test_normed_step_equals_the_step_that_sums_the_gradient_itself():
+    from gsplat_attack import pgd
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    for rows, cols in ((50000, 45), (50000, 3), (777, 4), (4097, 1)):
+        x0 = torch.randn(rows, cols, generator=g).to(dev)
+        x = (x0 + 0.3 * torch.randn(rows, cols, generator=g).to(dev)).contiguous()
+        grad = torch.randn(rows, cols, generator=g).to(dev)
+        grad[::3] = 0.0
+        ss = (grad.double() ** 2).sum().reshape(1)
+        a, b = x.clone(), x.clone()
+        pgd.l2_step_(a, grad, 0.5, 0.4, x0)
+        pgd.l2_step_(b, grad, 0.5, 0.4, x0, sumsq=ss)
+        assert (a - b).abs().max().item() <= 2e-6, (rows, cols)
+        assert (b - x).abs().max().item() > 0
+
+
+def test_colour_attack_with_fused_norms_follows_the_same_trajectory():
+    """BASELINE config 3's shape (one view per iteration, L2 on the SH colour): the loop whose steps take their norms from
+    the raster backward against the loop whose steps sum the gradient themselves."""
+    from gsplat_attack.attack import pgd_attack
+    dev, model, cams = _scene(n_views=1)
+    ref = model.clone()
+    bg = torch.zeros(3, device=dev)
+    h1 = pgd_attack(model, cams[:1], iters=4, groups=("color",), bg=bg, streams=1, fused_norms=True)
+    h0 = pgd_attack(ref, cams[:1], iters=4, groups=("color",), bg=bg, streams=1, fused_norms=False)
+    assert h1 == pytest.approx(h0, rel=1e-5, abs=1e-7)
+    for n in ("_features_dc", "_features_rest"):
+        a, b = getattr(model, n).detach(), getattr(ref, n).detach()
+        assert (a - b).abs().max().item() <= 1e-5 and (a - b).abs().max().item() < 0.1 * (a - cams[0].camera_center.new_zeros(1)).abs().max().item()
+    # all five groups, one view: the bucket path
+    m2, r2 = model.clone(), model.clone()
+    groups = ("color", "position", "scaling", "rotation", "opacity")
+    g1 = pgd_attack(m2, cams[:1], iters=3, groups=groups, bg=bg, streams=1, fused_norms=True)
+    g0 = pgd_attack(r2, cams[:1], iters=3, groups=groups, bg=bg, streams=1, fused_norms=False)
+    assert g1 == pytest.approx(g0, rel=1e-4, abs=1e-6)
+    for n in NAMES:
+        assert (getattr(m2, n).detach() - getattr(r2, n).detach()).abs().max().item() <= 2e-5, n
