@@ -899,10 +899,11 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   {
     StageTimer t(GSR_STAGE_RENDER_FWD, st);
     // Long tile lists are split into segments for the backward (gsr_kernels.hip.h, "Segments"): the forward stores the
-    // per-pixel (T, C) at the segment boundaries.  Not with object channels (their 16 running sums are not stored), not
+    // per-pixel (T, C) at the segment boundaries -- with object channels too (round 5): a backward without dL/dobjects then
+    // still walks segments; one WITH dL/dobjects ignores the records (the 16 running object sums are not stored).  Not
     // for a forward-only call, not under GSR_FLAG_NO_SEGMENTS.
     static const int seg_shift_env = [] { const char* e = getenv("GSR_SEG_SHIFT"); int v = e ? atoi(e) : 8; return (v >= 6 && v <= 16) ? v : 8; }();
-    if (nbound > 0 && ctx_out && !fwd_only && !(out_objects && sh_objs) && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
+    if (nbound > 0 && ctx_out && !fwd_only && !(s->flags & GSR_FLAG_NO_SEGMENTS)) {
       const uint32_t per = nbound >> seg_shift_env;
       c->seg_shift = (uint32_t)seg_shift_env;
       // sum over split tiles of ceil(len / seg) <= N / seg + min(T, N / seg): every split tile's records always fit

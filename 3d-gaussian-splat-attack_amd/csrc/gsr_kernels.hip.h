@@ -685,7 +685,10 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
   const int tx = tile % a.gridx, ty = tile / a.gridx;
   const uint2 rg = a.ranges[tile];
   // a split tile (see "Segments"): this wave stores (T, C) of its pixels at every segment boundary it walks past
-  const uint32_t rec0 = (!OBJ && a.bnd != nullptr) ? a.segoff[tile] : SEG_NONE;
+  // (also with object channels composited: the records hold T and the colour sums, which is all a backward WITHOUT
+  // dL/dobjects needs -- the attack never differentiates the object map -- to walk the list in segments; a backward that
+  // is handed dL/dobjects walks whole lists, the 16 running object sums are not stored)
+  const uint32_t rec0 = (a.bnd != nullptr) ? a.segoff[tile] : SEG_NONE;
   const uint32_t seg_mask = (1u << a.seg_shift) - 1u;
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   const int x = tx * TILE + (lane & 15);
@@ -881,7 +884,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
     }
     }
     if (WPB == 1) __builtin_amdgcn_wave_barrier();
-    if (!OBJ && rec0 != SEG_NONE) {
+    if (rec0 != SEG_NONE) {
       const uint32_t pos_end = base - rg.x + (uint32_t)jb + 64u;   // list positions 1 .. pos_end are behind us
       if ((pos_end & seg_mask) == 0u && pos_end < rg.y - rg.x) {
         float4* rec = a.bnd + ((size_t)(rec0 + (pos_end >> a.seg_shift) - 1u) * PXL + sub * NPX) * 64 + lane;
@@ -899,7 +902,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
       if (any == 0u) break;
     }
   }
-  if (!OBJ && rec0 != SEG_NONE) {                       // final state of a split tile: record rec0 + nseg - 1
+  if (rec0 != SEG_NONE) {                               // final state of a split tile: record rec0 + nseg - 1
     const uint32_t nseg = (rg.y - rg.x + seg_mask) >> a.seg_shift;
     float4* rec = a.bnd + ((size_t)(rec0 + nseg - 1u) * PXL + sub * NPX) * 64 + lane;
 #pragma unroll

@@ -46,11 +46,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "r04_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r04.sh)
+PMC_FILE = "r05_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r05.sh)
 
 
 def sources_digest() -> str:
-    """SHA-256 over the library's sources (csrc/*, include/gsraster.h).  profiles/collect_r04.sh stores it next to the PMC
+    """SHA-256 over the library's sources (csrc/*, include/gsraster.h).  profiles/collect_r05.sh stores it next to the PMC
     counters it collects; a bench line quotes those counters as `roofline.traffic` only while the digest still matches --
     a kernel change silently keeping the old traffic figure was possible before."""
     import hashlib
@@ -559,7 +559,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if pmc.get("sources_sha256") != sources_digest():
                 traffic_note = (f"profiles/{PMC_FILE} was collected from other kernel sources than this build's (digest "
-                                "mismatch): not quoted; run profiles/collect_r04.sh again")
+                                "mismatch): not quoted; run profiles/collect_r05.sh again")
                 raise LookupError(traffic_note)
             kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2, 1>",
                     "preprocess_bwd": "void gsr::k_pre_bwd<true, true, false>",

@@ -101,3 +101,30 @@ def test_colour_attack_with_fused_norms_follows_the_same_trajectory():
     assert g1 == pytest.approx(g0, rel=1e-4, abs=1e-6)
     for n in NAMES:
         assert (getattr(m2, n).detach() - getattr(r2, n).detach()).abs().max().item() <= 2e-5, n
+
+
+def test_backward_without_object_gradients_after_an_object_forward_walks_segments():
+    """The reference's render() always composites the 16 object channels and the attack never differentiates them
+    (gaussian_renderer/__init__.py:80-95, attack.py:486-494).  The forward with objects now stores the segment-boundary
+    records too, so that backward is the segmented K7 of the objects-off path: same image, bit-equal gradients -- on a scene
+    whose lists are long enough to be split."""
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams = _scene(P=150000, W=480, H=270, n_views=1)
+    import diff_gaussian_rasterization as D
+    bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
+    gc = torch.randn(3, 270, 480, generator=torch.Generator().manual_seed(4)).to(dev)
+    out = {}
+    for objects in (False, True):
+        model.zero_grad()
+        r = render(cams[0], model, PipelineParams(skip_objects=not objects), bg, 2.0)
+        if not objects:
+            lens = D.export_state(r["render"], "ranges").view(-1, 2).long()
+            assert int((lens[:, 1] - lens[:, 0]).max()) > 512          # split lists exist
+        r["render"].backward(gc)
+        torch.cuda.synchronize()
+        out[objects] = (r["render"].detach().clone(), {n: getattr(model, n).grad.clone() for n in NAMES})
+        if objects:
+            assert float(r["render_object"].abs().max()) > 0
+    assert torch.equal(out[False][0], out[True][0])
+    for n in NAMES:
+        assert torch.equal(out[False][1][n], out[True][1][n]), n
