@@ -85,3 +85,32 @@ print(f"  GaussianRasterizer fwd+bwd on ready activated tensors host {h:.3f}  de
 for name, pipe in pipes.items():
     h, d = timed(view(pipe), NV)
     print(f"  {name:52s} host {h:.3f}  device {d:.3f}  -> {1e3 / max(h, d):.0f} views/s on one stream")
+
+# ---- the same views dealt over four streams, with and without the host's wait for the pair count ---------------------
+from gsplat_attack.streams import StreamRing  # noqa: E402
+ring = StreamRing(4, dev)
+
+
+def piped(pipe, n):
+    def run(k):
+        for i in range(k):
+            with ring.next():
+                model.zero_grad()
+                render(cams[i % 8], model, pipe, bg)["render"].backward(gc)
+        ring.join()
+    run(12)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0), host / n * 1e3
+
+
+print("four streams: views/s (host ms per view to enqueue)")
+for flags, tag in ((0, "pair count awaited by the host"), (D.FLAG_ASYNC_COUNT, "asynchronous pair count")):
+    D.set_flags(flags)
+    for name, pipe in pipes.items():
+        r, h = piped(pipe, 2 * NV)
+        print(f"  {tag:32s} {name:52s} {r:7.0f} views/s  (host {h:.3f})")
+D.set_flags(0)
