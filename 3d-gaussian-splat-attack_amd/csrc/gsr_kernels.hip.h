@@ -3,8 +3,9 @@
 //
 // Data layout in HBM (all float32 / uint32):
 //   G0,G1,G2[REC * g]   per-Gaussian screen geometry written by K1, 3 x float4:
-//                 G0=(px,py,A,B)  G1=(C,opacity,r,g)  G2=(b, depth, rectx_bits, recty_bits)
-//                 rectx_bits = minx | maxx<<12,  recty_bits = miny | maxy<<12   (tile units); a colour whose SH sum was
+//                 G0=(px,py,A,B)  G1=(C,opacity,r,g)  G2=(b, depth, rectx_bits, recty_bits); (px, py) = the pixel centre
+//                 RELATIVE to the first pixel of the reference rect's first tile (16 (minx - offx), ...), from double-precision projection
+//                 rectx_bits = minx | maxx<<12 | offx<<24,  recty_bits likewise (tile units; off: RECT_OFF_MAX); a colour whose SH sum was
 //                 clamped at 0 is stored as -0.0f (the clamp flag of the backward)
 //   dkey[g]       float bits of view depth (positive => order-preserving), 0xFFFFFFFF for a Gaussian that emits no pair
 //   tcnt[g]       tiles of its (tightened) rect; offg[g] = exclusive scan of tcnt in storage order (numbers the
@@ -41,6 +42,11 @@ __device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
 }
 
 constexpr uint32_t RECT_MASK = 0xFFFu;
+// Bits 24..31 of a rect word: how many tiles the TIGHTENED rect's first tile lies behind the first tile of the reference's
+// 3-sigma rect.  The stored centre is relative to the latter -- the same origin whether or not the footprint cull ran, so
+// that its float32 rounding, and with it every pixel, is bit-identical under GSR_FLAG_NO_CULL -- and the compositors get
+// it back as (tightened min - this offset).  A tightening of more than 255 tiles is cut short (a few more pairs emitted).
+constexpr int RECT_OFF_MAX = 255;
 // The three float4 of a splat record are interleaved (48 contiguous bytes per Gaussian): X0/X1/X2 below are the same
 // array offset by 0/1/2 float4 and are indexed [REC * i].  REC = 3: 48 contiguous bytes per Gaussian, half of the records
 // straddle two 64-byte sectors.  -DGSR_REC=4 puts them at a 64-byte pitch (one sector per gather): measured in round 3,
@@ -127,7 +133,9 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
     radii[g] = ok ? s.radius : 0;
     if (ok) {
       const float o = opac[g];
+      const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, o, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
+      s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
       cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
       if (cnt != 0u) {
         float rgb[3];
@@ -135,13 +143,13 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
         if (colors) { rgb[0] = colors[3 * g]; rgb[1] = colors[3 * g + 1]; rgb[2] = colors[3 * g + 2]; }
         else cl = sh_to_rgb(va.deg, sh + (size_t)g * K * 3, p, v.cam, rgb);
         key = __float_as_uint(s.depth);
-        const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12);
-        const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
+        const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | ((uint32_t)(s.rminx - fminx) << 24);
+        const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12) | ((uint32_t)(s.rminy - fminy) << 24);
         // a clamped colour is stored as -0.0f: the backward reads the clamp flags off the sign bits
         if (cl & 1u) rgb[0] = -0.0f;
         if (cl & 2u) rgb[1] = -0.0f;
         if (cl & 4u) rgb[2] = -0.0f;
-        G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
+        G0[REC * g] = make_float4((float)(s.pxd - (double)(fminx * TILE)), (float)(s.pyd - (double)(fminy * TILE)), s.A, s.B);
         G1[REC * g] = make_float4(s.C, o, rgb[0], rgb[1]);
         G2[REC * g] = make_float4(rgb[2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
       }
@@ -366,7 +374,10 @@ k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, con
     if (cull) {
       const float x0 = (float)(tx * TILE);
       const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
-      mask = strip_masks4(ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, x0, x1, (float)(ty * TILE), (float)(H - 1));
+      // (the record's centre is relative to the rect's first tile: back to image coordinates for the footprint test)
+      mask = strip_masks4(ra[k].x + (float)((int)(minx - (rx >> 24)) * TILE), ra[k].y + (float)((int)(miny - (ry >> 24)) * TILE),
+                          ra[k].z, ra[k].w, rb[k].x, rb[k].y, x0,
+                          x1, (float)(ty * TILE), (float)(H - 1));
       if (mask == 0) key = ntiles;
     }
     pair_tile[e[k]] = key;
@@ -629,10 +640,16 @@ inline int render_grid(int nitems) { return 256 * ((nitems + 255) / 256); }   //
 // slightly LOWERED bound on the p2 at which alpha reaches 1/255 (a per-pixel prefilter: the reference's exact alpha
 // test is applied afterwards) whose four lowest mantissa bits are replaced by the pair's strip mask (bit k: strip k
 // of the tile can be reached) -- a 2e-6 relative nudge, far inside the bound's own 1e-4 margin.
+// The staged centre is relative to the first pixel of the TILE being composited (tx, ty): the record's centre is
+// relative to the rect's first tile (rx, ry bits), the difference is a multiple of 16 -- two small numbers, so that
+// dx = centre - column keeps float32's full resolution at any image size.
 struct StagedSplat { float4 a; float4 b; float2 c; };
-__device__ __forceinline__ StagedSplat stage_splat(const float4 r0, const float4 r1, const float bch, uint32_t mask) {
+__device__ __forceinline__ StagedSplat stage_splat(const float4 r0, const float4 r1, const float4 r2, uint32_t mask, int tx, int ty) {
   StagedSplat s;
-  s.a = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
+  const float bch = r2.x;
+  const uint32_t rxw = __float_as_uint(r2.z), ryw = __float_as_uint(r2.w);
+  const int minx = (int)(rxw & RECT_MASK) - (int)(rxw >> 24), miny = (int)(ryw & RECT_MASK) - (int)(ryw >> 24);
+  s.a = make_float4(r0.x + (float)((minx - tx) * TILE), r0.y + (float)((miny - ty) * TILE), -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
   s.b = make_float4(-0.5f * LOG2E * r1.x, r1.y, r1.z, r1.w);
   const float t = -__log2f(255.0f * r1.y);             // +inf for opacity 0: never a candidate
   const float thr = t - 1e-4f * (fabsf(t) + 1.0f);
@@ -692,7 +709,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
   const uint32_t seg_mask = (1u << a.seg_shift) - 1u;
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item] = wall_clock64();
   const int x = tx * TILE + (lane & 15);
-  const float pxf = (float)x;
+  const float pxf = (float)(lane & 15);                    // pixel coordinates relative to the tile's first pixel (stage_splat)
   int y[NPX];
   float pyf[NPX], T[NPX], C[NPX][3];
   float O[OBJ ? NPX : 1][NUM_OBJ];
@@ -702,7 +719,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
   for (int k = 0; k < NPX; ++k) {
     y[k] = ty * TILE + sub * (4 * NPX) + (lane >> 4) + 4 * k;
     const bool inside = x < a.W && y[k] < a.H;
-    pyf[k] = inside ? (float)y[k] : PX_OFF;
+    pyf[k] = inside ? (float)(y[k] - ty * TILE) : PX_OFF;
     T[k] = 1.f;
     C[k][0] = C[k][1] = C[k][2] = 0.f;
     last[k] = 0;
@@ -723,7 +740,7 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
       const float4 c = a.R2[REC * r];
       // staged mask bits: this wave's strips (own workgroup) or all four strips of the tile (shared workgroup)
       mine = WPB > 1 ? (pv >> RANK_BITS) & 0xFu : ((pv >> RANK_BITS) >> (sub * NPX)) & ((1u << NPX) - 1u);
-      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, mine);
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c, mine, tx, ty);
       rown = r;                                           // the pair's value IS the Gaussian's storage index
       s0[slot] = sp.a; s1[slot] = sp.b; s2[slot] = make_float4(sp.c.x, sp.c.y, __uint_as_float(r), 0.f);
       if (OBJ && !GSR_K6_OBJ_SCALAR && (GSR_K6_OBJ_STAGE_ALL || mine != 0u)) {   // (an entry no strip of this wave reaches is never read)
@@ -1089,7 +1106,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   int red_j = 0;       // lane b: batch index j of the b-th parked entry
   int red_n = 0;       // parked entries (wave uniform)
   const int x = tx * TILE + (lane & 15);
-  const float pxf = (float)x;
+  const float pxf = (float)(lane & 15);                    // relative to the tile's first pixel, like the staged centres
   const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
   const size_t HW = (size_t)a.H * a.W;
   float pyf[NPX], T[NPX], Acc[NPX], g0[NPX], g1[NPX], g2[NPX];
@@ -1099,7 +1116,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
 #pragma unroll
   for (int k = 0; k < NPX; ++k) {
     const int y = ty * TILE + sub * (4 * NPX) + (lane >> 4) + 4 * k;
-    pyf[k] = (float)y;
+    pyf[k] = (float)(y - ty * TILE);
     Acc[k] = 0.f;
     if (x < a.W && y < a.H) {
       const size_t pix = (size_t)y * a.W + x;
@@ -1153,7 +1170,7 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
       uint32_t live = 0;
 #pragma unroll
       for (int k = 0; k < NPX; ++k) live |= (pos <= smax[k] ? 1u : 0u) << k;
-      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c.x, ((pv >> RANK_BITS) >> (sub * NPX)) & live);
+      const StagedSplat sp = stage_splat(a.R0[REC * r], a.R1[REC * r], c, ((pv >> RANK_BITS) >> (sub * NPX)) & live, tx, ty);
       s0[lane] = sp.a; s1[lane] = sp.b; s2[lane] = sp.c;
       const uint32_t rx = __float_as_uint(c.z), ry = __float_as_uint(c.w);
       const uint32_t minx = rx & RECT_MASK, wx = ((rx >> 12) & RECT_MASK) - minx, miny = ry & RECT_MASK;
@@ -1617,13 +1634,15 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     if (vis) {
       const float oraw = second ? a.opac_b[gl] : a.opac[gl];
       const float op = RAW ? act_sigmoid(oraw) : oraw;
+      const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (a.cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, op, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
+      s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
       cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
       if (cnt != 0u) {
         key = __float_as_uint(s.depth);
-        const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12);
-        const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12);
-        a.G0[REC * g] = make_float4(s.px, s.py, s.A, s.B);
+        const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | ((uint32_t)(s.rminx - fminx) << 24);
+        const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12) | ((uint32_t)(s.rminy - fminy) << 24);
+        a.G0[REC * g] = make_float4((float)(s.pxd - (double)(fminx * TILE)), (float)(s.pyd - (double)(fminy * TILE)), s.A, s.B);
         float* g1 = reinterpret_cast<float*>(&a.G1[REC * g]);
         float* g2 = reinterpret_cast<float*>(&a.G2[REC * g]);
         if (a.colors) {

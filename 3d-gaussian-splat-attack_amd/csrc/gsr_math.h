@@ -92,7 +92,13 @@ GSR_HD void cov3d_from_scale_rot(const float s_in[3], float mod, const float q[4
 // Geometry of one Gaussian on screen (K1 steps 1-8, 10)
 // ---------------------------------------------------------------------------------------------
 struct Splat {
-  float px, py;      // pixel-space centre
+  float px, py;      // pixel-space centre, the published float32 arithmetic: every INTEGER decision (radius, tile rect, culls)
+                     // is taken from these, like the reference's
+  double pxd, pyd;   // the same centre from double-precision dot products of the float32 inputs: what the compositors measure
+                     // distances from (round 5).  A float32 coordinate beyond 2048 resolves 2.4e-4 px, and d ln(alpha) / d centre
+                     // of a one-pixel splat is O(1): at 4K the published float32 centre alone costs up to 2e-4 in a pixel's
+                     // colour (profiles/r05_fullsize_sweep.txt, tests/diag_cfg5_pixel.py).  Stored relative to the rect's
+                     // first tile (a small number: full float32 resolution), see k_pre_geom / stage_splat.
   float depth;       // view-space z
   float A, B, C;     // conic = inverse of the dilated 2D covariance
   int radius;        // 0 => culled
@@ -167,6 +173,15 @@ GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Sp
   const int radius = (int)ceilf(3.0f * sqrtf(lam));
   s.px = ((ndcx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
   s.py = ((ndcy + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+  {
+    const double x = (double)p[0], y = (double)p[1], z = (double)p[2];
+    const double h0 = x * (double)v.PV[0] + y * (double)v.PV[4] + z * (double)v.PV[8] + (double)v.PV[12];
+    const double h1 = x * (double)v.PV[1] + y * (double)v.PV[5] + z * (double)v.PV[9] + (double)v.PV[13];
+    const double h3 = x * (double)v.PV[3] + y * (double)v.PV[7] + z * (double)v.PV[11] + (double)v.PV[15];
+    const double wd = 1.0 / (h3 + (double)1e-7f);
+    s.pxd = ((h0 * wd + 1.0) * (double)v.W - 1.0) * 0.5;
+    s.pyd = ((h1 * wd + 1.0) * (double)v.H - 1.0) * 0.5;
+  }
   const float rf = (float)radius;
   s.rminx = trunc_clamp((s.px - rf) / (float)TILE, v.gridx);
   s.rminy = trunc_clamp((s.py - rf) / (float)TILE, v.gridy);
