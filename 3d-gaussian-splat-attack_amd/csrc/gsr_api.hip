@@ -464,6 +464,7 @@ struct GsrCtx {
   size_t keep_bytes = 0;
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // splat records, storage order (the compositors gather them)
   float* D = nullptr;             // [P,9] d rgb / d view direction (lane-group kernels, SH input, backward expected)
+  double* abc = nullptr;          // [P,3] the dilated 2D covariance from the double chain (K1 -> K9; backward expected)
   bool lanegroup = false;         // K1 ran as k_pre_geom + k_pre_color: K8+K9 runs as k_pre_bwd
   uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
@@ -680,6 +681,9 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->lanegroup = raw || (shs && K == 16) || colors_precomp != nullptr;
   const bool want_D = c->lanegroup && shs != nullptr && ctx_out != nullptr && !fwd_only;
   if (want_D) kp.add<float>(9 * Pp);
+  const bool needle_double = (s->flags & GSR_FLAG_NEEDLE_DOUBLE) != 0u;
+  const bool want_abc = needle_double && c->lanegroup && ctx_out != nullptr && !fwd_only;
+  if (want_abc) kp.add<double>(3 * Pp);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
@@ -703,6 +707,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->dv = ks.take<uint32_t>(DV_WORDS);
   c->sched = ks.take<uint32_t>(ntiles);
   if (want_D) c->D = ks.take<float>(9 * Pp);
+  if (want_abc) c->abc = ks.take<double>(3 * Pp);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkey = ss.take<uint32_t>(Pp); uint32_t* k1 = ss.take<uint32_t>(Pp); uint32_t* vtmp = ss.take<uint32_t>(Pp);
@@ -777,18 +782,24 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
         pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
         pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt; pa.offg = nullptr;
+        pa.abc = c->abc;
         pa.Pa = segb ? P - segb->Pb : P;
         pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
         pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
         pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
         pa.cull = cull; pa.bo = bo;
-        if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
-        else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
+        if (needle_double) {
+          if (raw) hipLaunchKernelGGL((k_pre_geom<true, true>), gridPre, blkPre, 0, st, pa);
+          else hipLaunchKernelGGL((k_pre_geom<false, true>), gridPre, blkPre, 0, st, pa);
+        } else {
+          if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
+          else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
+        }
         color_pa = pa;
         want_color = !colors_precomp;
         if (want_color && !fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
       } else
-        hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, cull, means3D, scales, rotations, cov3D_precomp,
+        hipLaunchKernelGGL(k_preprocess, gridPre, blkPre, 0, st, P, K, va, (cull ? 1 : 0) | (needle_double ? 2 : 0), means3D, scales, rotations, cov3D_precomp,
                            opacities, shs, colors_precomp, radii, G0, G1, G2, dkey, tcnt, bo);
       // storage-order numbering of the pairs (where the backward puts its partial rows), the depth sort's digit width
       // and first histogram, the device-side pair count -- published to the host slot by the kernel itself: one launch
@@ -1163,7 +1174,8 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.part = part; pa.part_obj = obj ? part_obj : nullptr;
     pa.tag_lo = tag_lo; pa.tag_hi = tag_hi; pa.nsub = nsub;
     pa.means = c->means3D; pa.scales = c->scales; pa.rots = c->rots; pa.cov3d = c->cov3d; pa.sh = c->shs;
-    pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc; pa.D = c->D;
+    pa.sh_dc = c->sh_dc; pa.dsh_dc = dsh_dc; pa.D = c->D; pa.abc = c->abc;
+    pa.needle_double = (c->st.flags & GSR_FLAG_NEEDLE_DOUBLE) != 0u ? 1 : 0;
     pa.dmeans3D = dmeans3D; pa.dmeans2D = dmeans2D; pa.dsh = c->shs ? dshs : nullptr; pa.dsh_objs = dsh_objs;
     pa.dcolors = c->colors ? dcolors_precomp : nullptr; pa.dopac = dopacities;
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;

@@ -103,7 +103,8 @@ __device__ __forceinline__ void pre_block_epilogue(const PreBlockOut& o, int g, 
 // ------------------------------------------------------------------------------------------------
 // K1, generic form: one thread per Gaussian in storage order, any SH coefficient count K (the layouts the reference
 // uses -- K = 16, the raw dc | rest pair, precomputed colours -- take k_pre_geom / k_pre_color below).
-// cull != 0: the tile rect is shrunk to the alpha >= 1/255 footprint's bounding box (tighten_rect).
+// cull bit 0: the tile rect is shrunk to the alpha >= 1/255 footprint's bounding box (tighten_rect); bit 1: needles get their
+// conic from the double chain (GSR_FLAG_NEEDLE_DOUBLE).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArgs va, int cull, const float* __restrict__ means,
                                                     const float* __restrict__ scales, const float* __restrict__ rots,
@@ -133,8 +134,19 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
     radii[g] = ok ? s.radius : 0;
     if (ok) {
       const float o = opac[g];
+      if ((cull & 2) && is_needle(s.ca, s.cb, s.cc)) {       // cull bit 1: GSR_FLAG_NEEDLE_DOUBLE
+        // a needle's conic (compositors and footprint tests): the same chain in double (gsr_math.h conic_accurate)
+        float scd[3] = {0.f, 0.f, 0.f}, qd[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!cov3d) {
+          scd[0] = scales[3 * g]; scd[1] = scales[3 * g + 1]; scd[2] = scales[3 * g + 2];
+          const float4 q4d = reinterpret_cast<const float4*>(rots)[g];
+          qd[0] = q4d.x; qd[1] = q4d.y; qd[2] = q4d.z; qd[3] = q4d.w;
+        }
+        conic_accurate(v, p, scd, va.mod, qd, cov3d ? c6 : nullptr, s);
+        s.A = (float)s.Ad; s.B = (float)s.Bd; s.C = (float)s.Cd;
+      }
       const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
-      if (cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, o, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
+      if (cull & 1) tighten_rect(s.px, s.py, s.A, s.B, s.C, o, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
       s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
       cnt = (uint32_t)((s.rmaxx - s.rminx) * (s.rmaxy - s.rminy));
       if (cnt != 0u) {
@@ -1360,6 +1372,8 @@ struct PreBwdArgs {
   const float* sh;        // RAW: _features_rest
   const float* sh_dc;     // RAW: _features_dc
   const float* D;         // [P,9] d rgb / d view direction left by k_pre_color (lane-group kernels only)
+  const double* abc;      // [P,3] the dilated 2D covariance (double chain) left by k_pre_geom (k_pre_bwd with GEOM needs it; the
+                          // generic k_preprocess_bwd recomputes it)
   float* dmeans3D;
   float* dmeans2D;
   float* dsh;             // RAW: gradient of _features_rest
@@ -1372,6 +1386,7 @@ struct PreBwdArgs {
   float* dcov3d;
   int accumulate;         // != 0 (k_pre_bwd only): the 59 attribute gradients are ADDED to (Gaussians without pairs are
                           // left alone); dmeans2D and dsh_objs, which belong to one view, are overwritten regardless
+  int needle_double;      // GSR_FLAG_NEEDLE_DOUBLE was set in the forward (generic k_preprocess_bwd recomputes the double chain)
   float* sumsq;           // k_pre_bwd<RAW = true, ., ACC = false> only, or null: [workgroups][SUMSQ_W] per-workgroup sums of
                           // squares of the gradients this launch writes, per attribute tensor (SUMSQ_* below)
 };
@@ -1478,7 +1493,21 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
       cov3d_from_scale_rot(sc, a.va.mod, q, c6);
     }
     float dc6[6];
-    project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+    // (the 2D covariance the forward's conic was inverted from: the double chain for a needle, else the float32 one)
+    double abc[3];
+    bool needle;
+    {
+      float tt[3];
+      for (int j = 0; j < 3; ++j) tt[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+      ProjLin pl;
+      proj_linear(v, tt, pl);
+      float fa, fb, fc;
+      cov2d_from_M(pl.M, c6, fa, fb, fc);
+      needle = is_needle(fa, fb, fc);
+      abc[0] = fa; abc[1] = fb; abc[2] = fc;
+    }
+    if (needle && a.needle_double) cov2d_accurate(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, abc[0], abc[1], abc[2]);
+    project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6, true, abc[0], abc[1], abc[2]);
     if (a.dmeans3D) { put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]); }
     if (a.cov3d) {
       if (a.dcov3d) for (int i = 0; i < 6; ++i) put(&a.dcov3d[6 * g + i], dc6[i]);
@@ -1582,6 +1611,7 @@ struct PreArgs {
   float4* G1;
   float4* G2;
   float* D;               // [P,9] d rgb_c / d dir_axis (before the clamp), or null: not wanted (no backward follows)
+  double* abc;            // [P,3] k_pre_geom: the dilated 2D covariance of the double chain, for K9 (or null: no backward)
   uint32_t* dkey;         // float bits of the view depth; 0xFFFFFFFF for a Gaussian that emits no pair
   uint32_t* tcnt;         // tiles of the (tightened) rect
   const uint32_t* offg;   // colour kernel with tcnt == null (re-render of a kept context): a Gaussian emits pairs iff
@@ -1601,7 +1631,7 @@ __device__ __forceinline__ uint32_t clamp_bits_of(float r, float g, float b) {
 // K1, geometry half: one thread per Gaussian -- projection, culls, tile rect, depth key, tiles touched, the geometric
 // words of the 48-byte record ((px,py,A,B) (C,opacity,.,.) (.,depth,rect x,rect y)) -- and the workgroup sums the storage
 // scan starts from.  Reads 44 bytes per Gaussian.  With precomputed colours it writes those too (nothing else to do).
-template <bool RAW>
+template <bool RAW, bool NDL = false>
 __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
   const int g = blockIdx.x * PREG_BLOCK + threadIdx.x;
   uint32_t cnt = 0, key = 0xFFFFFFFFu;
@@ -1613,14 +1643,15 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     const float* means = second ? a.means_b : a.means;
     const float p[3] = {means[3 * gl], means[3 * gl + 1], means[3 * gl + 2]};
     float c6[6];
+    float sc[3] = {0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.cov3d) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) c6[i] = a.cov3d[6 * g + i];
     } else {
       const float* scales = second ? a.scales_b : a.scales;
-      float sc[3] = {scales[3 * gl], scales[3 * gl + 1], scales[3 * gl + 2]};
+      sc[0] = scales[3 * gl]; sc[1] = scales[3 * gl + 1]; sc[2] = scales[3 * gl + 2];
       const float4 q4 = reinterpret_cast<const float4*>(second ? a.rots_b : a.rots)[gl];
-      float q[4] = {q4.x, q4.y, q4.z, q4.w};
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
       if (RAW) {
         sc[0] = expf(sc[0]); sc[1] = expf(sc[1]); sc[2] = expf(sc[2]);
         float inv_n;
@@ -1634,6 +1665,17 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     if (vis) {
       const float oraw = second ? a.opac_b[gl] : a.opac[gl];
       const float op = RAW ? act_sigmoid(oraw) : oraw;
+      // NDL (GSR_FLAG_NEEDLE_DOUBLE): a needle's conic -- what the compositors and the footprint tests use -- comes from the
+      // same chain in double, on the same float32 (activated) inputs (gsr_math.h is_needle / cov2d_accurate); every other
+      // splat, and every splat without the flag, keeps the published float32 conic.  Radius, rect and culls above are the
+      // float32 chain's either way.  (A template parameter: the double chain costs the kernel 20 registers.)
+      double ca = (double)s.ca, cb = (double)s.cb, cc = (double)s.cc;
+      if (NDL && is_needle(s.ca, s.cb, s.cc)) {
+        cov2d_accurate(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, ca, cb, cc);
+        const double dinv = 1.0 / (ca * cc - cb * cb);     // >= 0.09 in exact arithmetic: a PSD matrix + 0.3 I
+        s.A = (float)(cc * dinv); s.B = (float)(-cb * dinv); s.C = (float)(ca * dinv);
+      }
+      if (a.abc) { a.abc[3 * (size_t)g] = ca; a.abc[3 * (size_t)g + 1] = cb; a.abc[3 * (size_t)g + 2] = cc; }   // for K9
       const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (a.cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, op, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
       s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
@@ -1935,7 +1977,11 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
           cov3d_from_scale_rot(sc, a.va.mod, q, c6);
         }
         float dc6[6];
-        project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+        // (the 2D covariance the forward's conic was inverted from: the double chain, like k_pre_geom)
+        // (GSR_FLAG_NEEDLE_DOUBLE: k_pre_geom left it beside the records; without the flag the float32 chain's is formed here)
+        double abc0 = 0.0, abc1 = 0.0, abc2 = 0.0;
+        if (a.abc) { abc0 = a.abc[3 * (size_t)g]; abc1 = a.abc[3 * (size_t)g + 1]; abc2 = a.abc[3 * (size_t)g + 2]; }
+        project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6, a.abc != nullptr, abc0, abc1, abc2);
         if (a.dmeans3D) {
           put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]);
           ssq[SUMSQ_XYZ] = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];

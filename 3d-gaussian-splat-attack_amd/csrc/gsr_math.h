@@ -94,6 +94,11 @@ GSR_HD void cov3d_from_scale_rot(const float s_in[3], float mod, const float q[4
 struct Splat {
   float px, py;      // pixel-space centre, the published float32 arithmetic: every INTEGER decision (radius, tile rect, culls)
                      // is taken from these, like the reference's
+  float ca, cb, cc;  // the dilated 2D covariance of the float32 chain (what A, B, C were inverted from)
+  double Ad, Bd, Cd; // the conic from the same chain (covariance -> J W Sigma W^T J^T + 0.3 I -> inverse) evaluated in double on
+                     // the float32 inputs (conic_accurate): for a strongly elongated splat det = a c - b^2 cancels by the
+                     // eigenvalue ratio, and the float32 chain leaves 1e-7 x that ratio in every conic entry (1.5e-4 for a
+                     // 1500:1 needle whose exponent sums terms of 1e4) -- in the reference's kernels as much as anywhere
   double pxd, pyd;   // the same centre from double-precision dot products of the float32 inputs: what the compositors measure
                      // distances from (round 5).  A float32 coordinate beyond 2048 resolves 2.4e-4 px, and d ln(alpha) / d centre
                      // of a one-pixel splat is O(1): at 4K the published float32 centre alone costs up to 2e-4 in a pixel's
@@ -168,6 +173,7 @@ GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Sp
   if (det == 0.0f) return false;
   const float dinv = 1.0f / det;
   s.A = c * dinv; s.B = -b * dinv; s.C = a * dinv;
+  s.ca = a; s.cb = b; s.cc = c;
   const float mid = 0.5f * (a + c);
   const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
   const int radius = (int)ceilf(3.0f * sqrtf(lam));
@@ -191,6 +197,69 @@ GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Sp
   s.depth = t[2];
   s.radius = radius;
   return true;
+}
+
+// A splat is a NEEDLE for the purposes below when the eigenvalues of its dilated 2D covariance are more than
+// NEEDLE_RATIO apart ((a + c)^2 / det = r + 2 + 1/r): the float32 chain leaves about 1e-7 x that ratio in every conic
+// entry -- 3e-5 at the threshold, where the two chains therefore agree to five digits --, the exponent of a needle sums
+// terms of (radius)^2 that cancel to O(1), and its gradients cancel once more (EXPERIMENTS.md, rounds 3-5: a 1500:1 needle's
+// dL/dmean2D 2.3 % off in float32).  Ordinary splats keep the published float32 conic bit for bit.
+constexpr float NEEDLE_RATIO = 256.0f;
+GSR_HD bool is_needle(float a, float b, float c) { const float tr = a + c; return tr * tr > (NEEDLE_RATIO + 2.0f) * (a * c - b * b); }
+
+// The conic of a visible splat in double (round 5): the published chain -- Sigma = (R diag(mod s)) (...)^T from the
+// quaternion AS GIVEN, or the precomputed covariance; t = p V with t.x/t.z, t.y/t.z clamped to +-1.3 tan(fov/2); J; cov2D =
+// J W Sigma W^T J^T + 0.3 I; conic = cov2D^-1 -- with every product in double, from the same float32 inputs the float32
+// chain of project_splat() reads.  Nothing INTEGER comes from it: radius, rect and culls stay project_splat()'s.
+// (cov2d_accurate: the dilated 2D covariance (a, b, c) of that chain; conic_accurate: its inverse, into the Splat)
+GSR_HD void cov2d_accurate(const View& v, const float p[3], const float* sc, float mod, const float* q, const float* c6pre,
+                           double& a, double& b, double& c) {
+  double S[6];
+  if (c6pre) {
+    for (int i = 0; i < 6; ++i) S[i] = (double)c6pre[i];
+  } else {
+    const double r = q[0], x = q[1], y = q[2], z = q[3];
+    const double R[9] = {1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - r * z), 2.0 * (x * z + r * y),
+                         2.0 * (x * y + r * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z - r * x),
+                         2.0 * (x * z - r * y), 2.0 * (y * z + r * x), 1.0 - 2.0 * (x * x + y * y)};
+    const double s0 = (double)mod * sc[0], s1 = (double)mod * sc[1], s2 = (double)mod * sc[2];
+    const double L[9] = {R[0] * s0, R[1] * s1, R[2] * s2, R[3] * s0, R[4] * s1, R[5] * s2, R[6] * s0, R[7] * s1, R[8] * s2};
+    S[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+    S[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+    S[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+    S[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+    S[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+    S[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+  }
+  double t[3];
+  for (int j = 0; j < 3; ++j)
+    t[j] = (double)p[0] * v.V[j] + (double)p[1] * v.V[4 + j] + (double)p[2] * v.V[8 + j] + (double)v.V[12 + j];
+  const double limx = (double)FOV_CLAMP * v.tanfovx, limy = (double)FOV_CLAMP * v.tanfovy;
+  const double tz = t[2];
+  double tx = t[0] / tz, ty = t[1] / tz;
+  tx = (tx < -limx ? -limx : (tx > limx ? limx : tx)) * tz;
+  ty = (ty < -limy ? -limy : (ty > limy ? limy : ty)) * tz;
+  const double fx = (double)v.W / (2.0 * (double)v.tanfovx), fy = (double)v.H / (2.0 * (double)v.tanfovy);
+  const double J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+  double M[6];
+  for (int i = 0; i < 3; ++i) {
+    M[i] = J00 * v.V[i * 4 + 0] + J02 * v.V[i * 4 + 2];
+    M[3 + i] = J11 * v.V[i * 4 + 1] + J12 * v.V[i * 4 + 2];
+  }
+  const double u0 = S[0] * M[0] + S[1] * M[1] + S[2] * M[2], u1 = S[1] * M[0] + S[3] * M[1] + S[4] * M[2],
+               u2 = S[2] * M[0] + S[4] * M[1] + S[5] * M[2];
+  const double w0 = S[0] * M[3] + S[1] * M[4] + S[2] * M[5], w1 = S[1] * M[3] + S[3] * M[4] + S[4] * M[5],
+               w2 = S[2] * M[3] + S[4] * M[4] + S[5] * M[5];
+  a = M[0] * u0 + M[1] * u1 + M[2] * u2 + (double)DILATE;
+  b = M[3] * u0 + M[4] * u1 + M[5] * u2;
+  c = M[3] * w0 + M[4] * w1 + M[5] * w2 + (double)DILATE;
+}
+
+GSR_HD void conic_accurate(const View& v, const float p[3], const float* sc, float mod, const float* q, const float* c6pre, Splat& s) {
+  double a, b, c;
+  cov2d_accurate(v, p, sc, mod, q, c6pre, a, b, c);
+  const double dinv = 1.0 / (a * c - b * b);       // >= 0.09 in exact arithmetic: a PSD matrix + 0.3 I
+  s.Ad = c * dinv; s.Bd = -b * dinv; s.Cd = a * dinv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,8 +360,11 @@ GSR_HD void sh_to_rgb_bwd(int deg, int Kstore, const float* sh, const float p[3]
 // Inputs: true partials dL/dA, dL/dB, dL/dC of the conic (B counted once), dL/d(ndc.xy) (= the
 // extension's dL_dmean2D), and the forward inputs.  Outputs: dL/dmean (added into dp), dL/dcov3D
 // packed (dc6), to be pushed further to scale/rotation by cov3d_bwd when those were the inputs.
+// have_abc: (abc0, abc1, abc2) is the dilated 2D covariance from cov2d_accurate (what the forward's conic was inverted from
+// under GSR_FLAG_NEEDLE_DOUBLE); otherwise the float32 chain's is formed here
 GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6], double dA, double dB, double dC,
-                              float dndcx, float dndcy, float dp[3], float dc6[6]) {
+                              float dndcx, float dndcy, float dp[3], float dc6[6], bool have_abc = false, double abc0 = 0.0,
+                              double abc1 = 0.0, double abc2 = 0.0) {
   float t[3];
   for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
   ProjLin pl;
@@ -303,7 +375,7 @@ GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6]
   // dL/dconic ~ K (u_x^2, 2 u_x u_y, u_y^2) from the pixels along its axis: every term is ~ l1^2 K, their sum ~ l1 l2 K),
   // so they are formed in double: float32 products lose l1 / l2 (1e4 for a 100:1 needle) times 6e-8 here, on top of
   // what the summed dL/dconic already carries.  A few dozen double operations per Gaussian, in a memory-bound kernel.
-  const double ad = (double)a, bd = (double)b, cd = (double)c;
+  const double ad = have_abc ? abc0 : (double)a, bd = have_abc ? abc1 : (double)b, cd = have_abc ? abc2 : (double)c;
   const double det = ad * cd - bd * bd;
   const double d2 = 1.0 / (det * det);   // det >= DILATE^2 - rounding > 0 for a PSD covariance
   const float da = (float)((-cd * cd * dA + bd * cd * dB - bd * bd * dC) * d2);

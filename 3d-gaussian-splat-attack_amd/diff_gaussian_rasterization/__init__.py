@@ -30,6 +30,7 @@ FLAG_NO_SEGMENTS = 1 << 16
 FLAG_FWD_SHARED = 1 << 17   # the forward waves of a tile share one staging of the list (opt-in; include/gsraster.h)
 FLAG_ASYNC_COUNT = 1 << 18  # GSR_FLAG_ASYNC_COUNT: never wait for the pair count (capacity guess + overflow flag)
 FLAG_NO_SIDE_STREAM = 1 << 19   # GSR_FLAG_NO_SIDE_STREAM: SH -> RGB on the caller's stream instead of the side stream
+FLAG_NEEDLE_DOUBLE = 1 << 20    # GSR_FLAG_NEEDLE_DOUBLE: needles' conic (and its backward) from the double chain (opt-in)
 _FLAGS = int(os.environ.get("GSR_FLAGS", "0"), 0)
 
 

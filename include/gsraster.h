@@ -75,6 +75,14 @@ enum {
  * binning chain of the same view, and joins it before compositing (events; the caller's stream semantics are
  * unchanged).  This flag keeps everything on the caller's stream. */
 #define GSR_FLAG_NO_SIDE_STREAM (1u << 19)
+/* GSR_FLAG_NEEDLE_DOUBLE: splats whose dilated 2D covariance has eigenvalues more than 256 apart ("needles") get their
+ * conic -- and the backward the 2D covariance it is differentiated through -- from the published chain evaluated in double on
+ * the same float32 inputs.  The float32 chain leaves 1e-7 x that ratio in every conic entry, which a needle's exponent
+ * (terms of radius^2 cancelling to O(1)) and gradients (cancelling once more) amplify: a 1500:1 needle's dL/dmean2D is 2.3 %
+ * off in float32 -- in the reference's kernels as in any float32 statement of the formula.  Integer decisions (radius, tile
+ * rect, culls) and every ordinary splat are unchanged.  Opt-in: it costs the geometry kernel 20 registers and a view
+ * 1.3 % (one stream) to 2.8 % (four) on S-nyc-1M, whose splats are not needles (EXPERIMENTS.md, round 5). */
+#define GSR_FLAG_NEEDLE_DOUBLE (1u << 20)
 
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the

@@ -128,3 +128,45 @@ def test_backward_without_object_gradients_after_an_object_forward_walks_segment
     assert torch.equal(out[False][0], out[True][0])
     for n in NAMES:
         assert torch.equal(out[False][1][n], out[True][1][n]), n
+
+
+@pytest.mark.parametrize("seed,elem_frac", [(106, 1e-3), (102, 0.035), (45, 1e-3)])
+def test_needle_splats_under_the_double_chain_flag(seed, elem_frac):
+    """GSR_FLAG_NEEDLE_DOUBLE: the anisotropic draws whose gradient elements float32 cannot hold (round 3 / 4: a 1500:1
+    needle's dL/dmean2D 2.3 % off, a 2300:1 needle's dL/dmean3D 8-11 % off, while the float32 oracle is itself 0.4-5 % off)
+    against the float64 oracle OUTRIGHT -- no float32 yardstick: solid pixels to 1e-4, every gradient group to 1e-3, at most
+    one significant element in a thousand off by more than 5e-3 (seed 102: 21 Gaussians, 84 % of the pixels fragile, 32
+    significant screen-space elements: one of them may be)."""
+    import diff_gaussian_rasterization as D
+    import test_gpu_parity as T
+    from fuzz_cases import aniso_case
+    inp, cam, bg, kw, desc = aniso_case(seed)
+    with D.extra_flags(D.FLAG_NEEDLE_DOUBLE):
+        rep = T.check(inp, cam, bg, frag_frac=1.0, elem_frac=elem_frac, f32_grads=False, **kw)
+    assert rep, "nothing compared"
+    print(f"needle seed {seed} {desc}: " + ", ".join(f"{k} {v[0]:.1e}" for k, v in rep.items()))
+
+
+def test_needle_flag_leaves_ordinary_splats_alone():
+    """Splats whose covariance eigenvalues are less than 256 apart keep the published float32 conic under the flag: a scene
+    without needles renders and differentiates to the same numbers (to rounding: the flag selects another instantiation
+    of the geometry kernel, whose float32 chain the compiler may contract differently)."""
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.renderer import PipelineParams, render
+    dev, model, cams = _scene(n_views=1)
+    with torch.no_grad():
+        model._scaling.copy_(model._scaling.mean(dim=1, keepdim=True).expand(-1, 3) + 0.05 * torch.randn_like(model._scaling))
+    bg = torch.zeros(3, device=dev)
+    gc = torch.randn(3, 192, 320, generator=torch.Generator().manual_seed(8)).to(dev)
+    res = []
+    for flags in (0, D.FLAG_NEEDLE_DOUBLE):
+        with D.extra_flags(flags):
+            model.zero_grad()
+            out = render(cams[0], model, PipelineParams(skip_objects=True), bg)
+            out["render"].backward(gc)
+            torch.cuda.synchronize()
+            res.append((out["render"].detach().clone(), {n: getattr(model, n).grad.clone() for n in NAMES}))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 2e-6
+    for n in NAMES:
+        scale = res[0][1][n].abs().max().item()
+        assert (res[0][1][n] - res[1][1][n]).abs().max().item() <= 2e-5 * scale, n
