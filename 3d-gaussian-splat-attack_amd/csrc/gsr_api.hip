@@ -1213,18 +1213,23 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
         pa.g0 = gb; pa.P = ge;
         const dim3 gridK9((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK));
         if (c->lanegroup) {
+          const bool ndl = pa.needle_double != 0 && pa.abc != nullptr;
           if (c->raw && accumulate) {
-            if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            if (geom && ndl) hipLaunchKernelGGL((k_pre_bwd<true, true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            else if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else hipLaunchKernelGGL((k_pre_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
           } else if (c->raw) {
-            if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            if (geom && ndl) hipLaunchKernelGGL((k_pre_bwd<true, true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            else if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
           } else {
-            if (geom) hipLaunchKernelGGL((k_pre_bwd<false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            if (geom && ndl) hipLaunchKernelGGL((k_pre_bwd<false, true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+            else if (geom) hipLaunchKernelGGL((k_pre_bwd<false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else hipLaunchKernelGGL((k_pre_bwd<false, false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
           }
         } else {
-          if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+          if (geom && pa.needle_double) hipLaunchKernelGGL((k_preprocess_bwd<true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
+          else if (geom) hipLaunchKernelGGL((k_preprocess_bwd<true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
           else hipLaunchKernelGGL((k_preprocess_bwd<false>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
         }
       }

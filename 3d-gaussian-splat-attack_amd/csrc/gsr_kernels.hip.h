@@ -142,8 +142,9 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
           const float4 q4d = reinterpret_cast<const float4*>(rots)[g];
           qd[0] = q4d.x; qd[1] = q4d.y; qd[2] = q4d.z; qd[3] = q4d.w;
         }
-        conic_accurate(v, p, scd, va.mod, qd, cov3d ? c6 : nullptr, s);
-        s.A = (float)s.Ad; s.B = (float)s.Bd; s.C = (float)s.Cd;
+        double ca, cb, cc;
+        cov2d_accurate(v, p, scd, va.mod, qd, cov3d ? c6 : nullptr, ca, cb, cc);
+        needle_conic_to_float(ca, cb, cc, s.A, s.B, s.C);
       }
       const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (cull & 1) tighten_rect(s.px, s.py, s.A, s.B, s.C, o, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
@@ -1372,8 +1373,7 @@ struct PreBwdArgs {
   const float* sh;        // RAW: _features_rest
   const float* sh_dc;     // RAW: _features_dc
   const float* D;         // [P,9] d rgb / d view direction left by k_pre_color (lane-group kernels only)
-  const double* abc;      // [P,3] the dilated 2D covariance (double chain) left by k_pre_geom (k_pre_bwd with GEOM needs it; the
-                          // generic k_preprocess_bwd recomputes it)
+  const double* abc;      // [P,3] k_pre_geom's needle marks under GSR_FLAG_NEEDLE_DOUBLE (first word: a number = needle, NaN = not)
   float* dmeans3D;
   float* dmeans2D;
   float* dsh;             // RAW: gradient of _features_rest
@@ -1410,8 +1410,8 @@ __global__ void __launch_bounds__(256) k_sumsq_reduce(const float* __restrict__ 
 
 // Generic form (any K): one thread per Gaussian walks its own partial rows and its own SH row.
 // GEOM = false: the rows carry the three colour sums only (K7 without the geometry sums) and only the SH / colour /
-// object-feature gradients are produced.
-template <bool GEOM>
+// object-feature gradients are produced.  NDL: GSR_FLAG_NEEDLE_DOUBLE was set in the forward (needles run needle_bwd_d).
+template <bool GEOM, bool NDL = false>
 __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
   const int g = a.g0 + blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int K = a.K;
@@ -1493,10 +1493,10 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
       cov3d_from_scale_rot(sc, a.va.mod, q, c6);
     }
     float dc6[6];
-    // (the 2D covariance the forward's conic was inverted from: the double chain for a needle, else the float32 one)
-    double abc[3];
-    bool needle;
-    {
+    float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    // GSR_FLAG_NEEDLE_DOUBLE: a needle (the forward's test, on the float32 chain's 2D covariance) runs its chain rule in double
+    bool needle = false;
+    if (NDL) {
       float tt[3];
       for (int j = 0; j < 3; ++j) tt[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
       ProjLin pl;
@@ -1504,16 +1504,22 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
       float fa, fb, fc;
       cov2d_from_M(pl.M, c6, fa, fb, fc);
       needle = is_needle(fa, fb, fc);
-      abc[0] = fa; abc[1] = fb; abc[2] = fc;
     }
-    if (needle && a.needle_double) cov2d_accurate(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, abc[0], abc[1], abc[2]);
-    project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6, true, abc[0], abc[1], abc[2]);
+    if (NDL && needle) {
+      double dpd[3] = {(double)dp[0], (double)dp[1], (double)dp[2]}, dsd[3], dqd[4], dS6[6];
+      needle_bwd_d(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, (double)dA, (double)dB, (double)dC, (double)dndcx, (double)dndcy,
+                   dpd, dsd, dqd, dS6);
+      for (int i = 0; i < 3; ++i) { dp[i] = (float)dpd[i]; ds[i] = (float)dsd[i]; }
+      for (int i = 0; i < 4; ++i) dq[i] = (float)dqd[i];
+      for (int i = 0; i < 6; ++i) dc6[i] = (float)dS6[i];
+    } else {
+      project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+      if (!a.cov3d && (a.dscales || a.drots)) cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
+    }
     if (a.dmeans3D) { put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]); }
     if (a.cov3d) {
       if (a.dcov3d) for (int i = 0; i < 6; ++i) put(&a.dcov3d[6 * g + i], dc6[i]);
     } else if (a.dscales || a.drots) {
-      float ds[3], dq[4];
-      cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
       if (a.dscales) { put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]); }
       if (a.drots) { put(&a.drots[4 * g], dq[0]); put(&a.drots[4 * g + 1], dq[1]); put(&a.drots[4 * g + 2], dq[2]); put(&a.drots[4 * g + 3], dq[3]); }
     }
@@ -1611,7 +1617,7 @@ struct PreArgs {
   float4* G1;
   float4* G2;
   float* D;               // [P,9] d rgb_c / d dir_axis (before the clamp), or null: not wanted (no backward follows)
-  double* abc;            // [P,3] k_pre_geom: the dilated 2D covariance of the double chain, for K9 (or null: no backward)
+  double* abc;            // [P,3] k_pre_geom<., NDL>: needle marks for K9 (first word: the needle's 2D covariance a, or NaN), or null
   uint32_t* dkey;         // float bits of the view depth; 0xFFFFFFFF for a Gaussian that emits no pair
   uint32_t* tcnt;         // tiles of the (tightened) rect
   const uint32_t* offg;   // colour kernel with tcnt == null (re-render of a kept context): a Gaussian emits pairs iff
@@ -1670,12 +1676,12 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
       // splat, and every splat without the flag, keeps the published float32 conic.  Radius, rect and culls above are the
       // float32 chain's either way.  (A template parameter: the double chain costs the kernel 20 registers.)
       double ca = (double)s.ca, cb = (double)s.cb, cc = (double)s.cc;
-      if (NDL && is_needle(s.ca, s.cb, s.cc)) {
+      const bool ndl = NDL && is_needle(s.ca, s.cb, s.cc);
+      if (ndl) {
         cov2d_accurate(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, ca, cb, cc);
-        const double dinv = 1.0 / (ca * cc - cb * cb);     // >= 0.09 in exact arithmetic: a PSD matrix + 0.3 I
-        s.A = (float)(cc * dinv); s.B = (float)(-cb * dinv); s.C = (float)(ca * dinv);
+        needle_conic_to_float(ca, cb, cc, s.A, s.B, s.C);
       }
-      if (a.abc) { a.abc[3 * (size_t)g] = ca; a.abc[3 * (size_t)g + 1] = cb; a.abc[3 * (size_t)g + 2] = cc; }   // for K9
+      if (NDL && a.abc) a.abc[3 * (size_t)g] = ndl ? ca : __longlong_as_double(0x7FF8000000000000ll);   // K9's needle mark
       const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (a.cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, op, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
       s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
@@ -1799,7 +1805,10 @@ constexpr int HAND_W = 7;          // hand-over: unit direction (3) + clamped dL
 
 // ACC: the outputs are added to instead of overwritten (PreBwdArgs::accumulate) -- a template parameter so that the
 // overwriting kernel contains no loads of its outputs at all.
-template <bool RAW, bool GEOM, bool ACC = false>
+// NDL (GSR_FLAG_NEEDLE_DOUBLE): the Gaussians k_pre_geom marked as needles (a number, not NaN, in their first abc word) run
+// their whole chain rule in double (gsr_math.h needle_bwd_d); a separate instantiation, because the double chain's
+// registers cost the kernel a wave per SIMD.
+template <bool RAW, bool GEOM, bool ACC = false, bool NDL = false>
 __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   __shared__ float4 srow[PRE_WAVES * ROW_CHUNK * PART_F4];
   __shared__ float shand[PRE_WAVES * 64 * HAND_W];
@@ -1977,11 +1986,29 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
           cov3d_from_scale_rot(sc, a.va.mod, q, c6);
         }
         float dc6[6];
-        // (the 2D covariance the forward's conic was inverted from: the double chain, like k_pre_geom)
-        // (GSR_FLAG_NEEDLE_DOUBLE: k_pre_geom left it beside the records; without the flag the float32 chain's is formed here)
-        double abc0 = 0.0, abc1 = 0.0, abc2 = 0.0;
-        if (a.abc) { abc0 = a.abc[3 * (size_t)g]; abc1 = a.abc[3 * (size_t)g + 1]; abc2 = a.abc[3 * (size_t)g + 2]; }
-        project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6, a.abc != nullptr, abc0, abc1, abc2);
+        float ds[3], dq[4];
+        bool needle = false;
+        if (NDL && a.abc) { const double m0 = a.abc[3 * (size_t)g]; needle = m0 == m0; }      // NaN: an ordinary splat
+        if (NDL && needle) {
+          // a needle: the whole chain rule in double on the float32 inputs (like its forward), activations included
+          double dpd[3] = {(double)dp[0], (double)dp[1], (double)dp[2]}, dsd[3], dqd[4], dS6[6];
+          const double dnx = -((double)A * mx + (double)B * my) * (0.5 * (double)v.W);
+          const double dny = -((double)B * mx + (double)C * my) * (0.5 * (double)v.H);
+          needle_bwd_d(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, dA, dB, dC, dnx, dny, dpd, dsd, dqd, dS6);
+          dp[0] = (float)dpd[0]; dp[1] = (float)dpd[1]; dp[2] = (float)dpd[2];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) dc6[i] = (float)dS6[i];
+          if (RAW) {
+            dsd[0] *= (double)sc[0]; dsd[1] *= (double)sc[1]; dsd[2] *= (double)sc[2];     // d exp(x) = exp(x)
+            const double dot = (double)q[0] * dqd[0] + (double)q[1] * dqd[1] + (double)q[2] * dqd[2] + (double)q[3] * dqd[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dqd[i] = (dqd[i] - (double)q[i] * dot) * (double)inv_qn;
+          }
+          ds[0] = (float)dsd[0]; ds[1] = (float)dsd[1]; ds[2] = (float)dsd[2];
+          dq[0] = (float)dqd[0]; dq[1] = (float)dqd[1]; dq[2] = (float)dqd[2]; dq[3] = (float)dqd[3];
+        } else {
+          project_splat_bwd(v, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+        }
         if (a.dmeans3D) {
           put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]);
           ssq[SUMSQ_XYZ] = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
@@ -1989,11 +2016,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         if (a.cov3d) {
           if (a.dcov3d) for (int i = 0; i < 6; ++i) put(&a.dcov3d[6 * g + i], dc6[i]);
         } else if (a.dscales || a.drots) {
-          float ds[3], dq[4];
-          cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
-          if (RAW) {
-            ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2];     // d exp(x) = exp(x)
-            act_normalize4_bwd(q, inv_qn, dq, dq);
+          if (!(NDL && needle)) {
+            cov3d_bwd(sc, a.va.mod, q, dc6, ds, dq);
+            if (RAW) {
+              ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2];     // d exp(x) = exp(x)
+              act_normalize4_bwd(q, inv_qn, dq, dq);
+            }
           }
           if (a.dscales) {
             put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]);

@@ -255,6 +255,49 @@ GSR_HD void cov2d_accurate(const View& v, const float p[3], const float* sc, flo
   c = M[3] * w0 + M[4] * w1 + M[5] * w2 + (double)DILATE;
 }
 
+// A needle's conic, double -> the three float32 numbers the records carry.  The small eigenvalue k_b of the conic (1 / the
+// long axis's variance; 2e-3 where the entries are ~1 for a 440:1 needle) is what a float32 triple cannot hold: independent
+// rounding of the entries leaves up to 6e-8 in u^T K u along the long axis u -- 3e-5 of k_b -- and a needle's rotation
+// gradient amplifies that by ~250 (0.6 % measured, against 0.04 % for the float32 chain's error, which is a COMMON FACTOR
+// on the conic (the determinant) and harmless in that direction: EXPERIMENTS.md round 5, tests/diag_needle_sensitivity.py).
+// So among the float32 neighbours (+-2 ulps per entry) of the rounded triple, take the one whose quadratic form along u is
+// closest to the double conic's: 125 candidates, residual ~1/9 of plain rounding's.  (a, b, c): the dilated 2D covariance.
+GSR_HD float gsr_step_ulps(float x, int n) {
+  if (x == 0.0f || n == 0) return x;
+  union { float f; int32_t i; } w;
+  w.f = x;
+  w.i += n;               // sign-magnitude: +n moves away from zero; the search is symmetric, so direction does not matter
+  return w.f;
+}
+GSR_HD void needle_conic_to_float(double a, double b, double c, float& A, float& B, float& C) {
+  const double dinv = 1.0 / (a * c - b * b);     // det >= 0.09 in exact arithmetic: a PSD matrix + 0.3 I
+  const double Ad = c * dinv, Bd = -b * dinv, Cd = a * dinv;
+  // u: eigenvector of the covariance's LARGE eigenvalue
+  const double hd = 0.5 * (a - c), lam = 0.5 * (a + c) + sqrt(hd * hd + b * b);
+  double ux, uy;
+  if (a >= c) { ux = lam - c; uy = b; } else { ux = b; uy = lam - a; }
+  const double un = 1.0 / (ux * ux + uy * uy);
+  const double wA = ux * ux * un, wB = 2.0 * ux * uy * un, wC = uy * uy * un;
+  const float A0 = (float)Ad, B0 = (float)Bd, C0 = (float)Cd;
+  double eA[5], eB[5], eC[5];
+  for (int i = 0; i < 5; ++i) {
+    eA[i] = wA * ((double)gsr_step_ulps(A0, i - 2) - Ad);
+    eB[i] = wB * ((double)gsr_step_ulps(B0, i - 2) - Bd);
+    eC[i] = wC * ((double)gsr_step_ulps(C0, i - 2) - Cd);
+  }
+  double best = fabs(eA[2] + eB[2] + eC[2]);
+  int bi = 2, bj = 2, bk = 2;
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) {
+      const double eab = eA[i] + eB[j];
+      for (int k = 0; k < 5; ++k) {
+        const double e = fabs(eab + eC[k]);
+        if (e < best) { best = e; bi = i; bj = j; bk = k; }
+      }
+    }
+  A = gsr_step_ulps(A0, bi - 2); B = gsr_step_ulps(B0, bj - 2); C = gsr_step_ulps(C0, bk - 2);
+}
+
 GSR_HD void conic_accurate(const View& v, const float p[3], const float* sc, float mod, const float* q, const float* c6pre, Splat& s) {
   double a, b, c;
   cov2d_accurate(v, p, sc, mod, q, c6pre, a, b, c);
@@ -360,11 +403,8 @@ GSR_HD void sh_to_rgb_bwd(int deg, int Kstore, const float* sh, const float p[3]
 // Inputs: true partials dL/dA, dL/dB, dL/dC of the conic (B counted once), dL/d(ndc.xy) (= the
 // extension's dL_dmean2D), and the forward inputs.  Outputs: dL/dmean (added into dp), dL/dcov3D
 // packed (dc6), to be pushed further to scale/rotation by cov3d_bwd when those were the inputs.
-// have_abc: (abc0, abc1, abc2) is the dilated 2D covariance from cov2d_accurate (what the forward's conic was inverted from
-// under GSR_FLAG_NEEDLE_DOUBLE); otherwise the float32 chain's is formed here
 GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6], double dA, double dB, double dC,
-                              float dndcx, float dndcy, float dp[3], float dc6[6], bool have_abc = false, double abc0 = 0.0,
-                              double abc1 = 0.0, double abc2 = 0.0) {
+                              float dndcx, float dndcy, float dp[3], float dc6[6]) {
   float t[3];
   for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
   ProjLin pl;
@@ -375,7 +415,7 @@ GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6]
   // dL/dconic ~ K (u_x^2, 2 u_x u_y, u_y^2) from the pixels along its axis: every term is ~ l1^2 K, their sum ~ l1 l2 K),
   // so they are formed in double: float32 products lose l1 / l2 (1e4 for a 100:1 needle) times 6e-8 here, on top of
   // what the summed dL/dconic already carries.  A few dozen double operations per Gaussian, in a memory-bound kernel.
-  const double ad = have_abc ? abc0 : (double)a, bd = have_abc ? abc1 : (double)b, cd = have_abc ? abc2 : (double)c;
+  const double ad = (double)a, bd = (double)b, cd = (double)c;
   const double det = ad * cd - bd * bd;
   const double d2 = 1.0 / (det * det);   // det >= DILATE^2 - rounding > 0 for a PSD covariance
   const float da = (float)((-cd * cd * dA + bd * cd * dB - bd * bd * dC) * d2);
@@ -443,6 +483,107 @@ GSR_HD void cov3d_bwd(const float s_in[3], float mod, const float q[4], const fl
   dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
   dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
   dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GSR_FLAG_NEEDLE_DOUBLE, backward: project_splat_bwd + cov3d_bwd for ONE needle in double, end to end.  Differentiating
+// the double chain's conic through float32 M / Sigma / quaternion products is worse than either consistent chain (a 440:1
+// needle's rotation gradient 0.6 % off where the all-float32 backward is 0.05 % off: tests/diag_aniso_elem.py, seed 41),
+// so a needle's whole per-Gaussian chain rule runs in double on the float32 inputs, like its forward (cov2d_accurate).
+// sc / q: the scales and the quaternion AS USED by the forward (activated); c6pre: the precomputed covariance instead.
+// dp: dL/dmean, added to; ds / dq: dL/d(sc), dL/d(q as used); dS6: dL/dSigma (packed, off-diagonals doubled) for c6pre.
+// ---------------------------------------------------------------------------------------------
+GSR_HD void needle_bwd_d(const View& v, const float p[3], const float* sc, float mod, const float* q, const float* c6pre,
+                         double dA, double dB, double dC, double dndcx, double dndcy, double dp[3], double ds[3], double dq[4],
+                         double dS6[6]) {
+  double S[6], R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, s3[3] = {0, 0, 0};
+  if (c6pre) {
+    for (int i = 0; i < 6; ++i) S[i] = (double)c6pre[i];
+  } else {
+    const double r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - r * z);       R[2] = 2.0 * (x * z + r * y);
+    R[3] = 2.0 * (x * y + r * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - r * x);
+    R[6] = 2.0 * (x * z - r * y);       R[7] = 2.0 * (y * z + r * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+    for (int k = 0; k < 3; ++k) s3[k] = (double)mod * sc[k];
+    double L[9];
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) L[i * 3 + k] = R[i * 3 + k] * s3[k];
+    S[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2]; S[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+    S[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8]; S[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+    S[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8]; S[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+  }
+  double t[3];
+  for (int j = 0; j < 3; ++j)
+    t[j] = (double)p[0] * v.V[j] + (double)p[1] * v.V[4 + j] + (double)p[2] * v.V[8 + j] + (double)v.V[12 + j];
+  const double limx = (double)FOV_CLAMP * v.tanfovx, limy = (double)FOV_CLAMP * v.tanfovy;
+  const double tz = t[2], txtz = t[0] / tz, tytz = t[1] / tz;
+  const bool clx = (txtz < -limx) || (txtz > limx), cly = (tytz < -limy) || (tytz > limy);
+  const double tx = (txtz < -limx ? -limx : (txtz > limx ? limx : txtz)) * tz;
+  const double ty = (tytz < -limy ? -limy : (tytz > limy ? limy : tytz)) * tz;
+  const double fx = (double)v.W / (2.0 * (double)v.tanfovx), fy = (double)v.H / (2.0 * (double)v.tanfovy);
+  const double J00 = fx / tz, J02 = -(fx * tx) / (tz * tz), J11 = fy / tz, J12 = -(fy * ty) / (tz * tz);
+  double M[6];
+  for (int i = 0; i < 3; ++i) {
+    M[i] = J00 * v.V[i * 4 + 0] + J02 * v.V[i * 4 + 2];
+    M[3 + i] = J11 * v.V[i * 4 + 1] + J12 * v.V[i * 4 + 2];
+  }
+  const double Sf[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
+  double SM0[3], SM1[3];                                       // Sigma M0^T, Sigma M1^T
+  for (int i = 0; i < 3; ++i) {
+    SM0[i] = Sf[i * 3] * M[0] + Sf[i * 3 + 1] * M[1] + Sf[i * 3 + 2] * M[2];
+    SM1[i] = Sf[i * 3] * M[3] + Sf[i * 3 + 1] * M[4] + Sf[i * 3 + 2] * M[5];
+  }
+  const double a = M[0] * SM0[0] + M[1] * SM0[1] + M[2] * SM0[2] + (double)DILATE;
+  const double b = M[3] * SM0[0] + M[4] * SM0[1] + M[5] * SM0[2];
+  const double c = M[3] * SM1[0] + M[4] * SM1[1] + M[5] * SM1[2] + (double)DILATE;
+  const double det = a * c - b * b, d2 = 1.0 / (det * det);
+  const double da = (-c * c * dA + b * c * dB - b * b * dC) * d2;
+  const double db = (2.0 * b * c * dA - (det + 2.0 * b * b) * dB + 2.0 * a * b * dC) * d2;
+  const double dc = (-b * b * dA + a * b * dB - a * a * dC) * d2;
+  const double hb = 0.5 * db;
+  double DM[6];
+  for (int i = 0; i < 3; ++i) { DM[i] = da * M[i] + hb * M[3 + i]; DM[3 + i] = hb * M[i] + dc * M[3 + i]; }
+  double G[9];                                                 // dL/dSigma3 = M^T D M (full symmetric matrix)
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) G[i * 3 + j] = M[i] * DM[j] + M[3 + i] * DM[3 + j];
+  dS6[0] = G[0]; dS6[1] = 2.0 * G[1]; dS6[2] = 2.0 * G[2]; dS6[3] = G[4]; dS6[4] = 2.0 * G[5]; dS6[5] = G[8];
+  double dM[6];                                                // dL/dM = 2 D M Sigma3
+  for (int r = 0; r < 2; ++r)
+    for (int j = 0; j < 3; ++j)
+      dM[r * 3 + j] = 2.0 * (DM[r * 3 + 0] * Sf[0 * 3 + j] + DM[r * 3 + 1] * Sf[1 * 3 + j] + DM[r * 3 + 2] * Sf[2 * 3 + j]);
+  const double dJ00 = dM[0] * v.V[0] + dM[1] * v.V[4] + dM[2] * v.V[8];
+  const double dJ02 = dM[0] * v.V[2] + dM[1] * v.V[6] + dM[2] * v.V[10];
+  const double dJ11 = dM[3] * v.V[1] + dM[4] * v.V[5] + dM[5] * v.V[9];
+  const double dJ12 = dM[3] * v.V[2] + dM[4] * v.V[6] + dM[5] * v.V[10];
+  const double itz = 1.0 / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+  const double dtx = clx ? 0.0 : -fx * itz2 * dJ02;            // clamped axes: t.x (t.y) is treated as a constant
+  const double dty = cly ? 0.0 : -fy * itz2 * dJ12;
+  const double dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.0 * fx * tx * itz3 * dJ02 + 2.0 * fy * ty * itz3 * dJ12;
+  for (int i = 0; i < 3; ++i) dp[i] += v.V[i * 4 + 0] * dtx + v.V[i * 4 + 1] * dty + v.V[i * 4 + 2] * dtz;
+  double h[4];
+  for (int j = 0; j < 4; ++j)
+    h[j] = (double)p[0] * v.PV[j] + (double)p[1] * v.PV[4 + j] + (double)p[2] * v.PV[8 + j] + (double)v.PV[12 + j];
+  const double w = 1.0 / (h[3] + (double)1e-7f);
+  const double dh0 = dndcx * w, dh1 = dndcy * w, dh3 = -(dndcx * h[0] + dndcy * h[1]) * w * w;
+  for (int i = 0; i < 3; ++i) dp[i] += v.PV[i * 4 + 0] * dh0 + v.PV[i * 4 + 1] * dh1 + v.PV[i * 4 + 3] * dh3;
+  ds[0] = ds[1] = ds[2] = 0.0; dq[0] = dq[1] = dq[2] = dq[3] = 0.0;
+  if (c6pre) return;
+  // Sigma = L L^T, L = R diag(s): dL/dL = 2 G L; ds_k = sum_i dL[i][k] R[i][k] * mod; dR[i][k] = dL[i][k] s_k
+  double dR[9];
+  for (int k = 0; k < 3; ++k) {
+    double acc = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      const double dL = 2.0 * (G[i * 3 + 0] * R[0 * 3 + k] + G[i * 3 + 1] * R[1 * 3 + k] + G[i * 3 + 2] * R[2 * 3 + k]) * s3[k];
+      acc += dL * R[i * 3 + k];
+      dR[i * 3 + k] = dL * s3[k];
+    }
+    ds[k] = acc * (double)mod;
+  }
+  const double r = q[0], x = q[1], y = q[2], z = q[3];
+  dq[0] = 2.0 * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+  dq[1] = 2.0 * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0 * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0 * x * dR[8]);
+  dq[2] = 2.0 * (-2.0 * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0 * y * dR[8]);
+  dq[3] = 2.0 * (-2.0 * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0 * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
 }
 
 // ---------------------------------------------------------------------------------------------

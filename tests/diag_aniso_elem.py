@@ -52,3 +52,16 @@ for idx in torch.nonzero(off).tolist():
         print(f"    [{name}] hip {gv[group].detach().double().cpu()[j].item():+.6e}")
     full = {k: (grads[k][i].detach().cpu().flatten()[:4].tolist(), rg[k][i].flatten()[:4].tolist()) for k in ("means3D", "means2D", "opacities")}
     print("    its other gradients (hip, f64):", full)
+
+# DIAG_GAUSSIAN=i: every element of Gaussian i's gradients without and with GSR_FLAG_NEEDLE_DOUBLE, next to both oracles
+if os.environ.get("DIAG_GAUSSIAN"):
+    i = int(os.environ["DIAG_GAUSSIAN"])
+    with D.extra_flags(D.FLAG_NEEDLE_DOUBLE):
+        g_on = T.run_hip(inp, cam, bg, gc, None, kw["sh_degree"], kw["scale_modifier"])[3]
+    for k in ("means3D", "scales", "rotations", "opacities", "means2D"):
+        f64, f32 = rg[k][i].double().flatten(), rg32[k][i].double().flatten()
+        off_, on_ = grads[k][i].detach().double().cpu().flatten(), g_on[k][i].detach().double().cpu().flatten()
+        for j in range(f64.numel()):
+            den = max(abs(f64[j].item()), 1e-30)
+            print(f"  G{i} {k}[{j}]: f64 {f64[j].item():+.6e} | rel err: f32 oracle {abs(f32[j] - f64[j]).item() / den:.2e}, "
+                  f"hip {abs(off_[j] - f64[j]).item() / den:.2e}, hip with the flag {abs(on_[j] - f64[j]).item() / den:.2e}")

@@ -88,4 +88,33 @@ void hm_tighten_rect(int n, const float* geo, int gridx, int gridy, const int* r
   }
 }
 
+// GSR_FLAG_NEEDLE_DOUBLE, one Gaussian (scales + quaternion as used): conic_d [3] = the double chain's conic,
+// conic_f [3] = needle_conic_to_float's triple, needle [1], and for dL/dconic = (dA, dB, dC): out_f [10] = dp, ds, dq of the
+// float32 chain rule (project_splat_bwd + cov3d_bwd), out_d [10] = needle_bwd_d's.
+void hm_needle(int H, int W, float tanfovx, float tanfovy, float mod, const float* vm, const float* pm, const float* campos,
+               const float* mean, const float* scale, const float* rot, double dA, double dB, double dC, double* conic_d,
+               float* conic_f, int* needle, float* out_f, double* out_d) {
+  View v;
+  make_view(v, vm, pm, campos, H, W, tanfovx, tanfovy, mod, 0);
+  float c6[6];
+  cov3d_from_scale_rot(scale, mod, rot, c6);
+  Splat s;
+  project_splat(v, mean, c6, s);
+  needle[0] = is_needle(s.ca, s.cb, s.cc) ? 1 : 0;
+  double a, b, c;
+  cov2d_accurate(v, mean, scale, mod, rot, nullptr, a, b, c);
+  const double dinv = 1.0 / (a * c - b * b);
+  conic_d[0] = c * dinv; conic_d[1] = -b * dinv; conic_d[2] = a * dinv;
+  needle_conic_to_float(a, b, c, conic_f[0], conic_f[1], conic_f[2]);
+  float dp[3] = {0.f, 0.f, 0.f}, dc6[6], ds[3], dq[4];
+  project_splat_bwd(v, mean, c6, dA, dB, dC, 0.f, 0.f, dp, dc6);
+  cov3d_bwd(scale, mod, rot, dc6, ds, dq);
+  for (int i = 0; i < 3; ++i) { out_f[i] = dp[i]; out_f[3 + i] = ds[i]; }
+  for (int i = 0; i < 4; ++i) out_f[6 + i] = dq[i];
+  double dpd[3] = {0.0, 0.0, 0.0}, dsd[3], dqd[4], dS6[6];
+  needle_bwd_d(v, mean, scale, mod, rot, nullptr, dA, dB, dC, 0.0, 0.0, dpd, dsd, dqd, dS6);
+  for (int i = 0; i < 3; ++i) { out_d[i] = dpd[i]; out_d[3 + i] = dsd[i]; }
+  for (int i = 0; i < 4; ++i) out_d[6 + i] = dqd[i];
+}
+
 }  // extern "C"

@@ -288,3 +288,73 @@ def test_tightened_rect_keeps_every_contributing_tile(lib):
                 assert (x1 - x0) * (y1 - y0) == 0
             shrunk += int((x1 - x0) * (y1 - y0) < G * G)
     assert shrunk > 0.5 * n
+
+
+def _needle_case(seed):
+    """One strongly elongated Gaussian (0.024 x 0.021 x 1.56, the 440:1 needle of tests/diag_aniso_elem.py seed 41) under a
+    random rotation, a realistic dL/dconic (signed pixel weights along its footprint) and the float64 truth by autograd."""
+    g = torch.Generator().manual_seed(seed)
+    cam = look_at_camera((0.2, -0.3, -9.0), (0.0, 0.0, 0.0), fovx=0.9, fovy=0.9, width=256, height=256)
+    st = settings_for(cam, torch.zeros(3), scale_modifier=1.0)
+    # (the kernels receive tan(fov/2) as float32: the float64 truth starts from the same numbers)
+    st = st._replace(tanfovx=float(np.float32(st.tanfovx)), tanfovy=float(np.float32(st.tanfovy)))
+    mean = (torch.rand(1, 3, generator=g) - 0.5).float()
+    scale = torch.tensor([[0.0239, 0.0207, 1.5583]])
+    rot = torch.nn.functional.normalize(torch.randn(1, 4, generator=g), dim=1).float()
+    leaf = [t.double().clone().requires_grad_(True) for t in (mean, scale, rot)]
+    K = O._project(leaf[0], leaf[1], leaf[2], None, st)["conic"][0]
+    Kd = K.detach()
+    ys, xs = torch.meshgrid(torch.arange(-70, 71, dtype=torch.float64), torch.arange(-70, 71, dtype=torch.float64), indexing="ij")
+    dx, dy = xs + 0.3, ys - 0.2
+    power = -0.5 * (Kd[0] * dx * dx + Kd[2] * dy * dy) - Kd[1] * dx * dy
+    w = torch.where(power > -6.0, (torch.rand(power.shape, generator=g, dtype=torch.float64) * 2 - 1) * power.exp(), torch.zeros_like(power))
+    dK = torch.stack([(w * -0.5 * dx * dx).sum(), (w * -dx * dy).sum(), (w * -0.5 * dy * dy).sum()])
+    (K * dK).sum().backward()
+    truth = torch.cat([leaf[0].grad[0], leaf[1].grad[0], leaf[2].grad[0]])
+    return st, cam, mean, scale, rot, Kd, dK, truth
+
+
+def _hm_needle(lib, st, cam, mean, scale, rot, dK):
+    vm, pm, cp = f32(st.viewmatrix), f32(st.projmatrix), f32(st.campos)
+    kd, kf, nd = np.zeros(3, np.float64), np.zeros(3, np.float32), np.zeros(1, np.int32)
+    of, od = np.zeros(10, np.float32), np.zeros(10, np.float64)
+    lib.hm_needle(cam.image_height, cam.image_width, cf(st.tanfovx), cf(st.tanfovy), cf(1.0), ptr(vm), ptr(pm), ptr(cp),
+                  ptr(f32(mean)), ptr(f32(scale)), ptr(f32(rot)), ctypes.c_double(dK[0]), ctypes.c_double(dK[1]),
+                  ctypes.c_double(dK[2]), ptr(kd), ptr(kf), ptr(nd), ptr(of), ptr(od))
+    return kd, kf, int(nd[0]), of, od
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_needle_chain_rule_in_double(lib, seed):
+    """GSR_FLAG_NEEDLE_DOUBLE: needle_bwd_d (gsr_math.h) is the float64 chain rule of the conic -- to 1e-9 of autograd through
+    oracle-R's projection in float64 -- and the float32 chain rule it replaces for needles is good to a few 1e-5."""
+    st, cam, mean, scale, rot, Kd, dK, truth = _needle_case(seed)
+    kd, kf, needle, of, od = _hm_needle(lib, st, cam, mean, scale, rot, dK.tolist())
+    assert needle == 1
+    # (the dilation is the published float32 constant 0.3f = 0.3 + 1.2e-8 in the kernels' double chain, 0.3 in oracle-R's)
+    np.testing.assert_allclose(kd, Kd.numpy(), rtol=1e-7)
+    t = truth.numpy()
+    for sl in (slice(0, 3), slice(3, 6), slice(6, 10)):             # dL/dmean, dL/dscale, dL/dq
+        scale_ = np.abs(t[sl]).max()
+        ed, ef = np.abs(od[sl] - t[sl]).max() / scale_, np.abs(of[sl].astype(np.float64) - t[sl]).max() / scale_
+        print(f"seed {seed} {sl}: double chain {ed:.2e}, float32 chain {ef:.2e}")
+        assert ed <= 2e-7 and ef <= 3e-4
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_needle_conic_keeps_the_long_axis_in_float32(lib, seed):
+    """needle_conic_to_float: each float32 entry within 2 ulps of the double conic's, and the quadratic form along the long axis
+    (the conic's small eigenvalue -- what a needle's gradients amplify) no further from the double conic's than plain rounding
+    leaves it, and within 1e-8 (plain rounding: up to 6e-8)."""
+    st, cam, mean, scale, rot, Kd, dK, truth = _needle_case(seed)
+    kd, kf, needle, of, od = _hm_needle(lib, st, cam, mean, scale, rot, dK.tolist())
+    w, V = np.linalg.eigh(np.array([[kd[0], kd[1]], [kd[1], kd[2]]]))
+    u = V[:, 0]                                                      # small conic eigenvalue = the long axis
+
+    def along(k):
+        e = np.asarray(k, np.float64) - kd
+        return abs(u[0] ** 2 * e[0] + 2 * u[0] * u[1] * e[1] + u[1] ** 2 * e[2])
+    plain = kd.astype(np.float32)
+    assert np.all(np.abs(kf.astype(np.float64) - kd) <= 2.5 * np.spacing(np.abs(plain)).astype(np.float64))
+    assert along(kf) <= along(plain) + 1e-18
+    assert along(kf) <= 1e-8, (along(kf), along(plain), w[0])
