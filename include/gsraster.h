@@ -76,8 +76,8 @@ enum {
  * unchanged).  This flag keeps everything on the caller's stream. */
 #define GSR_FLAG_NO_SIDE_STREAM (1u << 19)
 /* GSR_FLAG_NEEDLE_DOUBLE: splats whose dilated 2D covariance has eigenvalues more than 256 apart ("needles") get their
- * conic -- and the backward the 2D covariance it is differentiated through -- from the published chain evaluated in double on
- * the same float32 inputs.  The float32 chain leaves 1e-7 x that ratio in every conic entry, which a needle's exponent
+ * conic -- and, in the backward, their whole per-Gaussian chain rule -- from the published chain evaluated in double on
+ * the same float32 inputs (the conic is rounded to its float32 record so that the form along the long axis is preserved).  The float32 chain leaves 1e-7 x that ratio in every conic entry, which a needle's exponent
  * (terms of radius^2 cancelling to O(1)) and gradients (cancelling once more) amplify: a 1500:1 needle's dL/dmean2D is 2.3 %
  * off in float32 -- in the reference's kernels as in any float32 statement of the formula.  Integer decisions (radius, tile
  * rect, culls) and every ordinary splat are unchanged.  Opt-in: it costs the geometry kernel 20 registers and a view
