@@ -117,4 +117,11 @@ void hm_needle(int H, int W, float tanfovx, float tanfovy, float mod, const floa
   for (int i = 0; i < 4; ++i) out_d[6 + i] = dqd[i];
 }
 
+// needle_conic_to_float on a given dilated 2D covariance (a, b, c): out [3] = the float32 triple, outd [3] = the double conic
+void hm_conic_to_float(double a, double b, double c, float* out, double* outd) {
+  needle_conic_to_float(a, b, c, out[0], out[1], out[2]);
+  const double dinv = 1.0 / (a * c - b * b);
+  outd[0] = c * dinv; outd[1] = -b * dinv; outd[2] = a * dinv;
+}
+
 }  // extern "C"

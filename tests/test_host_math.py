@@ -358,3 +358,25 @@ def test_needle_conic_keeps_the_long_axis_in_float32(lib, seed):
     assert np.all(np.abs(kf.astype(np.float64) - kd) <= 2.5 * np.spacing(np.abs(plain)).astype(np.float64))
     assert along(kf) <= along(plain) + 1e-18
     assert along(kf) <= 1e-8, (along(kf), along(plain), w[0])
+
+
+@pytest.mark.parametrize("a,b,c", [(4000.3, 0.0, 0.31), (0.31, 0.0, 4000.3), (2000.0, 1999.0, 2000.0), (2000.0, -1999.0, 2000.0),
+                                   (900.7, 300.1, 100.4), (100.4, -300.1, 900.7), (0.3001, 1e-9, 1500.0)])
+def test_needle_conic_rounding_on_axis_aligned_diagonal_and_mirrored_covariances(lib, a, b, c):
+    """needle_conic_to_float on hand-picked covariances: the long axis along x, along y (b = 0: the off-diagonal entry is not
+    stepped), along either diagonal, mirrored, and with a vanishing off-diagonal -- entries within 2 ulps, finite, and the
+    form along the long axis no worse than plain rounding's."""
+    kf, kd = np.zeros(3, np.float32), np.zeros(3, np.float64)
+    lib.hm_conic_to_float(ctypes.c_double(a), ctypes.c_double(b), ctypes.c_double(c), ptr(kf), ptr(kd))
+    assert np.all(np.isfinite(kf))
+    plain = kd.astype(np.float32)
+    assert np.all(np.abs(kf.astype(np.float64) - kd) <= 2.5 * np.spacing(np.abs(plain)).astype(np.float64) + 1e-300)
+    if b == 0.0:
+        assert kf[1] == 0.0
+    w, V = np.linalg.eigh(np.array([[kd[0], kd[1]], [kd[1], kd[2]]]))
+    u = V[:, 0]
+
+    def along(k):
+        e = np.asarray(k, np.float64) - kd
+        return abs(u[0] ** 2 * e[0] + 2 * u[0] * u[1] * e[1] + u[1] ** 2 * e[2])
+    assert along(kf) <= along(plain) * (1 + 1e-9) + 1e-22
