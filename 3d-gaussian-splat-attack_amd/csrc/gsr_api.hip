@@ -440,6 +440,12 @@ struct GsrCtx {
   GsrSettings st{};
   int P = 0, K = 0;
   int gridx = 0, gridy = 0, ntiles = 0;
+  // A batch of views rendered as one virtual scene (gsr_forward_raw_batch; gsr_kernels.hip.h, ViewDev): B views, view v owns
+  // the virtual Gaussians [v * Ppad, v * Ppad + P) and the tiles [v * tpv, (v + 1) * tpv); Pv = B * Ppad, ntiles = B * tpv.
+  // One view: B = 1, Ppad = Pv = P, tpv = ntiles, vpack = null.
+  int B = 1, Ppad = 0, Pv = 0, tpv = 0;
+  std::vector<GsrSettings> views;   // B > 1: the views' settings (device pointers owned by the caller); st = views[0]
+  ViewDev* vpack = nullptr;
   // Pairs: `nbound` is what the host sized every pair-proportional buffer and grid for -- the exact count when the
   // forward waited for it, the capacity guess of an asynchronous-count forward otherwise; the device-side count lives
   // in dv[DV_N] and reaches the host through `slot` (n_known: already read).
@@ -493,7 +499,7 @@ static int ctx_resolve_count(GsrCtx* c) {
   c->n64 = (unsigned long long)c->slot.host[HS_N64] | ((unsigned long long)c->slot.host[HS_N64 + 1] << 32);
   c->overflow = c->slot.host[HS_OVF] != 0u;
   c->n_known = true;
-  const CapKey key{c->dev, c->P, c->st.image_height, c->st.image_width};
+  const CapKey key{c->dev, c->Pv, c->st.image_height, c->st.image_width};
   cap_store(key, c->n64, c->overflow);
   slot_put(c->slot);
   return GSR_OK;
@@ -531,7 +537,7 @@ void gsr_ctx_free(GsrCtx* c) {
       (void)ctx_resolve_count(c);
     } else {
       std::lock_guard<std::mutex> lk(g_pending_mu);
-      g_pending.push_back(PendingSlot{c->slot, CapKey{c->dev, c->P, c->st.image_height, c->st.image_width}});
+      g_pending.push_back(PendingSlot{c->slot, CapKey{c->dev, c->Pv, c->st.image_height, c->st.image_width}});
       c->slot = CountSlot{};
     }
   }
@@ -576,6 +582,7 @@ static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hi
   ra.wave_clock = g_wave_clock_fwd.load();
   ra.bnd = c->bnd; ra.segoff = c->bnd ? c->segoff : nullptr; ra.seg_shift = c->bnd ? c->seg_shift : 0u;
   ra.out_color = out_color; ra.out_objects = out_objects; ra.final_T = c->final_T; ra.n_contrib = c->n_contrib;
+  ra.tpv = c->tpv; ra.vpack = c->vpack;
   const dim3 blkT(64);
   // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
   // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
@@ -614,7 +621,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                         const float* sh_dc, const float* sh_objs, const float* colors_precomp, const float* opacities,
                         const float* scales, const float* rotations, const float* cov3D_precomp, float* out_color,
                         float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered, void* stream,
-                        bool raw, const SegB* segb = nullptr, bool fwd_only = false) {
+                        bool raw, const SegB* segb = nullptr, bool fwd_only = false, int nviews = 1) {
+  // nviews > 1 (gsr_forward_raw_batch): `s` points at nviews settings; the batch is one virtual scene (GsrCtx::B)
   if (ctx_out) *ctx_out = nullptr;
   if (!s || !out_color) return set_err(GSR_ERR_INVALID, "gsr_forward: null settings / out_color");
   if (P < 0 || s->image_height <= 0 || s->image_width <= 0)
@@ -639,14 +647,23 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const int dev = cur_dev();
   const int H = s->image_height, W = s->image_width;
   const int gridx = (W + TILE - 1) / TILE, gridy = (H + TILE - 1) / TILE;
-  const int ntiles = gridx * gridy;
+  const int tpv = gridx * gridy;                                       // tiles per view
   if (gridx > 4095 || gridy > 4095) return set_err(GSR_ERR_INVALID, "gsr_forward: image larger than 65520 px per side");
-  if ((uint32_t)P > RANK_MASK) return set_err(GSR_ERR_INVALID, "gsr_forward: more than 2^28 Gaussians");
-  const size_t HW = (size_t)H * W;
+  // a batch: B views as one virtual scene of B * Ppad Gaussians and B * tpv tiles (a batch of one is an ordinary forward)
+  const int B = (nviews > 1 && P > 0) ? nviews : 1;
+  const int Ppad = B > 1 ? (int)(((size_t)P + BATCH_PAD - 1) / BATCH_PAD * BATCH_PAD) : P;
+  if ((size_t)B * (size_t)Ppad > (size_t)RANK_MASK)
+    return set_err(GSR_ERR_INVALID, "gsr_forward: more than 2^28 Gaussians (times views of a batch)");
+  if ((size_t)B * (size_t)tpv >= (size_t)SCHED_TILE_MASK) return set_err(GSR_ERR_INVALID, "gsr_forward: more than 2^28 tiles in the batch");
+  const int Pv = B > 1 ? B * Ppad : P;                                 // virtual Gaussians
+  const int ntiles = B * tpv;                                          // virtual tiles
+  const size_t HW = (size_t)H * W * (size_t)B;                         // pixels of all views
 
   GsrCtx* c = new (std::nothrow) GsrCtx();
   if (!c) return set_err(GSR_ERR_NOMEM, "gsr_forward: host allocation failed");
   c->dev = dev; c->st = *s; c->P = P; c->K = K; c->gridx = gridx; c->gridy = gridy; c->ntiles = ntiles;
+  c->B = B; c->Ppad = Ppad; c->Pv = Pv; c->tpv = tpv;
+  if (B > 1) c->views.assign(s, s + B);
   c->means3D = means3D; c->shs = shs; c->sh_objs = sh_objs; c->colors = colors_precomp; c->opac = opacities;
   c->scales = scales; c->rots = rotations; c->cov3d = cov3D_precomp;
   c->raw = raw; c->sh_dc = sh_dc;
@@ -657,7 +674,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     c->b.objects_dc = segb->objects_dc; c->b.opacity = segb->opacity; c->b.scaling = segb->scaling; c->b.rotation = segb->rotation;
   }
 
-  const size_t Pp = (size_t)std::max(P, 1);
+  const size_t Pp = (size_t)std::max(Pv, 1);
   pending_harvest();
   // Asynchronous pair count (GSR_FLAG_ASYNC_COUNT, or GSR_ASYNC_COUNT=1 in the environment): the host does not wait
   // for the pair count; buffers and grids are sized from the count an earlier forward of the same (P, H, W) saw, with
@@ -667,7 +684,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   bool async_count = false;
   if (P > 0 && (async_env != 0 || (s->flags & GSR_FLAG_ASYNC_COUNT))) {
     unsigned long long seen = 0;
-    if (cap_lookup(CapKey{dev, P, H, W}, seen)) {
+    if (cap_lookup(CapKey{dev, Pv, H, W}, seen)) {
       cap_pairs = std::min<unsigned long long>(seen + seen / 4 + 65536ull, MAX_PAIRS - 1);
       async_count = true;
     }
@@ -684,16 +701,21 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const bool needle_double = (s->flags & GSR_FLAG_NEEDLE_DOUBLE) != 0u;
   const bool want_abc = needle_double && c->lanegroup && ctx_out != nullptr && !fwd_only;
   if (want_abc) kp.add<double>(3 * Pp);
+  if (B > 1) kp.add<ViewDev>((size_t)B);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
   // ---- scratch slab (released at the end of forward) ----------------------------------------
   const uint32_t nbP = (uint32_t)((Pp + DCHUNK - 1) / DCHUNK);             // chunks of the storage scan / depth sort
-  const uint32_t nk1 = (uint32_t)((Pp + PREG_BLOCK - 1) / PREG_BLOCK);     // workgroups of K1's geometry half
-  const uint32_t nkc = (uint32_t)((Pp + PREF_BLOCK - 1) / PREF_BLOCK);     // ... of its colour half
+  const uint32_t nk1 = (uint32_t)((Pp + PREG_BLOCK - 1) / PREG_BLOCK);     // workgroups of K1's geometry half (all views)
+  const uint32_t nk1v = B > 1 ? (uint32_t)(Ppad / PREG_BLOCK) : nk1;       // ... per view
+  const uint32_t nkc = (uint32_t)(((size_t)std::max(P, 1) + PREF_BLOCK - 1) / PREF_BLOCK);   // ... of its colour half, per view
+  const bool group_sums = nk1 > K1_GROUP_MIN;                              // K2 reads K1's sums through group sums (k_bout_group_sum)
+  const uint32_t ngroups = (nk1 + K1_GROUP - 1) / K1_GROUP;
   SlabPlan sp;
   sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp); sp.add<uint32_t>(Pp);   // dkey, k1, vtmp, v2, tcnt
   sp.add<uint32_t>((size_t)RS_BINS_DEV * nbP); sp.add<uint32_t>(RS_BINS_DEV);
   sp.add<uint4>(nk1); sp.add<uint32_t>(nbP + 2);
+  if (group_sums) sp.add<uint4>(ngroups);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
     pool_free(dev, scratch_blk);
@@ -708,6 +730,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->sched = ks.take<uint32_t>(ntiles);
   if (want_D) c->D = ks.take<float>(9 * Pp);
   if (want_abc) c->abc = ks.take<double>(3 * Pp);
+  if (B > 1) c->vpack = ks.take<ViewDev>((size_t)B);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
   uint32_t* dkey = ss.take<uint32_t>(Pp); uint32_t* k1 = ss.take<uint32_t>(Pp); uint32_t* vtmp = ss.take<uint32_t>(Pp);
@@ -715,6 +738,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   uint32_t* table = ss.take<uint32_t>((size_t)RS_BINS_DEV * nbP); uint32_t* tsums = ss.take<uint32_t>(RS_BINS_DEV);
   uint4* bout = ss.take<uint4>(nk1);
   uint32_t* psums = ss.take<uint32_t>(nbP + 2);
+  uint4* gsum = group_sums ? ss.take<uint4>(ngroups) : nullptr;
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
   void* tbl_blk = nullptr;
@@ -741,12 +765,12 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
 
   const ViewArgs va = view_args(*s);
   const dim3 blk(256);
-  const dim3 blkPre(PREG_BLOCK), gridPre(nk1), blkCol(PREF_BLOCK), gridCol(nkc);
+  const dim3 blkPre(PREG_BLOCK), gridPre(nk1v), blkCol(PREF_BLOCK), gridCol(nkc);
   const int cull = (s->flags & GSR_FLAG_NO_CULL) ? 0 : 1;
   uint32_t nbound = 0;
   // K1's colour half: on the side stream unless the caller turned that off (GSR_FLAG_NO_SIDE_STREAM / GSR_SIDE_STREAM=0).
   // GSR_FORK_LATE=1 (experiment) starts it behind the depth sort instead of behind the geometry half.
-  PreArgs color_pa{};
+  PreArgs color_pa[MAX_BATCH] = {};
   bool want_color = false;
   static const int fork_late = [] { const char* e = getenv("GSR_FORK_LATE"); return e ? atoi(e) : 0; }();
   auto launch_color = [&]() -> int {
@@ -761,8 +785,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     // beside the chain: a thin grid (GSR_COLOR_BLOCKS workgroups looping over the chunks); alone: one per chunk
     static const int col_blocks = [] { const char* e = getenv("GSR_COLOR_BLOCKS"); int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
     const dim3 gridC(side_used ? std::min<unsigned>(gridCol.x, (unsigned)col_blocks) : gridCol.x);
-    if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, color_pa);
-    else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, color_pa);
+    for (int v = 0; v < B; ++v) {
+      if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, color_pa[v]);
+      else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, color_pa[v]);
+    }
     if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
     return GSR_OK;
   };
@@ -771,31 +797,49 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       StageTimer t(GSR_STAGE_PREPROCESS, st);
       PreBlockOut bo;
       bo.bout = bout;
-      bo.ranges = P >= ntiles ? c->ranges : nullptr;      // the tile ranges are cleared by K1's first threads
-      bo.ntiles = ntiles;
+      bo.ranges = P >= tpv ? c->ranges : nullptr;         // the tile ranges are cleared by K1's first threads
+      bo.ntiles = tpv;
       if (!bo.ranges) {                                   // fewer Gaussians than tiles: spans (0xFFFFFFFF, 0) by two fills
         F_TRY("ranges", hipMemset2DAsync(c->ranges, sizeof(uint2), 0xFF, sizeof(uint32_t), ntiles, st));
         F_TRY("ranges", hipMemset2DAsync(reinterpret_cast<char*>(c->ranges) + sizeof(uint32_t), sizeof(uint2), 0, sizeof(uint32_t), ntiles, st));
       }
-      if (c->lanegroup) {
-        PreArgs pa;
-        pa.P = P; pa.va = va; pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
-        pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
-        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt; pa.offg = nullptr;
-        pa.abc = c->abc;
-        pa.Pa = segb ? P - segb->Pb : P;
-        pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
-        pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
-        pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
-        pa.cull = cull; pa.bo = bo;
-        if (needle_double) {
-          if (raw) hipLaunchKernelGGL((k_pre_geom<true, true>), gridPre, blkPre, 0, st, pa);
-          else hipLaunchKernelGGL((k_pre_geom<false, true>), gridPre, blkPre, 0, st, pa);
-        } else {
-          if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
-          else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
+      if (B > 1) {
+        // the views' constants in one device array (the compositors find a tile's background there)
+        ViewPtrs vp{};
+        for (int v = 0; v < B; ++v) {
+          vp.vm[v] = s[v].viewmatrix; vp.pm[v] = s[v].projmatrix; vp.cam[v] = s[v].campos; vp.bg[v] = s[v].bg;
+          vp.tanfovx[v] = s[v].tanfovx; vp.tanfovy[v] = s[v].tanfovy;
         }
-        color_pa = pa;
+        hipLaunchKernelGGL(k_pack_views, dim3(B), dim3(64), 0, st, vp, B, c->vpack);
+      }
+      if (c->lanegroup) {
+        // (a batch: one launch per view over that view's padded range of the virtual scene -- the same kernels, their
+        // per-Gaussian arrays offset by v * Ppad; everything behind K1 then runs once over the B * Ppad virtual Gaussians)
+        for (int v = 0; v < B; ++v) {
+          const size_t o = (size_t)v * (size_t)Ppad;
+          PreArgs pa;
+          pa.P = P; pa.Pfill = B > 1 ? Ppad : P; pa.va = view_args(s[v]);
+          pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
+          pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii + (size_t)v * (size_t)P;
+          pa.G0 = G0 + REC * o; pa.G1 = G1 + REC * o; pa.G2 = G2 + REC * o; pa.D = c->D ? c->D + 9 * o : nullptr;
+          pa.dkey = dkey + o; pa.tcnt = tcnt + o; pa.offg = nullptr;
+          pa.abc = c->abc ? c->abc + 3 * o : nullptr;
+          pa.Pa = segb ? P - segb->Pb : P;
+          pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
+          pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
+          pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
+          pa.cull = cull; pa.bo = bo;
+          pa.bo.bout = bout + (size_t)v * nk1v;
+          if (bo.ranges) pa.bo.ranges = bo.ranges + (size_t)v * (size_t)tpv;
+          if (needle_double) {
+            if (raw) hipLaunchKernelGGL((k_pre_geom<true, true>), gridPre, blkPre, 0, st, pa);
+            else hipLaunchKernelGGL((k_pre_geom<false, true>), gridPre, blkPre, 0, st, pa);
+          } else {
+            if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
+            else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
+          }
+          color_pa[v] = pa;
+        }
         want_color = !colors_precomp;
         if (want_color && !fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
       } else
@@ -812,8 +856,9 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                             "the same (P, H, W) on this device (the pair count cannot be waited for while capturing)"));
       if (!capturing && !slot_get(c->slot)) return fail(set_err(GSR_ERR_NOMEM, "gsr_forward: pinned host slot allocation failed"));
       c->fwd_stream = st;
-      hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)P, (const uint32_t*)tcnt, (const uint32_t*)dkey,
-                         (const uint4*)bout, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
+      if (group_sums) hipLaunchKernelGGL(k_bout_group_sum, dim3(ngroups), dim3(K1_GROUP), 0, st, (const uint4*)bout, nk1, gsum);
+      hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)Pv, (const uint32_t*)tcnt, (const uint32_t*)dkey,
+                         (const uint4*)bout, (const uint4*)gsum, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
       F_LAUNCH("preprocess");
     }
     {
@@ -823,11 +868,11 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       // histogram came from k_storage_scan_hist), the last pass also gathers cnt[r] = tiles touched by rank r.
       const uint32_t* nV = c->dv + DV_V;
       DigitSpec d0{c->dv, 0, 0, 0u}, d1{c->dv, 1, 0, 0u}, d2{c->dv, 2, 0, 0u};
-      radix_pass<RS_BINS_DEV>(dkey, nullptr, k1, vtmp, (uint32_t)P, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
+      radix_pass<RS_BINS_DEV>(dkey, nullptr, k1, vtmp, (uint32_t)Pv, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
                               c->dv + DV_V, nullptr, nullptr, st);
-      radix_pass<RS_BINS_DEV>(k1, vtmp, dkey, v2, (uint32_t)P, nV, d1, DROUNDS, table, tsums, true, 0, 0, nullptr, nullptr,
+      radix_pass<RS_BINS_DEV>(k1, vtmp, dkey, v2, (uint32_t)Pv, nV, d1, DROUNDS, table, tsums, true, 0, 0, nullptr, nullptr,
                               nullptr, st);
-      radix_pass<RS_BINS_DEV>(dkey, v2, nullptr, c->order, (uint32_t)P, nV, d2, DROUNDS, table, tsums, true, 0, 0, nullptr,
+      radix_pass<RS_BINS_DEV>(dkey, v2, nullptr, c->order, (uint32_t)Pv, nV, d2, DROUNDS, table, tsums, true, 0, 0, nullptr,
                               tcnt, vtmp, st);
       F_LAUNCH("depth sort");
     }
@@ -878,18 +923,21 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       // (two launches: block sums, then carry + local scan.  Round 3's one-launch variant, in which a block waited for its
       // predecessors' published sums, saved 2.4 us and could, in principle, give up waiting with nothing but a poisoned
       // image to show for it: removed)
-      scan_exclusive_u32(vtmp, c->off, (uint32_t)P, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
+      scan_exclusive_u32(vtmp, c->off, (uint32_t)Pv, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
       F_LAUNCH("rank scan");
       int sh0; uint32_t mask0;
       radix_first_digit(tile_bits, sh0, mask0);
+      // a batch: the view of a virtual Gaussian is g / Ppad (one multiply by ceil(2^32 / Ppad) and one correction)
+      const uint32_t e_ppad = B > 1 ? (uint32_t)Ppad : 0u;
+      const uint32_t e_magic = B > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)Ppad - 1ull) / (uint64_t)Ppad) : 0u;
       if (rounds == RS_ROUNDS_MIN)
         hipLaunchKernelGGL((k_emit<RS_ROUNDS_MIN>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MIN) / EMIT_PER_THREAD), 0, st, (const uint32_t*)c->off, (const uint32_t*)c->order,
                            (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
-                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
+                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0, e_ppad, e_magic, (uint32_t)tpv);
       else
         hipLaunchKernelGGL((k_emit<RS_ROUNDS_MAX>), dim3(nbN), dim3(rs_chunk(RS_ROUNDS_MAX) / EMIT_PER_THREAD), 0, st, (const uint32_t*)c->off, (const uint32_t*)c->order,
                            (const uint32_t*)chunk_first, (const uint32_t*)c->dv, (const float4*)c->G0, (const float4*)c->G1, (const float4*)c->G2, gridx, W, H,
-                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0);
+                           (uint32_t)ntiles, cull, tileA, rankA, tableN, nbN, mask0, e_ppad, e_magic, (uint32_t)tpv);
       F_LAUNCH("emit");
     }
     int res;
@@ -1010,6 +1058,40 @@ int gsr_forward_raw(const GsrSettings* s, int32_t P, const float* xyz, const flo
                       rotation_raw, nullptr, out_color, out_objects, radii, ctx_out, num_rendered, stream, true);
 }
 
+// A batch of views of ONE set of raw parameters through one launch chain (include/gsraster.h): the views must agree in
+// image size, scale modifier, SH degree, flags; cameras, tan(fov / 2) and backgrounds are per view.
+int gsr_forward_raw_batch(const GsrSettings* s, int32_t B, int32_t P, const float* xyz, const float* features_dc,
+                          const float* features_rest, const float* opacity_logit, const float* log_scaling,
+                          const float* rotation_raw, float* out_color, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered,
+                          void* stream) {
+  if (ctx_out) *ctx_out = nullptr;
+  if (!s || B < 1 || B > MAX_BATCH) return set_err(GSR_ERR_INVALID, "gsr_forward_raw_batch: 1..%d views, got %d", MAX_BATCH, B);
+  if (P > 0 && (!features_dc || !features_rest || !log_scaling || !rotation_raw))
+    return set_err(GSR_ERR_INVALID, "gsr_forward_raw_batch: null features_dc / features_rest / log_scaling / rotation_raw");
+  for (int v = 0; v < B; ++v) {
+    if (!s[v].bg || !s[v].viewmatrix || !s[v].projmatrix || !s[v].campos)
+      return set_err(GSR_ERR_INVALID, "gsr_forward_raw_batch: view %d: settings tensors (bg, viewmatrix, projmatrix, campos) must be device pointers", v);
+    if (s[v].image_height != s[0].image_height || s[v].image_width != s[0].image_width || s[v].scale_modifier != s[0].scale_modifier ||
+        s[v].sh_degree != s[0].sh_degree || s[v].flags != s[0].flags)
+      return set_err(GSR_ERR_INVALID, "gsr_forward_raw_batch: view %d differs from view 0 in image size, scale modifier, SH degree or "
+                     "flags (a batch shares them)", v);
+  }
+  if (s[0].flags & GSR_FLAG_NEEDLE_DOUBLE) return set_err(GSR_ERR_INVALID, "gsr_forward_raw_batch: GSR_FLAG_NEEDLE_DOUBLE is a single-view flag");
+  if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_forward_raw_batch: out_color is null");
+  if (P == 0 && B > 1) {                 // an empty scene: B backgrounds; the context (of view 0) has nothing to differentiate
+    const size_t img = (size_t)3 * (size_t)s[0].image_height * (size_t)s[0].image_width;
+    for (int v = 0; v < B; ++v) {
+      const int rc = forward_impl(s + v, 0, 16, xyz, features_rest, features_dc, nullptr, nullptr, opacity_logit, log_scaling,
+                                  rotation_raw, nullptr, out_color + (size_t)v * img, nullptr, radii, v == 0 ? ctx_out : nullptr,
+                                  num_rendered, stream, true);
+      if (rc != GSR_OK) return rc;
+    }
+    return GSR_OK;
+  }
+  return forward_impl(s, P, 16, xyz, features_rest, features_dc, nullptr, nullptr, opacity_logit, log_scaling, rotation_raw,
+                      nullptr, out_color, nullptr, radii, ctx_out, num_rendered, stream, true, nullptr, false, B);
+}
+
 // Re-render of a kept context whose colour inputs (SH coefficients) may have changed and nothing else has: the colour
 // half of K1 over the Gaussians that emit pairs, then K6 over the kept lists.  include/gsraster.h has the contract.
 int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_rest, const float* features_dc_b,
@@ -1017,6 +1099,7 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
                      void* stream) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_rerender: null context");
   if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: out_color is null");
+  if (c->B > 1) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context is a batch of %d views (gsr_forward_raw_batch)", c->B);
   if (c->P > 0 && (!c->lanegroup || !c->shs))
     return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context was not rendered from SH coefficients (raw parameters, "
                    "or shs with K = 16): there is no colour stage to run again");
@@ -1137,6 +1220,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     const bool segs = c->bnd != nullptr && !obj;
     ra.bnd = segs ? c->bnd : nullptr; ra.segoff = c->segoff; ra.rec_item = c->rec_item; ra.nrec = c->dv + DV_NREC;
     ra.seg_shift = c->seg_shift; ra.extra_blocks = segs ? c->rec_cap * nsub : 0u;
+    ra.tpv = c->tpv; ra.vpack = c->vpack;
     const dim3 gridT(ra.extra_blocks + (unsigned)render_grid(c->ntiles * (int)nsub)), blk(64);
     CompStream comp_s{};
     bool comp_used = false;
@@ -1201,20 +1285,31 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     const int ss_blocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
     pa.sumsq = nullptr;
     if (ss_out) {
-      if (!(c->lanegroup && c->raw) || accumulate || nchunks != 1)
-        return done(set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: served by an overwriting gsr_backward_raw* over one range only"));
+      if (!(c->lanegroup && c->raw) || accumulate || nchunks != 1 || c->B > 1)
+        return done(set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: served by an overwriting gsr_backward_raw* of ONE view over one range only"));
       ss_blk = pool_alloc(dev, sizeof(float) * SUMSQ_W * (size_t)ss_blocks * PRE_WAVES, st);
       if (!ss_blk) return done(set_err(GSR_ERR_NOMEM, "gsr_backward_raw: sum-of-squares partials allocation failed"));
       pa.sumsq = static_cast<float*>(ss_blk);
     }
     for (int ck = 0; ck < nchunks; ++ck) {
       const int gb = std::min(ck * per, P), ge = (ck == nchunks - 1) ? P : std::min((ck + 1) * per, P);
-      if (ge > gb) {
+      // (a batch of views: one launch per view over the same range of Gaussians, the first overwriting -- unless the caller
+      // asked for accumulation -- and the others adding; the per-view arrays of the virtual scene are offset by v * Ppad)
+      for (int v = 0; ge > gb && v < c->B; ++v) {
+        const size_t o = (size_t)v * (size_t)c->Ppad;
+        const bool acc_v = accumulate || v > 0;
+        if (c->B > 1) {
+          pa.va = view_args(c->views[v]);
+          pa.offg = c->offg + o; pa.G0 = c->G0 + REC * o; pa.G1 = c->G1 + REC * o; pa.G2 = c->G2 + REC * o;
+          pa.D = c->D ? c->D + 9 * o : nullptr; pa.abc = c->abc ? c->abc + 3 * o : nullptr;
+          pa.dmeans2D = dmeans2D ? dmeans2D + 3 * (size_t)v * (size_t)P : nullptr;
+          pa.accumulate = acc_v ? 1 : 0;
+        }
         pa.g0 = gb; pa.P = ge;
         const dim3 gridK9((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK));
         if (c->lanegroup) {
           const bool ndl = pa.needle_double != 0 && pa.abc != nullptr;
-          if (c->raw && accumulate) {
+          if (c->raw && acc_v) {
             if (geom && ndl) hipLaunchKernelGGL((k_pre_bwd<true, true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
             else hipLaunchKernelGGL((k_pre_bwd<true, false, true>), gridK9, dim3(PRE_BLOCK), 0, st, pa);
@@ -1280,6 +1375,14 @@ int gsr_backward_raw_chunked(GsrCtx* c, const float* grad_color, const float* gr
                        dopacity_logit, dlog_scaling, drotation_raw, nullptr, stream, accumulate != 0, nchunks, chunk_done, user);
 }
 
+int gsr_backward_raw_batch_into(GsrCtx* c, const float* grad_color, float* dxyz, float* dmeans2D, float* dfeatures_dc,
+                                float* dfeatures_rest, float* dopacity_logit, float* dlog_scaling, float* drotation_raw,
+                                int32_t accumulate, void* stream) {
+  if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw_batch_into: context came from gsr_forward; use gsr_backward");
+  return backward_impl(c, grad_color, nullptr, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, nullptr, nullptr, dopacity_logit,
+                       dlog_scaling, drotation_raw, nullptr, stream, accumulate != 0);
+}
+
 int gsr_mark_visible(const GsrSettings* s, int32_t P, const float* means3D, uint8_t* present, void* stream) {
   if (!s || !s->viewmatrix || !means3D || !present) return set_err(GSR_ERR_INVALID, "gsr_mark_visible: null argument");
   if (P <= 0) return GSR_OK;
@@ -1313,13 +1416,16 @@ int gsr_ctx_info(const GsrCtx* c, int32_t what, int64_t* out) {
     case 1: *out = -1; return GSR_OK;
     case 2: *out = (int64_t)(c->keep_bytes + sizeof(uint32_t) * (size_t)c->nbound); return GSR_OK;
     case 3: *out = (int64_t)c->nbound; return GSR_OK;
+    case 4: *out = (int64_t)c->B; return GSR_OK;
+    case 5: *out = (int64_t)c->Ppad; return GSR_OK;
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_info: unknown item %d", what);
   }
 }
 
 int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, void* stream) {
   if (!c || !dst) return set_err(GSR_ERR_INVALID, "gsr_ctx_export: null argument");
-  const size_t HW = (size_t)c->st.image_height * c->st.image_width;
+  const size_t HW = (size_t)c->st.image_height * c->st.image_width * (size_t)c->B;   // (a batch: the B views one after another)
+  const size_t PV = (size_t)c->Pv;                                                    // (... B * Ppad virtual Gaussians)
   const void* src = nullptr;
   size_t bytes = 0;
   switch (what) {
@@ -1330,21 +1436,21 @@ int gsr_ctx_export(const GsrCtx* c, int32_t what, void* dst, int64_t dst_bytes, 
       break;
     case 2: src = c->n_contrib; bytes = sizeof(uint32_t) * HW; break;
     case 3: src = c->final_T; bytes = sizeof(float) * HW; break;
-    case 4: src = c->order; bytes = sizeof(uint32_t) * (size_t)c->P; break;
-    case 5: src = c->off; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
+    case 4: src = c->order; bytes = sizeof(uint32_t) * PV; break;
+    case 5: src = c->off; bytes = sizeof(uint32_t) * (PV + 1); break;
     case 6:                                                                   // (kept for old callers: same as 7)
     case 7: {                                                                 // splat records [P][3] float4, storage order
-      const size_t need = sizeof(float4) * 3 * (size_t)c->P;
+      const size_t need = sizeof(float4) * 3 * PV;
       if ((int64_t)need > dst_bytes)
         return set_err(GSR_ERR_INVALID, "gsr_ctx_export: item %d needs %zu bytes, buffer has %lld", what, need, (long long)dst_bytes);
-      if (c->P == 0) return GSR_OK;
+      if (PV == 0) return GSR_OK;
       // the records sit REC float4 apart in the workspace: copied out packed, 48 bytes each
       HIP_TRY("ctx export", hipMemcpy2DAsync(dst, sizeof(float4) * 3, c->G0, sizeof(float4) * REC, sizeof(float4) * 3,
-                                             (size_t)c->P, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+                                             PV, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
       return GSR_OK;
     }
     case 8: src = c->dv; bytes = sizeof(uint32_t) * DV_WORDS; break;          // device-side scalars (DV_*)
-    case 9: src = c->offg; bytes = sizeof(uint32_t) * ((size_t)c->P + 1); break;
+    case 9: src = c->offg; bytes = sizeof(uint32_t) * (PV + 1); break;
     default: return set_err(GSR_ERR_INVALID, "gsr_ctx_export: unknown item %d", what);
   }
   if ((int64_t)bytes > dst_bytes)

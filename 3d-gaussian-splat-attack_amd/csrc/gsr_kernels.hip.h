@@ -41,6 +41,41 @@ __device__ __forceinline__ void load_view(View& v, const ViewArgs& a) {
   make_view(v, a.vm, a.pm, a.cam, a.H, a.W, a.tanfovx, a.tanfovy, a.mod, a.deg);
 }
 
+// ------------------------------------------------------------------------------------------------
+// A BATCH of views (gsr_forward_raw_batch; reference attack.py:476-485 renders the B cameras of a batch one after another
+// from one set of attributes).  The batch is laid out as ONE virtual scene: view v owns the virtual Gaussians
+// [v * Ppad, v * Ppad + P) (Ppad = P rounded up to a multiple of BATCH_PAD, the tail of a view's range emits nothing) and the
+// virtual tiles [v * T, (v + 1) * T); scans, both sorts, the emission, the tile schedule and the two compositors then run
+// ONCE over B * Ppad Gaussians and B * T tiles -- the stable tile sort keeps every (view, tile) list in depth order because
+// the global depth order restricted to one view is that view's depth order.  ViewDev: what a compositor needs of view v
+// (its background) and what the per-Gaussian kernels need (matrices, camera position, tan(fov / 2)), gathered once per
+// forward from the B settings' device tensors.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_BATCH = 16;
+constexpr int BATCH_PAD = 16384;              // a multiple of every chunk size the per-Gaussian kernels and scans use
+struct ViewDev {
+  float vm[16];
+  float pm[16];
+  float cam[4];
+  float bg[4];
+  float tanfovx, tanfovy, pad0, pad1;
+};
+struct ViewPtrs {
+  const float* vm[MAX_BATCH];
+  const float* pm[MAX_BATCH];
+  const float* cam[MAX_BATCH];
+  const float* bg[MAX_BATCH];
+  float tanfovx[MAX_BATCH], tanfovy[MAX_BATCH];
+};
+__global__ void __launch_bounds__(64) k_pack_views(ViewPtrs p, int B, ViewDev* __restrict__ out) {
+  const int v = blockIdx.x, t = threadIdx.x;
+  if (v >= B) return;
+  ViewDev& o = out[v];
+  if (t < 16) { o.vm[t] = p.vm[v][t]; o.pm[t] = p.pm[v][t]; }
+  if (t < 3) { o.cam[t] = p.cam[v][t]; o.bg[t] = p.bg[v][t]; }
+  if (t == 3) { o.cam[3] = 0.f; o.bg[3] = 0.f; o.tanfovx = p.tanfovx[v]; o.tanfovy = p.tanfovy[v]; o.pad0 = 0.f; o.pad1 = 0.f; }
+}
+
 constexpr uint32_t RECT_MASK = 0xFFFu;
 // Bits 24..31 of a rect word: how many tiles the TIGHTENED rect's first tile lies behind the first tile of the reference's
 // 3-sigma rect.  The stored centre is relative to the latter -- the same origin whether or not the footprint cull ran, so
@@ -198,9 +233,31 @@ constexpr int DCHUNK = rs_chunk(DROUNDS);
 constexpr int DITEMS = DCHUNK / 256;
 static_assert(DCHUNK % PREG_BLOCK == 0, "a scan chunk covers whole K1 workgroups");
 
+// Every block of K2 adds up K1's per-workgroup sums in front of its chunk: 3907 words at 1 M Gaussians, but quadratic in
+// the Gaussian count (17 us at 1 M, 45 us at 2 M, and a batch of views is one scene of B * P).  Above K1_GROUP_MIN
+// workgroups a tiny launch in front of K2 folds every K1_GROUP consecutive workgroup sums into one (sum as 64 bits in
+// .x | .w << 32, min, max), and a K2 block reads the group sums plus the at most K1_GROUP - 1 workgroups of its own group.
+constexpr int K1_GROUP = 64;
+constexpr uint32_t K1_GROUP_MIN = 4096;
+static_assert((K1_GROUP * PREG_BLOCK) % rs_chunk(RS_ROUNDS_MIN) == 0, "a group covers whole scan chunks");
+__global__ void __launch_bounds__(K1_GROUP) k_bout_group_sum(const uint4* __restrict__ bout, uint32_t nk1, uint4* __restrict__ gsum) {
+  const uint32_t i = blockIdx.x * K1_GROUP + threadIdx.x;
+  unsigned long long s = 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+  if (i < nk1) { const uint4 bo = bout[i]; s = bo.x; mn = bo.y; mx = bo.z; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    s += __shfl_xor(s, d, 64);
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, d, 64));
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+  }
+  if (threadIdx.x == 0) gsum[blockIdx.x] = make_uint4((uint32_t)s, mn, mx, (uint32_t)(s >> 32));
+}
+
 __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uint32_t* __restrict__ tcnt,
                                                            const uint32_t* __restrict__ dkey,
-                                                           const uint4* __restrict__ bout, uint32_t* __restrict__ offg,
+                                                           const uint4* __restrict__ bout, const uint4* __restrict__ gsum,
+                                                           uint32_t* __restrict__ offg,
                                                            uint32_t* __restrict__ table, uint32_t nb,
                                                            uint32_t* __restrict__ dv, unsigned long long cap,
                                                            uint32_t* host_slot, uint32_t host_token) {
@@ -221,11 +278,23 @@ __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uin
   const uint32_t front = b * (DCHUNK / PREG_BLOCK);     // K1 workgroups in front of this chunk
   uint32_t part = 0, mn = 0xFFFFFFFFu, mx = 0u;
   unsigned long long all = 0;
-  for (uint32_t i = tid; i < nk1; i += 256) {
-    const uint4 bo = bout[i];
-    part += i < front ? bo.x : 0u;
-    all += bo.x;
-    mn = min(mn, bo.y); mx = max(mx, bo.z);
+  if (gsum != nullptr) {
+    const uint32_t ng = (nk1 + K1_GROUP - 1) / K1_GROUP, gf = front / K1_GROUP;
+    for (uint32_t i = tid; i < ng; i += 256) {
+      const uint4 gs = gsum[i];
+      part += i < gf ? gs.x : 0u;
+      all += (unsigned long long)gs.x | ((unsigned long long)gs.w << 32);
+      mn = min(mn, gs.y); mx = max(mx, gs.z);
+    }
+    const uint32_t i = gf * K1_GROUP + tid;                // the workgroups of the chunk's own group in front of it
+    if (tid < K1_GROUP && i < front) part += bout[i].x;
+  } else {
+    for (uint32_t i = tid; i < nk1; i += 256) {
+      const uint4 bo = bout[i];
+      part += i < front ? bo.x : 0u;
+      all += bo.x;
+      mn = min(mn, bo.y); mx = max(mx, bo.z);
+    }
   }
   uint32_t carry;
   block_excl_scan_256(part, tmp, carry);
@@ -288,7 +357,10 @@ __global__ void __launch_bounds__(rs_chunk(ROUNDS) / EMIT_PER_THREAD)
 k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, const uint32_t* __restrict__ chunk_first,
        const uint32_t* __restrict__ dv, const float4* __restrict__ R0, const float4* __restrict__ R1, const float4* __restrict__ R2, int gridx, int W, int H,
        uint32_t ntiles, int cull, uint32_t* __restrict__ pair_tile, uint32_t* __restrict__ pair_rank,
-       uint32_t* __restrict__ table, uint32_t nb, uint32_t digit_mask) {
+       uint32_t* __restrict__ table, uint32_t nb, uint32_t digit_mask, uint32_t ppad, uint32_t ppad_magic, uint32_t tpv) {
+  // ppad != 0: a batch of views as one virtual scene (see ViewDev) -- Gaussian g belongs to view g / ppad (ppad_magic =
+  // ceil(2^32 / ppad): the quotient from one multiply and one correction), whose tiles are keyed from view * tpv on;
+  // `ntiles` is then the batch's tile count B * tpv (the key of a culled pair)
   constexpr int CHUNK = rs_chunk(ROUNDS);
   constexpr int THREADS = CHUNK / EMIT_PER_THREAD;
   constexpr int WAVES = THREADS / 64;
@@ -383,6 +455,11 @@ k_emit(const uint32_t* __restrict__ off, const uint32_t* __restrict__ order, con
     const uint32_t dx = local - dy * wx;
     const uint32_t tx = minx + dx, ty = miny + dy;
     uint32_t key = ty * (uint32_t)gridx + tx;
+    if (ppad != 0u) {
+      uint32_t view = __umulhi(g[k], ppad_magic);          // floor(g / ppad) or one more
+      view -= (view * ppad > g[k]) ? 1u : 0u;
+      key += view * tpv;
+    }
     uint32_t mask = 0xFu;   // one bit per 16x4 strip of the tile that the Gaussian can reach
     if (cull) {
       const float x0 = (float)(tx * TILE);
@@ -436,6 +513,10 @@ struct RenderArgs {
   uint32_t seg_shift;     // log2 of the segment length
   const uint32_t* dv;     // device-side scalars of an asynchronous-count forward (dv[DV_OVF] != 0: the image is poisoned), or null
   unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock_fwd): [ntiles * NSUB][2] start/end, 100 MHz
+  // a batch of views (see ViewDev): ntiles = B * tpv tile ids, view = tile / tpv; the per-pixel arrays and out_color hold
+  // the B images one after another; vpack[view].bg is that view's background.  One view: tpv = ntiles, vpack = null.
+  int tpv;
+  const ViewDev* vpack;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -712,7 +793,9 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
     if (item >= a.ntiles * NSUB) return;
   }
   const int tile = item / NSUB, sub = item - tile * NSUB;
-  const int tx = tile % a.gridx, ty = tile / a.gridx;
+  const int view = a.tpv < a.ntiles ? __builtin_amdgcn_readfirstlane(tile / a.tpv) : 0;     // a batch of views: ViewDev
+  const int ltile = tile - view * a.tpv;
+  const int tx = ltile % a.gridx, ty = ltile / a.gridx;
   const uint2 rg = a.ranges[tile];
   // a split tile (see "Segments"): this wave stores (T, C) of its pixels at every segment boundary it walks past
   // (also with object channels composited: the records hold T and the colour sums, which is all a backward WITHOUT
@@ -939,7 +1022,8 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
     for (int k = 0; k < NPX; ++k) rec[k * 64] = make_float4(T[k], C[k][0], C[k][1], C[k][2]);
   }
   if (a.wave_clock && lane == 0) a.wave_clock[2 * item + 1] = wall_clock64();
-  float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const float* bgp = a.vpack != nullptr ? a.vpack[view].bg : a.bg;
+  float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
   if (a.dv != nullptr && a.dv[DV_OVF] != 0u) {
     // the pair count overflowed the capacity this forward was sized for: nothing was composited -- make that unmissable
     bg0 = bg1 = bg2 = __uint_as_float(0x7FC00000u);
@@ -947,15 +1031,18 @@ __global__ void __launch_bounds__(64 * WPB, (OBJ && NPX == 2 && WPB == 1) ? GSR_
     for (int k = 0; k < NPX; ++k) T[k] = 1.f;
   }
   const size_t HW = (size_t)a.H * a.W;
+  float* const oc = a.out_color + 3 * HW * (size_t)view;
+  float* const fT = a.final_T + HW * (size_t)view;
+  uint32_t* const nc = a.n_contrib + HW * (size_t)view;
 #pragma unroll
   for (int k = 0; k < NPX; ++k) {
     if (x < a.W && y[k] < a.H) {
       const size_t pix = (size_t)y[k] * a.W + x;
-      a.out_color[pix] = C[k][0] + T[k] * bg0;
-      a.out_color[HW + pix] = C[k][1] + T[k] * bg1;
-      a.out_color[2 * HW + pix] = C[k][2] + T[k] * bg2;
-      a.final_T[pix] = T[k];
-      a.n_contrib[pix] = last[k];
+      oc[pix] = C[k][0] + T[k] * bg0;
+      oc[HW + pix] = C[k][1] + T[k] * bg1;
+      oc[2 * HW + pix] = C[k][2] + T[k] * bg2;
+      fT[pix] = T[k];
+      nc[pix] = last[k];
       if (OBJ) {
 #pragma unroll
         for (int c = 0; c < NUM_OBJ; ++c) a.out_objects[c * HW + pix] = O[k][c];
@@ -1032,6 +1119,8 @@ struct RenderBwdArgs {
   uint32_t seg_shift, extra_blocks;
   uint32_t tag_lo, tag_hi;    // stamped into every row written by this call
   unsigned long long* wave_clock;   // diagnostic (gsr_debug_wave_clock): [ntiles][2] start/end of each tile's wave, 100 MHz
+  int tpv;                    // a batch of views, as in RenderArgs: view = tile / tpv; grad_color holds the B images' gradients
+  const ViewDev* vpack;
 };
 
 constexpr int PART_F4 = 3;
@@ -1089,7 +1178,9 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
     }
   }
   const int tile = item / NSUB, sub = item - tile * NSUB;
-  const int tx = tile % a.gridx, ty = tile / a.gridx;
+  const int view = a.tpv < a.ntiles ? __builtin_amdgcn_readfirstlane(tile / a.tpv) : 0;     // a batch of views: ViewDev
+  const int ltile = tile - view * a.tpv;
+  const int tx = ltile % a.gridx, ty = ltile / a.gridx;
   const uint2 rg = a.ranges[tile];
   // list positions (a_pos, b_pos] are this wave's; an unsplit tile: the whole list
   const uint32_t rec0 = (!OBJ && a.bnd != nullptr) ? a.segoff[tile] : SEG_NONE;
@@ -1120,8 +1211,12 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   int red_n = 0;       // parked entries (wave uniform)
   const int x = tx * TILE + (lane & 15);
   const float pxf = (float)(lane & 15);                    // relative to the tile's first pixel, like the staged centres
-  const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+  const float* bgp = a.vpack != nullptr ? a.vpack[view].bg : a.bg;
+  const float bg0 = bgp[0], bg1 = bgp[1], bg2 = bgp[2];
   const size_t HW = (size_t)a.H * a.W;
+  const float* const fT = a.final_T + HW * (size_t)view;
+  const uint32_t* const nc = a.n_contrib + HW * (size_t)view;
+  const float* const gcol = a.grad_color + 3 * HW * (size_t)view;
   float pyf[NPX], T[NPX], Acc[NPX], g0[NPX], g1[NPX], g2[NPX];
   float gO[OBJ ? NPX : 1][NUM_OBJ];
   uint32_t ncon[NPX], smax[NPX];
@@ -1133,9 +1228,9 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
     Acc[k] = 0.f;
     if (x < a.W && y < a.H) {
       const size_t pix = (size_t)y * a.W + x;
-      T[k] = a.final_T[pix];
-      ncon[k] = a.n_contrib[pix];
-      g0[k] = a.grad_color[pix]; g1[k] = a.grad_color[HW + pix]; g2[k] = a.grad_color[2 * HW + pix];
+      T[k] = fT[pix];
+      ncon[k] = nc[pix];
+      g0[k] = gcol[pix]; g1[k] = gcol[HW + pix]; g2[k] = gcol[2 * HW + pix];
       // Acc_i = sum over the entries j behind i of alpha_j (c_j.g) prod_{i<k<j} (1 - alpha_k): what the pixel shows
       // behind entry i, dotted with dL/dC.  The background is the list's last "entry" (alpha 1, colour bg): seeding
       // Acc with bg.g makes T_i (c_i.g - Acc_i) carry the -T_final/(1-alpha_i) (bg.g) term of dL/dalpha_i by itself.
@@ -1612,6 +1707,7 @@ struct PreArgs {
   const float* opac_b;
   const float* sh_b;
   const float* sh_dc_b;
+  int Pfill;              // >= P (a view of a batch: the view's padded range, see ViewDev): Gaussians [P, Pfill) emit nothing
   int32_t* radii;
   float4* G0;
   float4* G1;
@@ -1705,6 +1801,9 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     }
     a.dkey[g] = key;
     a.tcnt[g] = cnt;
+  } else if (g < a.Pfill) {
+    a.dkey[g] = 0xFFFFFFFFu;
+    a.tcnt[g] = 0u;
   }
   pre_block_epilogue(a.bo, g, cnt, key);
 }

@@ -129,6 +129,11 @@ def _load():
     lib.gsr_forward_raw2_keep.restype = ctypes.c_int
     lib.gsr_forward_raw2_keep.argtypes = ([ctypes.POINTER(_CSettings), i32] + [vp] * 7 + [i32] + [vp] * 7
                                           + [vp, vp, vp, ctypes.POINTER(vp), i64p, vp])
+    if hasattr(lib, "gsr_forward_raw_batch"):              # (absent from older builds selected through GSR_LIBRARY for A/B runs)
+        lib.gsr_forward_raw_batch.restype = ctypes.c_int
+        lib.gsr_forward_raw_batch.argtypes = ([ctypes.POINTER(_CSettings), i32, i32] + [vp] * 6 + [vp, vp, ctypes.POINTER(vp), i64p, vp])
+        lib.gsr_backward_raw_batch_into.restype = ctypes.c_int
+        lib.gsr_backward_raw_batch_into.argtypes = [vp] * 9 + [i32, vp]
     lib.gsr_ctx_rerender.restype = ctypes.c_int
     lib.gsr_ctx_rerender.argtypes = [vp] * 8 + [ctypes.c_uint32, vp]
     lib.gsr_ctx_free.restype = None
@@ -824,6 +829,137 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 shaped(d_obj, s[4]), shaped(d_op, s[5]), shaped(d_sc, s[6]), shaped(d_ro, s[7]), None, None, None, None, None, None)
 
 
+MAX_BATCH = 16                # views per gsr_forward_raw_batch call (csrc/gsr_kernels.hip.h)
+
+
+class _RasterizeGaussiansRawBatch(torch.autograd.Function):
+    """B views of one set of RAW parameters through ONE launch chain (gsr_forward_raw_batch / gsr_backward_raw_batch_into):
+    what the reference's batch loop does with B render() calls and one accumulated .grad (attack.py:476-494).
+    -> (color[B,3,H,W], radii[B,P]); the attribute gradients are the SUM over the views of dL/dC[v] pulled back."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, settings_list, keep=True,
+                bucket=None):
+        lib = _load()
+        ctx.bucket = bucket
+        if not xyz.is_cuda:
+            raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
+                               f"{xyz.device}); there is no CPU path")
+        device = xyz.device
+        P = int(xyz.shape[0])
+        B = len(settings_list)
+        if not 1 <= B <= MAX_BATCH:
+            raise ValueError(f"a batch holds 1..{MAX_BATCH} views, got {B}")
+        if tuple(features_dc.shape) != (P, 1, 3) or tuple(features_rest.shape) != (P, 15, 3):
+            raise ValueError("fused path needs _features_dc [P,1,3] and _features_rest [P,15,3] (SH degree 3 storage)")
+
+        def prep(t):
+            return None if t is None or t.numel() == 0 else _f32c(t.detach(), device)
+        x, dc, rest = prep(xyz), prep(features_dc), prep(features_rest)
+        op, sc, ro = prep(opacity), prep(scaling), prep(rotation)
+        H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+        packs = [_SettingsPack(rs, device) for rs in settings_list]
+        carr = (_CSettings * B)()
+        for v, pk in enumerate(packs):
+            carr[v] = pk.c
+        color = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
+        radii = torch.empty(B, P, dtype=torch.int32, device=device)
+        handle = ctypes.c_void_p(None)
+        nren = ctypes.c_int64(0)
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            rc = lib.gsr_forward_raw_batch(carr, B, P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(op), _ptr(sc), _ptr(ro), _ptr(color),
+                                           _ptr(radii), ctypes.byref(handle) if keep else None, ctypes.byref(nren), stream)
+        if rc != 0:
+            raise Exception(_err(lib)) if rc == 1 else (PairCapacityExceeded if rc == GSR_ERR_OVERFLOW else RuntimeError)(_err(lib))
+        ctx.holder = _CtxHolder(lib, handle) if (keep and handle.value) else None
+        ctx.packs = packs
+        ctx.pack = packs[0]
+        ctx.B = B
+        ctx._nren = nren.value
+        ctx.shapes = (xyz.shape, None if means2D is None else means2D.shape, features_dc.shape, features_rest.shape,
+                      opacity.shape, scaling.shape, rotation.shape)
+        ctx.kept = (x, dc, rest, op, sc, ro)
+        ctx.versions = _versions(ctx.kept)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii):
+        _check_versions(ctx.kept, ctx.versions)
+        x, dc, rest, op, sc, ro = ctx.kept
+        if x is None:                                  # an empty scene: empty gradients
+            need = ctx.needs_input_grad
+            s = ctx.shapes
+            dev0 = ctx.packs[0].device
+            z = lambda i, shp: torch.zeros(shp, dtype=torch.float32, device=dev0) if (need[i] and shp is not None) else None
+            return (z(0, s[0]), z(1, s[1]), z(2, s[2]), z(3, s[3]), z(4, s[4]), z(5, s[5]), z(6, s[6]), None, None, None)
+        lib = ctx.holder.lib
+        device = x.device
+        P, B = int(x.shape[0]), ctx.B
+        H, W = ctx.pack.c.image_height, ctx.pack.c.image_width
+        if grad_color is None:
+            grad_color = torch.zeros(B, 3, H, W, dtype=torch.float32, device=device)
+        gcol = _f32c(grad_color, device)
+        need = ctx.needs_input_grad
+
+        def out(cond, *shape):
+            return torch.empty(*shape, dtype=torch.float32, device=device) if cond else None
+        want_sh = need[2] or need[3]
+        all59 = need[0] and want_sh and need[4] and need[5] and need[6]
+        bucket = ctx.bucket if all59 else None
+        if bucket is not None:
+            if bucket.P != P or bucket.flat.device != device:
+                raise ValueError("grad bucket does not match the model (P or device)")
+            d_x, d_dc, d_rest, d_op, d_sc, d_ro = bucket.slices()
+        elif all59:
+            flat = torch.empty(59 * P, dtype=torch.float32, device=device)
+            cuts = [0, 3 * P, 6 * P, 51 * P, 52 * P, 55 * P, 59 * P]
+            d_x, d_dc, d_rest, d_op, d_sc, d_ro = (flat[cuts[i]:cuts[i + 1]] for i in range(6))
+        else:
+            d_x = out(need[0], P, 3)
+            d_dc = out(want_sh, P, 1, 3)
+            d_rest = out(want_sh, P, 15, 3)
+            d_op = out(need[4], P)
+            d_sc = out(need[5], P, 3)
+            d_ro = out(need[6], P, 4)
+        d_m2 = out(need[1], B, P, 3)
+        if P > 0:
+            with torch.cuda.device(device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                rc = lib.gsr_backward_raw_batch_into(ctx.holder.handle, _ptr(gcol), _ptr(d_x), _ptr(d_m2), _ptr(d_dc), _ptr(d_rest),
+                                                     _ptr(d_op), _ptr(d_sc), _ptr(d_ro),
+                                                     1 if (bucket is not None and not bucket.fresh) else 0, stream)
+            if rc != 0:
+                raise (PairCapacityExceeded if rc == 5 else RuntimeError)(_err(lib))
+        else:
+            for t in (d_x, d_dc, d_rest, d_op, d_sc, d_ro, d_m2):
+                if t is not None and bucket is None:
+                    t.zero_()
+        s = ctx.shapes
+        if bucket is not None:
+            bucket.fresh, bucket.used = False, True
+            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None)
+
+        def shaped(t, shape, wanted=True):
+            return None if (t is None or not wanted) else t.reshape(shape)
+        return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
+                shaped(d_op, s[4]), shaped(d_sc, s[5]), shaped(d_ro, s[6]), None, None, None)
+
+
+def rasterize_gaussians_raw_batch(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, settings_list,
+                                  grad_bucket: Optional["GradBucket"] = None):
+    """(color[B,3,H,W], radii[B,P]) of B views (a list of GaussianRasterizationSettings that agree in image size, scale
+    modifier and SH degree) of one set of RAW parameters, through one launch chain: every image and radius is bit for bit
+    what rasterize_gaussians_raw gives for that view alone, and the backward leaves the SUM over the views of the
+    attribute gradients, written once.  means2D: a [B,P,3] tensor whose .grad receives the per-view screen-space gradient
+    (viewspace_points.grad of the reference, one slice per view), or None.  No object channels."""
+    keep = _wants_backward(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation)
+    return _RasterizeGaussiansRawBatch.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
+                                             list(settings_list), keep, grad_bucket)
+
+
 def _wants_backward(*tensors) -> bool:
     """A forward keeps backward state only if autograd can reach it: grad mode on and an input that requires grad.
     Decided here, before Function.apply (inside forward() grad mode is off and needs_input_grad ignores no_grad())."""
@@ -1002,6 +1138,9 @@ def export_state(output: torch.Tensor, name: str) -> torch.Tensor:
     P = int(fn.kept[0].shape[0])
     H, W = fn.pack.c.image_height, fn.pack.c.image_width
     T = ((W + 15) // 16) * ((H + 15) // 16)
+    nb = max(holder.info(4), 1)                      # a batch context: B views as one virtual scene of B * Ppad Gaussians
+    if nb > 1:
+        P, T, H = nb * holder.info(5), nb * T, nb * H
     n = {"ranges": 2 * T, "pair_rank": holder.info(0), "n_contrib": H * W, "final_T": H * W, "order": P,
          "off": P + 1, "R": 12 * P, "G": 12 * P, "dv": 16, "offg": P + 1}[name]
     live = None
@@ -1047,6 +1186,6 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "rasterize_gaussians_raw2", "PairCapacityExceeded", "GradBucket", "GradNorms",
+           "rasterize_gaussians_raw2", "rasterize_gaussians_raw_batch", "MAX_BATCH", "PairCapacityExceeded", "GradBucket", "GradNorms",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

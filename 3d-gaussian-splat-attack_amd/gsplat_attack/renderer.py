@@ -11,8 +11,8 @@ import math
 
 import torch
 
-from diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw,
-                                         rasterize_gaussians_raw2)
+from diff_gaussian_rasterization import (MAX_BATCH, GaussianRasterizationSettings, GaussianRasterizer, _zero_scalar,
+                                         rasterize_gaussians_raw, rasterize_gaussians_raw2, rasterize_gaussians_raw_batch)
 
 from .sh import eval_sh
 
@@ -202,6 +202,42 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     else:
         kw["shs"] = pc.get_features
     image, radii, objects = GaussianRasterizer(raster_settings=st)(**kw)
+    return _result(image, screenspace_points, radii, objects)
+
+
+def can_batch(cameras, pc, pipe, override_color=None) -> bool:
+    """True when render_batch() can take `cameras` through one launch chain: the fused raw-parameter path, no object
+    channels, one image size, at most MAX_BATCH views."""
+    cams = list(cameras)
+    return bool(1 <= len(cams) <= MAX_BATCH and takes_fused_path(pc, pipe, override_color)
+                and bool(getattr(pipe, "skip_objects", False))
+                and len({(int(c.image_height), int(c.image_width)) for c in cams}) == 1)
+
+
+def render_batch(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
+    """render() of a BATCH of cameras of one model through ONE launch chain (gsr_forward_raw_batch).  The reference's batch is
+    a Python loop of render() calls whose backward passes add up in .grad (attack.py:476-494); here the B views are one
+    virtual scene: one scan, one depth sort, one emission, one tile sort, one schedule, one forward and one backward
+    composite over all B images, and the 59 attribute gradients per Gaussian are written once for the batch.
+    -> dict like render()'s with a leading view axis: render [B,3,H,W], viewspace_points [B,P,3] (a zero leaf whose .grad
+    receives every view's screen-space gradient), radii [B,P], visibility_filter (lazy) [B,P]; render_object is a
+    broadcast zero (no object channels: needs pipe.skip_objects).  Every image and radius is bit for bit render()'s for that
+    camera; the gradients are those of the B render() calls summed in view order."""
+    cams = list(cameras)
+    if not can_batch(cams, pc, pipe):
+        raise ValueError("render_batch needs the fused raw-parameter path without object channels (PipelineParams("
+                         f"skip_objects=True)), one image size and 1..{MAX_BATCH} cameras")
+    B, P = len(cams), int(pc.get_xyz.shape[0])
+    want_vs = bool(getattr(pipe, "viewspace_grad", True))
+    # one zero leaf [B,P,3] (no allocation per call: _zero_points keeps one zero buffer per shape)
+    screenspace_points = _zero_points(pc.get_xyz.detach().unsqueeze(0).expand(B, P, 3), True) if want_vs else None
+    sts = [_settings(cam, pc, pipe, bg_color, scaling_modifier) for cam in cams]
+    bucket = getattr(pipe, "grad_bucket", None)
+    if callable(bucket):
+        bucket = bucket()
+    image, radii = rasterize_gaussians_raw_batch(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
+                                                 pc._scaling, pc._rotation, sts, grad_bucket=bucket)
+    objects = _zero_scalar(image.device).unsqueeze(0).expand(B, 16, image.shape[2], image.shape[3])
     return _result(image, screenspace_points, radii, objects)
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 400 /* 0.4.0 */
+#define GSR_VERSION 500 /* 0.5.0 */
 #define GSR_NUM_OBJECTS 16 /* object-feature channels, reference scene/gaussian_model.py:52 */
 
 enum {
@@ -184,6 +184,30 @@ int gsr_backward_raw_chunked(GsrCtx* ctx, const float* grad_color, const float* 
                              float* dlog_scaling, float* drotation_raw, int32_t accumulate, int32_t nchunks,
                              gsr_chunk_fn chunk_done, void* user, void* stream);
 
+/* A BATCH of views of one set of raw parameters through ONE launch chain.  The reference's batch is a Python loop of B
+ * render() calls on the same attributes (reference attack.py:476-485; :522-530 for the success renders) whose B backward
+ * passes add up in .grad (:494); every call repeats the latency-bound binning chain (scan, two sorts, emission, schedule:
+ * ~20 short launches), re-reads the 192-byte SH rows and re-writes 236 bytes of gradient per Gaussian.  Here the B views
+ * form one virtual scene -- view v owns the virtual Gaussians [v * Ppad, v * Ppad + P) and the tiles [v * T, (v + 1) * T) --
+ * and the scans, both sorts, the emission, the tile schedule and the two compositors run once over it.
+ *   settings     [B] (1 <= B <= 16): per view the camera tensors, tan(fov / 2) and background; image size, scale_modifier,
+ *                sh_degree and flags must be the same in all of them (GSR_FLAG_NEEDLE_DOUBLE is not available)
+ *   out_color    [B,3,H,W]; radii [B,P]; no object channels
+ *   num_rendered receives the (tile, Gaussian) pairs of all B views together
+ * Every view's image and radii are bit for bit those of gsr_forward_raw on that view's settings.
+ * gsr_backward_raw_batch_into: grad_color [B,3,H,W]; the 59 attribute gradients are the SUM over the B views, written once
+ * (accumulate == 0; Gaussians without pairs in any view: zeros) or added to what the buffers hold (accumulate != 0) -- bit
+ * for bit what B calls of gsr_backward_raw_into in view order leave, the first with the caller's `accumulate` and the
+ * others adding; dmeans2D [B,P,3] or NULL is per view (overwritten).  gsr_backward_raw / _into / _chunked accept a batch
+ * context with these shapes too; gsr_ctx_rerender and gsr_ctx_request_sumsq do not. */
+int gsr_forward_raw_batch(const GsrSettings* settings, int32_t B, int32_t P, const float* xyz, const float* features_dc,
+                          const float* features_rest, const float* opacity_logit, const float* log_scaling,
+                          const float* rotation_raw, float* out_color, int32_t* radii, GsrCtx** ctx_out,
+                          int64_t* num_rendered, void* stream);
+int gsr_backward_raw_batch_into(GsrCtx* ctx, const float* grad_color, float* dxyz, float* dmeans2D, float* dfeatures_dc,
+                                float* dfeatures_rest, float* dopacity_logit, float* dlog_scaling, float* drotation_raw,
+                                int32_t accumulate, void* stream);
+
 /* Forward-only render of TWO parameter sets as one scene: the attacked target (a) followed by the frozen background (b),
  * Gaussians numbered a then b (radii [Pa+Pb]).  Replaces what the reference does after every PGD step to check the
  * attack: deep-copy the attacked model, append the background to each of its seven tensors (seven concat_setup calls,
@@ -290,7 +314,7 @@ int gsr_query(int32_t what, int64_t* out);
  * object channels are composited or GSR_FLAG_NO_SEGMENTS is set -- (N/256 + min(tiles, N/256) + 1) boundary records of
  * 4 KB: 50-190 MB at N = 3-10 M pairs.  num_rendered counts the pairs of the TIGHTENED tile rects (the tiles the
  * alpha >= 1/255 footprint's bounding box touches); under GSR_FLAG_NO_CULL it is the reference's count. */
-int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);
+int gsr_ctx_info(const GsrCtx* ctx, int32_t what, int64_t* out);   /* also: 4 = views of the context's batch (1: an ordinary forward), 5 = Ppad */
 
 /* Copies one internal array of a context into a caller DEVICE buffer (tests / diagnostics):
  * what 0 = tile ranges [T][2] u32, 1 = sorted pair list [N] u32 (Gaussian index | strip mask << 28, tile by tile, depth

@@ -1,0 +1,182 @@
+"""A batch of views through ONE launch chain (gsr_forward_raw_batch / gsr_backward_raw_batch_into).
+
+The reference's batch is a loop of render() calls on one set of attributes whose backward passes add up in .grad
+(reference attack.py:476-494).  The batch entry points render the B views as one virtual scene; what they must give:
+every view's image and radii bit for bit those of the single-view call, every view's screen-space gradient likewise, and
+the 59 attribute gradients equal to the B single-view backward passes accumulated in view order (gsr_backward_raw_into:
+the first overwrites, the others add).  One view of every batch is also held against oracle-R directly."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    return torch.device("cuda:0")
+
+
+PARAMS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+
+def _single_views(model, cams, pipe, bg_of, gcs, scale=1.0):
+    """The reference's loop: one render() + backward per view, gradients accumulated in a GradBucket in view order."""
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.renderer import render
+    import copy
+    P = int(model.get_xyz.shape[0])
+    bucket = D.GradBucket(P, model.get_xyz.device)
+    pipe = copy.copy(pipe)
+    pipe.grad_bucket = bucket
+    imgs, radii, vs = [], [], []
+    for v, cam in enumerate(cams):
+        out = render(cam, model, pipe, bg_of(v), scale)
+        out["render"].backward(gcs[v])
+        imgs.append(out["render"].detach())
+        radii.append(out["radii"])
+        vs.append(out["viewspace_points"].grad.clone() if out["viewspace_points"] is not None and
+                  out["viewspace_points"].grad is not None else None)
+    return torch.stack(imgs), torch.stack(radii), vs, bucket
+
+
+def _batched(model, cams, pipe, bg, gcs, scale=1.0, per_view_bg=None):
+    import diff_gaussian_rasterization as D
+    from gsplat_attack import renderer as R
+    import copy
+    P = int(model.get_xyz.shape[0])
+    bucket = D.GradBucket(P, model.get_xyz.device)
+    pipe = copy.copy(pipe)
+    pipe.grad_bucket = bucket
+    if per_view_bg is None:
+        out = R.render_batch(cams, model, pipe, bg, scale)
+    else:
+        sts = [R._settings(c, model, pipe, per_view_bg[v], scale) for v, c in enumerate(cams)]
+        vsp = torch.zeros(len(cams), P, 3, device=model.get_xyz.device, requires_grad=True)
+        image, radii = D.rasterize_gaussians_raw_batch(model._xyz, vsp, model._features_dc, model._features_rest,
+                                                       model._opacity, model._scaling, model._rotation, sts, grad_bucket=bucket)
+        out = dict(render=image, radii=radii, viewspace_points=vsp)
+    out["render"].backward(torch.stack(list(gcs)))
+    return out, bucket
+
+
+def _check_equal(model, cams, gcs, bg_list=None, scale=1.0, exact_grads=True):
+    from gsplat_attack.renderer import PipelineParams
+    dev = model.get_xyz.device
+    pipe = PipelineParams(skip_objects=True)
+    bgs = bg_list if bg_list is not None else [torch.tensor([0.1, 0.2, 0.3], device=dev)] * len(cams)
+    imgs, radii, vs, b1 = _single_views(model, cams, pipe, lambda v: bgs[v], gcs, scale)
+    out, b2 = _batched(model, cams, pipe, bgs[0], gcs, scale, per_view_bg=bgs if bg_list is not None else None)
+    torch.cuda.synchronize()
+    assert torch.equal(out["render"].detach(), imgs), "batched images differ from the single-view renders"
+    assert torch.equal(out["radii"], radii)
+    g = out["viewspace_points"].grad
+    for v in range(len(cams)):
+        assert torch.equal(g[v], vs[v]), f"view {v}: screen-space gradient differs"
+    assert b1.used and b2.used
+    if exact_grads:
+        assert torch.equal(b1.flat, b2.flat), "batched attribute gradients differ from the accumulated single-view ones"
+    else:
+        scale_ = b1.flat.abs().max().item()
+        assert (b1.flat - b2.flat).abs().max().item() <= 1e-6 * scale_
+    return out, b2
+
+
+def test_small_scene_batch_equals_single_views_and_oracle():
+    """S-hydrant-1k, 5 cameras at 128x128 (fewer Gaussians than tiles of the batch: the memset path of the ranges)."""
+    from gsplat_attack.scenes import make_scene
+    from oracle import oracle_r as O
+    from util import settings_for, model_inputs
+    dev = _dev()
+    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=5)
+    g = torch.Generator().manual_seed(5)
+    gcs = [torch.randn(3, 128, 128, generator=g).to(dev) for _ in cams]
+    out, _ = _check_equal(model, cams, gcs)
+    # view 3 of the batch against oracle-R (float64) on its solid pixels
+    ref, rcams, _ = make_scene("hydrant-1k", device="cpu", n_views=5)
+    st = settings_for(rcams[3], torch.tensor([0.1, 0.2, 0.3]))
+    ro = O.rasterize(ref.get_xyz, None, ref.get_opacity, st, shs=ref.get_features, scales=ref.get_scaling,
+                     rotations=ref.get_rotation)
+    solid = ~ro.fragile_px
+    err = (out["render"][3].detach().cpu().double() - ro.color.detach()).abs().amax(dim=0)[solid].max().item()
+    assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("P,W,H,B", [(60_000, 640, 360, 4), (20_001, 333, 190, 3), (70_000, 512, 512, 16), (300, 64, 48, 2)])
+def test_mid_scenes_ragged_sizes(P, W, H, B):
+    """Gaussian counts that are no multiple of anything, image sizes that are no multiple of a tile, 2..16 views,
+    split tile lists (segments) at the larger sizes."""
+    from gsplat_attack.scenes import make_scene
+    dev = _dev()
+    model, cams, _ = make_scene("nyc-1M", device=dev, P=P, width=W, height=H, n_views=B)
+    g = torch.Generator().manual_seed(P)
+    gcs = [torch.randn(3, H, W, generator=g).to(dev) for _ in cams]
+    _check_equal(model, cams, gcs)
+
+
+def test_per_view_backgrounds_and_fov():
+    """Backgrounds and fields of view are per view; image size is shared."""
+    from gsplat_attack.scenes import make_scene
+    from gsplat_attack.cameras import look_at_camera
+    dev = _dev()
+    model, cams, _ = make_scene("nyc-1M", device=dev, P=30_000, width=320, height=200, n_views=3)
+    cams[1] = look_at_camera((25.0, 5.0, 9.0), (0.0, 0.0, 3.0), up=(0.0, 0.0, 1.0), fovx=0.6, width=320, height=200, uid=9,
+                             device=dev)
+    bgs = [torch.tensor(b, device=dev) for b in ([0.0, 0.0, 0.0], [1.0, 0.5, 0.25], [0.3, 0.3, 0.9, 7.0])]
+    g = torch.Generator().manual_seed(11)
+    gcs = [torch.randn(3, 200, 320, generator=g).to(dev) for _ in cams]
+    _check_equal(model, cams, gcs, bg_list=bgs)
+
+
+def test_batch_of_one_and_empty_scene():
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.scenes import make_scene
+    from gsplat_attack.renderer import PipelineParams, render, render_batch
+    from gsplat_attack.gaussian_model import GaussianModel
+    dev = _dev()
+    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=2)
+    pipe = PipelineParams(skip_objects=True)
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+    one = render_batch(cams[:1], model, pipe, bg)
+    ref = render(cams[0], model, pipe, bg)
+    assert torch.equal(one["render"][0], ref["render"]) and torch.equal(one["radii"][0], ref["radii"])
+    # no Gaussians at all: B backgrounds
+    z = lambda *s: torch.zeros(*s, device=dev)
+    empty = GaussianModel.from_tensors(xyz=z(0, 3), features_dc=z(0, 1, 3), features_rest=z(0, 15, 3), scaling=z(0, 3),
+                                       rotation=z(0, 4), opacity=z(0, 1), objects_dc=z(0, 1, 16), device=dev)
+    out = render_batch(cams, empty, pipe, bg)
+    assert out["render"].shape == (2, 3, 128, 128)
+    assert torch.equal(out["render"], bg.view(1, 3, 1, 1).expand(2, 3, 128, 128))
+    out["render"].sum().backward()
+
+
+def test_batch_rejects_mixed_sizes_and_objects():
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.scenes import make_scene
+    from gsplat_attack.renderer import PipelineParams, render_batch, _settings
+    dev = _dev()
+    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=2)
+    _, cams2, _ = make_scene("hydrant-1k", device=dev, n_views=2, width=64, height=64)
+    bg = torch.zeros(3, device=dev)
+    with pytest.raises(ValueError):
+        render_batch([cams[0], cams2[1]], model, PipelineParams(skip_objects=True), bg)
+    with pytest.raises(ValueError):
+        render_batch(cams, model, PipelineParams(skip_objects=False), bg)
+    pipe = PipelineParams(skip_objects=True)
+    sts = [_settings(cams[0], model, pipe, bg, 1.0), _settings(cams2[1], model, pipe, bg, 1.0)]
+    with pytest.raises(Exception, match="differs from view 0"):
+        D.rasterize_gaussians_raw_batch(model._xyz, None, model._features_dc, model._features_rest, model._opacity,
+                                        model._scaling, model._rotation, sts)
+
+
+def test_fullsize_batch_of_four_equals_single_views():
+    """S-nyc-1M at 1080p, B = 4: images, radii and screen-space gradients bit for bit, the gradient bucket equal to the
+    four single-view backward passes accumulated in view order."""
+    from gsplat_attack.scenes import make_scene
+    dev = _dev()
+    model, cams, _ = make_scene("nyc-1M", device=dev, n_views=8)
+    g = torch.Generator().manual_seed(99)
+    gcs = [torch.randn(3, 1080, 1920, generator=g).to(dev) for _ in range(4)]
+    _check_equal(model, [cams[i] for i in (0, 3, 5, 6)], gcs)
