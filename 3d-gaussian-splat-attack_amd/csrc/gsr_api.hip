@@ -1281,12 +1281,16 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     // what it writes; one small launch behind it adds them up per tensor (fixed order) into the caller's six doubles
     double* ss_out = c->sumsq_out;
     c->sumsq_out = nullptr;
+    // a batch of views: ONE launch of k_pre_bwd_batch per range walks the B views and writes the gradients once
+    // (GSR_BATCH_K9=0: one k_pre_bwd launch per view instead, the others in accumulate mode -- the A/B and the bit-exact form)
+    static const int batch_k9_env = [] { const char* e = getenv("GSR_BATCH_K9"); return e ? atoi(e) : 1; }();
+    const bool batch_fused = c->B > 1 && c->raw && c->lanegroup && batch_k9_env != 0;
     void* ss_blk = nullptr;
     const int ss_blocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
     pa.sumsq = nullptr;
     if (ss_out) {
-      if (!(c->lanegroup && c->raw) || accumulate || nchunks != 1 || c->B > 1)
-        return done(set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: served by an overwriting gsr_backward_raw* of ONE view over one range only"));
+      if (!(c->lanegroup && c->raw) || accumulate || nchunks != 1 || (c->B > 1 && !batch_fused))
+        return done(set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: served by an overwriting gsr_backward_raw* over one range only"));
       ss_blk = pool_alloc(dev, sizeof(float) * SUMSQ_W * (size_t)ss_blocks * PRE_WAVES, st);
       if (!ss_blk) return done(set_err(GSR_ERR_NOMEM, "gsr_backward_raw: sum-of-squares partials allocation failed"));
       pa.sumsq = static_cast<float*>(ss_blk);
@@ -1295,7 +1299,26 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
       const int gb = std::min(ck * per, P), ge = (ck == nchunks - 1) ? P : std::min((ck + 1) * per, P);
       // (a batch of views: one launch per view over the same range of Gaussians, the first overwriting -- unless the caller
       // asked for accumulation -- and the others adding; the per-view arrays of the virtual scene are offset by v * Ppad)
-      for (int v = 0; ge > gb && v < c->B; ++v) {
+      if (batch_fused && ge > gb) {
+        PreBwdBatchArgs ba;
+        ba.P = ge; ba.g0 = gb; ba.B = c->B; ba.Ppad = c->Ppad; ba.vpack = c->vpack;
+        ba.H = c->st.image_height; ba.W = c->st.image_width; ba.deg = c->st.sh_degree; ba.mod = c->st.scale_modifier;
+        ba.offg = c->offg; ba.G0 = c->G0; ba.G1 = c->G1; ba.G2 = c->G2; ba.part = part;
+        ba.tag_lo = tag_lo; ba.tag_hi = tag_hi; ba.nsub = nsub;
+        ba.means = c->means3D; ba.scales = c->scales; ba.rots = c->rots; ba.D = c->D;
+        ba.dmeans3D = dmeans3D; ba.dmeans2D = dmeans2D; ba.dsh = dshs; ba.dsh_dc = dsh_dc; ba.dopac = dopacities;
+        ba.dscales = dscales; ba.drots = drotations; ba.sumsq = pa.sumsq;
+        const dim3 gridB((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK));
+        const size_t lds = sizeof(float) * 3 * 64 * (size_t)c->B;
+        if (geom) {
+          if (accumulate) hipLaunchKernelGGL((k_pre_bwd_batch<true, true>), gridB, dim3(PRE_BLOCK), lds, st, ba);
+          else hipLaunchKernelGGL((k_pre_bwd_batch<true, false>), gridB, dim3(PRE_BLOCK), lds, st, ba);
+        } else {
+          if (accumulate) hipLaunchKernelGGL((k_pre_bwd_batch<false, true>), gridB, dim3(PRE_BLOCK), lds, st, ba);
+          else hipLaunchKernelGGL((k_pre_bwd_batch<false, false>), gridB, dim3(PRE_BLOCK), lds, st, ba);
+        }
+      }
+      for (int v = 0; !batch_fused && ge > gb && v < c->B; ++v) {
         const size_t o = (size_t)v * (size_t)c->Ppad;
         const bool acc_v = accumulate || v > 0;
         if (c->B > 1) {

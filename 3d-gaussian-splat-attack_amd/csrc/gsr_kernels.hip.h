@@ -2187,4 +2187,280 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   flush_sumsq();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K8+K9 of a BATCH of views (gsr_backward_raw_batch_into; raw parameters): one wave per 64 consecutive Gaussians walks
+// the B views of the virtual scene (ViewDev) -- per view the partial rows of its (tile, Gaussian) pairs (contiguous per
+// wave, staged through LDS like k_pre_bwd's), the record and the d colour / d direction values of (view, Gaussian), the
+// projection chain rule for that view's camera -- and keeps the sums over the views in registers: dL/dmean, dL/dSigma3D
+// (its push to scale and rotation is linear: done once, behind the view loop), dL/dopacity, and per lane group the 12
+// dL/dSH floats it owns.  The 59 gradient floats of a Gaussian are written ONCE per batch (B single-view launches in
+// accumulate mode read and rewrite 236 bytes per Gaussian and view), zeros when no view sees it; dmeans2D [B,P,3] is per
+// view.  ACC: the sums are added to what the caller's buffers hold (Gaussians that no view sees are left alone).
+// Dynamic LDS: 3 * 64 * B floats (the views' clamped dL/drgb for the dL/dSH phase).
+// ------------------------------------------------------------------------------------------------
+struct PreBwdBatchArgs {
+  int P, g0;              // Gaussians [g0, P) (g0 a multiple of 64); block b owns g0 + 64 b ...
+  int B, Ppad;
+  const ViewDev* vpack;
+  int H, W, deg;
+  float mod;
+  const uint32_t* offg;   // [B * Ppad + 1]
+  const float4* G0;
+  const float4* G1;
+  const float4* G2;
+  const float4* part;
+  uint32_t tag_lo, tag_hi, nsub;
+  const float* means;
+  const float* scales;    // raw: log scales
+  const float* rots;      // raw: un-normalised quaternions
+  const float* D;         // [B * Ppad, 9]
+  float* dmeans3D;
+  float* dmeans2D;        // [B, P, 3] or null
+  float* dsh;             // gradient of _features_rest
+  float* dsh_dc;          // gradient of _features_dc
+  float* dopac;
+  float* dscales;
+  float* drots;
+  float* sumsq;           // ACC = false only, or null: [workgroups][SUMSQ_W] sums of squares of what is written
+};
+
+template <bool GEOM, bool ACC>
+__global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd_batch(PreBwdBatchArgs a) {
+  static_assert(PRE_WAVES == 1, "one wave per workgroup: the LDS arrays below are the wave's own");
+  __shared__ float4 srow[ROW_CHUNK * PART_F4];
+  __shared__ float spos[64 * 3];
+  __shared__ uint32_t sany[64];
+  extern __shared__ float shrgb[];                       // [B][64][3]
+  const int lane = threadIdx.x & 63;
+  const int gw0 = a.g0 + blockIdx.x * PRE_BLOCK;         // first Gaussian of this wave
+  const int g = gw0 + lane;
+  const int nw = min(64, a.P - gw0);
+  if (nw <= 0) return;
+  const bool mine = g < a.P;
+  float p[3] = {0.f, 0.f, 0.f};
+  if (mine) { p[0] = a.means[3 * g]; p[1] = a.means[3 * g + 1]; p[2] = a.means[3 * g + 2]; }
+  spos[3 * lane] = p[0]; spos[3 * lane + 1] = p[1]; spos[3 * lane + 2] = p[2];
+  // view-independent: activated scale / rotation and the 3D covariance
+  // (the activated scale and rotation themselves are formed again behind the view loop, where dL/dSigma3D is pushed through
+  // them: eight registers less across the loop)
+  float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto activated = [&](float sc[3], float q[4], float& inv_qn) {
+    sc[0] = expf(a.scales[3 * g]); sc[1] = expf(a.scales[3 * g + 1]); sc[2] = expf(a.scales[3 * g + 2]);
+    const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    act_normalize4(q, q, inv_qn);
+  };
+  if (GEOM && mine) {
+    float sc[3], q[4], inv_qn;
+    activated(sc, q, inv_qn);
+    cov3d_from_scale_rot(sc, a.mod, q, c6);
+  }
+  float dp[3] = {0.f, 0.f, 0.f}, dc6s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dops = 0.f, opv = 0.f;
+  bool any = false;
+#pragma unroll 1
+  for (int v = 0; v < a.B; ++v) {
+    const size_t o = (size_t)v * (size_t)a.Ppad;
+    const uint32_t* offg = a.offg + o;
+    uint32_t o0 = 0, o1 = 0;
+    if (mine) { o0 = offg[g] * a.nsub; o1 = offg[g + 1] * a.nsub; }
+    const bool has = o1 != o0;
+    float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e2 = e0;
+    if (has) { e0 = a.G0[REC * (o + g)]; e1 = a.G1[REC * (o + g)]; e2 = a.G2[REC * (o + g)]; }
+    // ---- this view's partial rows of the wave's Gaussians (one contiguous span), as in k_pre_bwd -----------------------
+    float dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+    double mx = 0.0, my = 0.0, mxx = 0.0, mxy = 0.0, myy = 0.0;
+    {
+      const uint32_t S = offg[gw0] * a.nsub, E = offg[gw0 + nw] * a.nsub;
+      const bool big = (o1 - o0) > (uint32_t)ROW_CHUNK;
+      for (uint32_t c0 = S; c0 < E; c0 += (uint32_t)ROW_CHUNK) {
+        const uint32_t rows = min((uint32_t)ROW_CHUNK, E - c0);
+        const float4* src = a.part + (size_t)c0 * PART_F4;
+        for (uint32_t i = lane; i < rows * PART_F4; i += 64) srow[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!big) {
+          const uint32_t lo = max(o0, c0), hi = min(o1, c0 + rows);
+          for (uint32_t e = lo; e < hi; ++e) {
+            const float4* r = &srow[(e - c0) * PART_F4];
+            const float4 p0 = r[0], p1 = r[1], p2 = r[2];
+            if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
+            if (GEOM) { mx += (double)p0.x; my += (double)p0.y; mxx += (double)p0.z; mxy += (double)p0.w; myy += (double)p1.x; dop += p1.y; }
+            dr += p1.z; dg += p1.w; db += p2.x;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      uint64_t bm = __ballot(big);
+      while (bm) {                                         // a Gaussian with more rows than a chunk: the whole wave sums it
+        const int L = __ffsll((unsigned long long)bm) - 1;
+        bm &= bm - 1;
+        const uint32_t b0 = __shfl(o0, L, 64), b1 = __shfl(o1, L, 64);
+        float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        double t2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (uint32_t e = b0 + lane; e < b1; e += 64) {
+          const float4 p0 = a.part[(size_t)e * PART_F4], p1 = a.part[(size_t)e * PART_F4 + 1], p2 = a.part[(size_t)e * PART_F4 + 2];
+          if (__float_as_uint(p2.y) != a.tag_lo || __float_as_uint(p2.z) != a.tag_hi) continue;
+          if (GEOM) { t2[3] += (double)p0.x; t2[4] += (double)p0.y; t2[0] += (double)p0.z; t2[1] += (double)p0.w; t2[2] += (double)p1.x; t[5] += p1.y; }
+          t[6] += p1.z; t[7] += p1.w; t[8] += p2.x;
+        }
+#pragma unroll
+        for (int i = 5; i < 9; ++i) t[i] = __shfl(wave_sum_to_hi(t[i]), 63, 64);
+        if (GEOM) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) t2[i] += __shfl_xor(t2[i], sft, 64);
+          }
+        }
+        if (lane == L) { mx = t2[3]; my = t2[4]; mxx = t2[0]; mxy = t2[1]; myy = t2[2]; dop = t[5]; dr = t[6]; dg = t[7]; db = t[8]; }
+      }
+    }
+    // ---- chain rule of this view -------------------------------------------------------------------------------------
+    float hr[3] = {0.f, 0.f, 0.f};
+    if (has) {
+      any = true;
+      const ViewDev& vd = a.vpack[v];
+      const uint32_t cl = clamp_bits_of(e1.z, e1.w, e2.x);
+      hr[0] = (cl & 1u) ? 0.f : dr; hr[1] = (cl & 2u) ? 0.f : dg; hr[2] = (cl & 4u) ? 0.f : db;
+      if (GEOM) {
+        View vw;
+        make_view(vw, vd.vm, vd.pm, vd.cam, a.H, a.W, vd.tanfovx, vd.tanfovy, a.mod, a.deg);
+        const float A = e0.z, Bc = e0.w, C = e1.x;
+        const float dndcx = (float)(-((double)A * mx + (double)Bc * my) * (0.5 * (double)vw.W));
+        const float dndcy = (float)(-((double)Bc * mx + (double)C * my) * (0.5 * (double)vw.H));
+        const double dA = -0.5 * mxx, dB = -mxy, dC = -0.5 * myy;
+        if (a.dmeans2D) {
+          float* m2 = a.dmeans2D + 3 * ((size_t)v * (size_t)a.P + (size_t)g);
+          m2[0] = dndcx; m2[1] = dndcy; m2[2] = 0.f;
+        }
+        dops += dop;
+        opv = e1.y;
+        // view-direction path of dL/dmean (d colour / d direction left by the colour kernel)
+        const float vx = p[0] - vw.cam[0], vy = p[1] - vw.cam[1], vz = p[2] - vw.cam[2];
+        const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+        const float hx = vx * inv, hy = vy * inv, hz = vz * inv;
+        const float* Dg = a.D + 9 * (o + (size_t)g);
+        const float ddx = Dg[0] * hr[0] + Dg[3] * hr[1] + Dg[6] * hr[2];
+        const float ddy = Dg[1] * hr[0] + Dg[4] * hr[1] + Dg[7] * hr[2];
+        const float ddz = Dg[2] * hr[0] + Dg[5] * hr[1] + Dg[8] * hr[2];
+        const float dot = hx * ddx + hy * ddy + hz * ddz;
+        dp[0] += (ddx - hx * dot) * inv;
+        dp[1] += (ddy - hy * dot) * inv;
+        dp[2] += (ddz - hz * dot) * inv;
+        float dc6[6];
+        project_splat_bwd(vw, p, c6, dA, dB, dC, dndcx, dndcy, dp, dc6);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dc6s[i] += dc6[i];
+      }
+    } else if (GEOM && mine && a.dmeans2D) {
+      float* m2 = a.dmeans2D + 3 * ((size_t)v * (size_t)a.P + (size_t)g);
+      m2[0] = 0.f; m2[1] = 0.f; m2[2] = 0.f;
+    }
+    float* hs = shrgb + ((size_t)v * 64 + lane) * 3;
+    hs[0] = hr[0]; hs[1] = hr[1]; hs[2] = hr[2];
+  }
+  sany[lane] = any ? 1u : 0u;
+  // ---- the sums over the views: scale / rotation / opacity through the activations, then the stores ----------------------
+  float ssq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool want_ss = !ACC && a.sumsq != nullptr;
+  auto put = [](float* ptr, float val) { if (ACC) *ptr += val; else *ptr = val; };
+  if (GEOM && mine && (any || !ACC)) {
+    float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (any && (a.dscales || a.drots)) {
+      float sc[3], q[4], inv_qn;
+      activated(sc, q, inv_qn);
+      cov3d_bwd(sc, a.mod, q, dc6s, ds, dq);
+      ds[0] *= sc[0]; ds[1] *= sc[1]; ds[2] *= sc[2];          // d exp(x) = exp(x)
+      act_normalize4_bwd(q, inv_qn, dq, dq);
+    }
+    if (a.dopac) {
+      const float dov = dops * opv * (1.f - opv);              // opv = sigmoid(raw opacity)
+      put(&a.dopac[g], dov);
+      ssq[SUMSQ_OPACITY] = dov * dov;
+    }
+    if (a.dmeans3D) {
+      put(&a.dmeans3D[3 * g], dp[0]); put(&a.dmeans3D[3 * g + 1], dp[1]); put(&a.dmeans3D[3 * g + 2], dp[2]);
+      ssq[SUMSQ_XYZ] = dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2];
+    }
+    if (a.dscales) {
+      put(&a.dscales[3 * g], ds[0]); put(&a.dscales[3 * g + 1], ds[1]); put(&a.dscales[3 * g + 2], ds[2]);
+      ssq[SUMSQ_SCALING] = ds[0] * ds[0] + ds[1] * ds[1] + ds[2] * ds[2];
+    }
+    if (a.drots) {
+      put(&a.drots[4 * g], dq[0]); put(&a.drots[4 * g + 1], dq[1]); put(&a.drots[4 * g + 2], dq[2]); put(&a.drots[4 * g + 3], dq[3]);
+      ssq[SUMSQ_ROTATION] = dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3];
+    }
+  }
+  auto flush_sumsq = [&]() {
+    if (!want_ss) return;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ssq[k] = wave_sum_to_hi(ssq[k]);
+    if (lane == 63) {
+      float* dst = a.sumsq + (size_t)blockIdx.x * SUMSQ_W;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = ssq[k];
+    }
+  };
+  if (a.dsh == nullptr) { flush_sumsq(); return; }
+  // ---- dL/dSH = sum over the views of basis(direction of the view) x dL/drgb of the view: four lanes per Gaussian ---------
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int qd = lane & 3, grp = lane >> 2;
+#pragma unroll 1
+  for (int r0 = 0; r0 < nw; r0 += 16) {
+    const int si = r0 + grp;
+    if (si < nw) {
+      const bool seen = sany[si] != 0u;
+      float out[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) out[j] = 0.f;
+      if (seen) {
+        const float px = spos[3 * si], py = spos[3 * si + 1], pz = spos[3 * si + 2];
+#pragma unroll 1
+        for (int v = 0; v < a.B; ++v) {
+          const float* hs = shrgb + ((size_t)v * 64 + si) * 3;
+          const float g0 = hs[0], g1 = hs[1], g2 = hs[2];
+          const float* cam = a.vpack[v].cam;
+          const float vx = px - cam[0], vy = py - cam[1], vz = pz - cam[2];
+          const float inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+          float b[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) b[k] = 0.f;
+          sh_basis(a.deg, vx * inv, vy * inv, vz * inv, b);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float bj = pick4(qd, b[j], b[4 + j], b[8 + j], b[12 + j]);
+            out[3 * j] = fmaf(bj, g0, out[3 * j]); out[3 * j + 1] = fmaf(bj, g1, out[3 * j + 1]); out[3 * j + 2] = fmaf(bj, g2, out[3 * j + 2]);
+          }
+        }
+      }
+      if (ACC) {
+        if (seen) {
+          float cur[12];
+          load_sh12<true>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), qd, cur);
+#pragma unroll
+          for (int j = 0; j < 12; ++j) out[j] += cur[j];
+          store_sh12<true>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), qd, out);
+        }
+      } else {
+        store_sh12<true>(a.dsh, a.dsh_dc, (uint32_t)(gw0 + si), qd, out);
+        if (want_ss) {
+          const float head = out[0] * out[0] + out[1] * out[1] + out[2] * out[2];
+          float rest = 0.f;
+#pragma unroll
+          for (int j = 3; j < 12; ++j) rest = fmaf(out[j], out[j], rest);
+          ssq[SUMSQ_DC] += qd == 0 ? head : 0.f;
+          ssq[SUMSQ_REST] += qd == 0 ? rest : rest + head;
+        }
+      }
+    }
+  }
+  flush_sumsq();
+}
+
 }  // namespace gsr

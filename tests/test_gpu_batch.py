@@ -32,6 +32,10 @@ def _single_views(model, cams, pipe, bg_of, gcs, scale=1.0):
     pipe = copy.copy(pipe)
     pipe.grad_bucket = bucket
     imgs, radii, vs = [], [], []
+    exact = torch.zeros(59 * P, dtype=torch.float64, device=model.get_xyz.device)   # the views' gradients summed in double
+    own = D.GradBucket(P, model.get_xyz.device)
+    pipe_own = copy.copy(pipe)
+    pipe_own.grad_bucket = own
     for v, cam in enumerate(cams):
         out = render(cam, model, pipe, bg_of(v), scale)
         out["render"].backward(gcs[v])
@@ -39,6 +43,10 @@ def _single_views(model, cams, pipe, bg_of, gcs, scale=1.0):
         radii.append(out["radii"])
         vs.append(out["viewspace_points"].grad.clone() if out["viewspace_points"] is not None and
                   out["viewspace_points"].grad is not None else None)
+        own.reset()
+        render(cam, model, pipe_own, bg_of(v), scale)["render"].backward(gcs[v])
+        exact += own.flat.double()
+    bucket.exact = exact
     return torch.stack(imgs), torch.stack(radii), vs, bucket
 
 
@@ -62,7 +70,7 @@ def _batched(model, cams, pipe, bg, gcs, scale=1.0, per_view_bg=None):
     return out, bucket
 
 
-def _check_equal(model, cams, gcs, bg_list=None, scale=1.0, exact_grads=True):
+def _check_equal(model, cams, gcs, bg_list=None, scale=1.0):
     from gsplat_attack.renderer import PipelineParams
     dev = model.get_xyz.device
     pipe = PipelineParams(skip_objects=True)
@@ -76,11 +84,30 @@ def _check_equal(model, cams, gcs, bg_list=None, scale=1.0, exact_grads=True):
     for v in range(len(cams)):
         assert torch.equal(g[v], vs[v]), f"view {v}: screen-space gradient differs"
     assert b1.used and b2.used
-    if exact_grads:
-        assert torch.equal(b1.flat, b2.flat), "batched attribute gradients differ from the accumulated single-view ones"
-    else:
-        scale_ = b1.flat.abs().max().item()
-        assert (b1.flat - b2.flat).abs().max().item() <= 1e-6 * scale_
+    # The fused per-Gaussian kernel of the batch sums the views in registers and pushes dL/dSigma3D through scale and
+    # rotation once (k_pre_bwd_batch): the same sum in another association -- float32 rounding of a sum of B terms, per
+    # tensor.  (GSR_BATCH_K9=0 runs one k_pre_bwd launch per view instead and is bit-equal to the single-view loop.)
+    import os
+    exact = os.environ.get("GSR_BATCH_K9", "1") == "0"
+    # Yardstick: the B single-view gradients summed in double.  The batch must be no further from that sum than the
+    # float32 accumulation of the single-view loop itself (factor 3), or within `floor` of the tensor's largest gradient.
+    # floor: 1e-5, and 1e-4 for scale and rotation -- the batch pushes the SUM of dL/dSigma3D through scale and rotation once
+    # (k_pre_bwd_batch), the loop pushes every view's share and adds the results: two float32 roundings of one linear map
+    # whose error is ~1e-7 |dL/dSigma3D|, which for an anisotropic splat is 10-100x the scale gradient of its long axis
+    # (tests/diag_batch_err.py: worst element 7e-6 of ITS OWN value off, 4e-6 of the tensor's largest at 60 k Gaussians,
+    # 5e-5 at 1 M).  The per-view values in the double sum carry the loop's rounding of that map, so this comparison
+    # cannot say which of the two is closer to the exact gradient; the oracle comparison below can, at small size.
+    P = b1.P
+    for name, s1, s2, c0, c1 in zip(b1.NAMES, b1.slices(), b2.slices(), b1.CUTS[:-1], b1.CUTS[1:]):
+        if exact:
+            assert torch.equal(s1, s2), f"{name}: batched gradients differ from the accumulated single-view ones"
+        else:
+            ex = b1.exact[c0 * P:c1 * P]
+            scale_ = ex.abs().max().item()
+            e_seq = (s1.double() - ex).abs().max().item()
+            e_bat = (s2.double() - ex).abs().max().item()
+            floor = 1e-4 if name in ("_scaling", "_rotation") else 1e-5
+            assert e_bat <= max(3.0 * e_seq, floor * scale_), f"{name}: batch {e_bat:.3e}, loop {e_seq:.3e}, scale {scale_:.3e}"
     return out, b2
 
 
@@ -102,6 +129,29 @@ def test_small_scene_batch_equals_single_views_and_oracle():
     solid = ~ro.fragile_px
     err = (out["render"][3].detach().cpu().double() - ro.color.detach()).abs().amax(dim=0)[solid].max().item()
     assert err <= 1e-4, err
+    # the batch's summed gradients against oracle-R differentiated in float64 on all five views (dL/dC zero on each view's
+    # fragile pixels, on both sides): BASELINE's 1e-3 per attribute group
+    from util import grad_error
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.renderer import PipelineParams, render_batch
+    leaves = [p_ for p_ in ref.parameters()]
+    for p_ in leaves:
+        p_.grad = None
+    gcs_solid = []
+    for v in range(5):
+        stv = settings_for(rcams[v], torch.tensor([0.1, 0.2, 0.3]))
+        rov = O.rasterize(ref.get_xyz, None, ref.get_opacity, stv, shs=ref.get_features, scales=ref.get_scaling,
+                          rotations=ref.get_rotation)
+        gk = gcs[v].cpu().double() * (~rov.fragile_px).double()
+        (rov.color * gk).sum().backward()
+        gcs_solid.append(gk.float().to(dev))
+    bucket = D.GradBucket(1000, dev)
+    render_batch(cams, model, PipelineParams(skip_objects=True, grad_bucket=bucket),
+                 torch.tensor([0.1, 0.2, 0.3], device=dev))["render"].backward(torch.stack(gcs_solid))
+    views = bucket.views()
+    for name in PARAMS:
+        norm, frac = grad_error(views[name], getattr(ref, name).grad)
+        assert norm <= 1e-3 and frac <= 0.01, (name, norm, frac)
 
 
 @pytest.mark.parametrize("P,W,H,B", [(60_000, 640, 360, 4), (20_001, 333, 190, 3), (70_000, 512, 512, 16), (300, 64, 48, 2)])
