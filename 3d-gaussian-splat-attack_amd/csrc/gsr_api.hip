@@ -709,6 +709,9 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   const uint32_t nk1 = (uint32_t)((Pp + PREG_BLOCK - 1) / PREG_BLOCK);     // workgroups of K1's geometry half (all views)
   const uint32_t nk1v = B > 1 ? (uint32_t)(Ppad / PREG_BLOCK) : nk1;       // ... per view
   const uint32_t nkc = (uint32_t)(((size_t)std::max(P, 1) + PREF_BLOCK - 1) / PREF_BLOCK);   // ... of its colour half, per view
+  // the depth sort: three passes of <= 11 bits (a latency-bound million keys) or four of <= 8 (several million: throughput)
+  static const int depth_passes_env = [] { const char* e = getenv("GSR_DEPTH_PASSES"); int v = e ? atoi(e) : 0; return (v == 3 || v == 4) ? v : 0; }();
+  const int depth_passes = depth_passes_env ? depth_passes_env : (Pp >= (size_t(3) << 20) ? 4 : 3);
   const bool group_sums = nk1 > K1_GROUP_MIN;                              // K2 reads K1's sums through group sums (k_bout_group_sum)
   const uint32_t ngroups = (nk1 + K1_GROUP - 1) / K1_GROUP;
   SlabPlan sp;
@@ -785,9 +788,19 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     // beside the chain: a thin grid (GSR_COLOR_BLOCKS workgroups looping over the chunks); alone: one per chunk
     static const int col_blocks = [] { const char* e = getenv("GSR_COLOR_BLOCKS"); int v = e ? atoi(e) : 512; return v > 0 ? v : 512; }();
     const dim3 gridC(side_used ? std::min<unsigned>(gridCol.x, (unsigned)col_blocks) : gridCol.x);
-    for (int v = 0; v < B; ++v) {
-      if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, color_pa[v]);
-      else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, color_pa[v]);
+    // a batch of views: ONE launch reads every SH row once for all the views that see the Gaussian (GSR_BATCH_COLOR=0:
+    // the single-view kernel once per view -- the A/B form)
+    static const int batch_color_env = [] { const char* e = getenv("GSR_BATCH_COLOR"); return e ? atoi(e) : 1; }();
+    if (B > 1 && raw && batch_color_env != 0) {
+      PreColorBatchArgs ca;
+      ca.P = P; ca.B = B; ca.Ppad = Ppad; ca.deg = s->sh_degree; ca.vpack = c->vpack; ca.means = means3D; ca.sh = shs; ca.sh_dc = sh_dc;
+      ca.tcnt = tcnt; ca.G1 = G1; ca.G2 = G2; ca.D = c->D;
+      hipLaunchKernelGGL(k_pre_color_batch, gridC, blkCol, 0, cs, ca);
+    } else {
+      for (int v = 0; v < B; ++v) {
+        if (raw) hipLaunchKernelGGL((k_pre_color<true>), gridC, blkCol, 0, cs, color_pa[v]);
+        else hipLaunchKernelGGL((k_pre_color<false>), gridC, blkCol, 0, cs, color_pa[v]);
+      }
     }
     if (side_used) F_TRY("side stream", hipEventRecord(side.join, side.side));
     return GSR_OK;
@@ -815,30 +828,35 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       if (c->lanegroup) {
         // (a batch: one launch per view over that view's padded range of the virtual scene -- the same kernels, their
         // per-Gaussian arrays offset by v * Ppad; everything behind K1 then runs once over the B * Ppad virtual Gaussians)
+        // (a batch: ONE launch of the geometry kernel over the B views' padded ranges -- view = workgroup / workgroups per
+        // view; everything behind K1 then runs once over the B * Ppad virtual Gaussians.  The colour kernel still runs once
+        // per view, its per-Gaussian arrays offset by v * Ppad.)
+        PreArgs pa;
+        pa.P = P; pa.Pfill = B > 1 ? Ppad : P; pa.va = va;
+        pa.vpack = B > 1 ? c->vpack : nullptr; pa.bpv = (int)nk1v;
+        pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
+        pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
+        pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt; pa.offg = nullptr;
+        pa.abc = c->abc;
+        pa.Pa = segb ? P - segb->Pb : P;
+        pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
+        pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
+        pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
+        pa.cull = cull; pa.bo = bo;
+        const dim3 gridG(nk1);
+        if (needle_double) {
+          if (raw) hipLaunchKernelGGL((k_pre_geom<true, true>), gridG, blkPre, 0, st, pa);
+          else hipLaunchKernelGGL((k_pre_geom<false, true>), gridG, blkPre, 0, st, pa);
+        } else {
+          if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridG, blkPre, 0, st, pa);
+          else hipLaunchKernelGGL((k_pre_geom<false>), gridG, blkPre, 0, st, pa);
+        }
         for (int v = 0; v < B; ++v) {
           const size_t o = (size_t)v * (size_t)Ppad;
-          PreArgs pa;
-          pa.P = P; pa.Pfill = B > 1 ? Ppad : P; pa.va = view_args(s[v]);
-          pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
-          pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii + (size_t)v * (size_t)P;
-          pa.G0 = G0 + REC * o; pa.G1 = G1 + REC * o; pa.G2 = G2 + REC * o; pa.D = c->D ? c->D + 9 * o : nullptr;
-          pa.dkey = dkey + o; pa.tcnt = tcnt + o; pa.offg = nullptr;
-          pa.abc = c->abc ? c->abc + 3 * o : nullptr;
-          pa.Pa = segb ? P - segb->Pb : P;
-          pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
-          pa.rots_b = segb ? segb->rotation : nullptr; pa.opac_b = segb ? segb->opacity : nullptr;
-          pa.sh_b = segb ? segb->features_rest : nullptr; pa.sh_dc_b = segb ? segb->features_dc : nullptr;
-          pa.cull = cull; pa.bo = bo;
-          pa.bo.bout = bout + (size_t)v * nk1v;
-          if (bo.ranges) pa.bo.ranges = bo.ranges + (size_t)v * (size_t)tpv;
-          if (needle_double) {
-            if (raw) hipLaunchKernelGGL((k_pre_geom<true, true>), gridPre, blkPre, 0, st, pa);
-            else hipLaunchKernelGGL((k_pre_geom<false, true>), gridPre, blkPre, 0, st, pa);
-          } else {
-            if (raw) hipLaunchKernelGGL((k_pre_geom<true>), gridPre, blkPre, 0, st, pa);
-            else hipLaunchKernelGGL((k_pre_geom<false>), gridPre, blkPre, 0, st, pa);
-          }
           color_pa[v] = pa;
+          color_pa[v].va = view_args(s[v]); color_pa[v].vpack = nullptr;
+          color_pa[v].G0 = G0 + REC * o; color_pa[v].G1 = G1 + REC * o; color_pa[v].G2 = G2 + REC * o;
+          color_pa[v].D = c->D ? c->D + 9 * o : nullptr; color_pa[v].tcnt = tcnt + o;
         }
         want_color = !colors_precomp;
         if (want_color && !fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
@@ -858,7 +876,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       c->fwd_stream = st;
       if (group_sums) hipLaunchKernelGGL(k_bout_group_sum, dim3(ngroups), dim3(K1_GROUP), 0, st, (const uint4*)bout, nk1, gsum);
       hipLaunchKernelGGL(k_storage_scan_hist, dim3(nbP), blk, 0, st, (uint32_t)Pv, (const uint32_t*)tcnt, (const uint32_t*)dkey,
-                         (const uint4*)bout, (const uint4*)gsum, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token);
+                         (const uint4*)bout, (const uint4*)gsum, c->offg, table, nbP, c->dv, cap_pairs, c->slot.dev, c->slot.token,
+                         (uint32_t)depth_passes);
       F_LAUNCH("preprocess");
     }
     {
@@ -868,12 +887,24 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       // histogram came from k_storage_scan_hist), the last pass also gathers cnt[r] = tiles touched by rank r.
       const uint32_t* nV = c->dv + DV_V;
       DigitSpec d0{c->dv, 0, 0, 0u}, d1{c->dv, 1, 0, 0u}, d2{c->dv, 2, 0, 0u};
+      if (depth_passes == 4) {
+        // millions of keys (a batch of views, a large scene): four passes of <= 8 bits through the 256-bin kernels; passes
+        // 1-3 in the chunk size the tile sort would pick for that many keys
+        DigitSpec d3{c->dv, 3, 0, 0u};
+        const int rn = radix_rounds_for((uint32_t)Pv);
+        radix_pass<RS_BINS>(dkey, nullptr, k1, vtmp, (uint32_t)Pv, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
+                            c->dv + DV_V, nullptr, nullptr, st);
+        radix_pass<RS_BINS>(k1, vtmp, dkey, v2, (uint32_t)Pv, nV, d1, rn, table, tsums, true, 0, 0, nullptr, nullptr, nullptr, st);
+        radix_pass<RS_BINS>(dkey, v2, k1, vtmp, (uint32_t)Pv, nV, d2, rn, table, tsums, true, 0, 0, nullptr, nullptr, nullptr, st);
+        radix_pass<RS_BINS>(k1, vtmp, nullptr, c->order, (uint32_t)Pv, nV, d3, rn, table, tsums, true, 0, 0, nullptr, tcnt, v2, st);
+      } else {
       radix_pass<RS_BINS_DEV>(dkey, nullptr, k1, vtmp, (uint32_t)Pv, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
                               c->dv + DV_V, nullptr, nullptr, st);
       radix_pass<RS_BINS_DEV>(k1, vtmp, dkey, v2, (uint32_t)Pv, nV, d1, DROUNDS, table, tsums, true, 0, 0, nullptr, nullptr,
                               nullptr, st);
       radix_pass<RS_BINS_DEV>(dkey, v2, nullptr, c->order, (uint32_t)Pv, nV, d2, DROUNDS, table, tsums, true, 0, 0, nullptr,
                               tcnt, vtmp, st);
+      }
       F_LAUNCH("depth sort");
     }
     if (want_color && fork_late) { const int rcol = launch_color(); if (rcol != GSR_OK) return rcol; }
@@ -923,7 +954,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       // (two launches: block sums, then carry + local scan.  Round 3's one-launch variant, in which a block waited for its
       // predecessors' published sums, saved 2.4 us and could, in principle, give up waiting with nothing but a poisoned
       // image to show for it: removed)
-      scan_exclusive_u32(vtmp, c->off, (uint32_t)Pv, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
+      scan_exclusive_u32(depth_passes == 4 ? v2 : vtmp, c->off, (uint32_t)Pv, c->dv + DV_V, psums, st, chunk_first, (uint32_t)EMIT_GRAIN, ngrain);
       F_LAUNCH("rank scan");
       int sh0; uint32_t mask0;
       radix_first_digit(tile_bits, sh0, mask0);

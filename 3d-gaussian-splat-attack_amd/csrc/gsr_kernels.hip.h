@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uin
                                                            uint32_t* __restrict__ offg,
                                                            uint32_t* __restrict__ table, uint32_t nb,
                                                            uint32_t* __restrict__ dv, unsigned long long cap,
-                                                           uint32_t* host_slot, uint32_t host_token) {
+                                                           uint32_t* host_slot, uint32_t host_token, uint32_t npass) {
   __shared__ uint32_t tmp[4];
   __shared__ unsigned long long tmp64[4];
   __shared__ uint32_t h[RS_BINS_DEV];
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uin
   uint32_t carry;
   block_excl_scan_256(part, tmp, carry);
   const uint32_t kmin = block_min_u32(mn, tmp), kmax = block_max_u32(mx, tmp);
-  const uint32_t w = depth_digit_width(kmin, kmax), mask = (1u << w) - 1u, nbins = 1u << w;
+  const uint32_t w = depth_digit_width(kmin, kmax, npass), mask = (1u << w) - 1u, nbins = 1u << w;
   for (uint32_t d = tid; d < nbins; d += 256) h[d] = 0;
   __syncthreads();
   uint32_t sum = 0;
@@ -1708,6 +1708,8 @@ struct PreArgs {
   const float* sh_b;
   const float* sh_dc_b;
   int Pfill;              // >= P (a view of a batch: the view's padded range, see ViewDev): Gaussians [P, Pfill) emit nothing
+  const ViewDev* vpack;   // k_pre_geom over a batch of views in one launch (else null): see there
+  int bpv;                // ... its workgroups per view (Pfill / PREG_BLOCK)
   int32_t* radii;
   float4* G0;
   float4* G1;
@@ -1735,11 +1737,20 @@ __device__ __forceinline__ uint32_t clamp_bits_of(float r, float g, float b) {
 // scan starts from.  Reads 44 bytes per Gaussian.  With precomputed colours it writes those too (nothing else to do).
 template <bool RAW, bool NDL = false>
 __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
-  const int g = blockIdx.x * PREG_BLOCK + threadIdx.x;
+  // A batch of views in ONE launch (a.vpack != null; ViewDev): view = block / bpv, the block's Gaussians are those of that
+  // view's padded range; the per-view arrays (records, keys, counts, needle marks) are indexed at vo + g, radii at view * P + g.
+  const int view = a.vpack != nullptr ? (int)(blockIdx.x / (uint32_t)a.bpv) : 0;
+  const int g = (int)(blockIdx.x - (uint32_t)(view * a.bpv)) * PREG_BLOCK + threadIdx.x;
+  const size_t vo = (size_t)view * (size_t)a.bpv * PREG_BLOCK;
   uint32_t cnt = 0, key = 0xFFFFFFFFu;
   if (g < a.P) {
     View v;
-    load_view(v, a.va);
+    if (a.vpack != nullptr) {
+      const ViewDev& vd = a.vpack[view];
+      make_view(v, vd.vm, vd.pm, vd.cam, a.va.H, a.va.W, vd.tanfovx, vd.tanfovy, a.va.mod, a.va.deg);
+    } else {
+      load_view(v, a.va);
+    }
     const bool second = g >= a.Pa;                       // which attribute segment this Gaussian lives in
     const int gl = second ? g - a.Pa : g;
     const float* means = second ? a.means_b : a.means;
@@ -1763,7 +1774,7 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     }
     Splat s;
     const bool vis = project_splat(v, p, c6, s);
-    a.radii[g] = vis ? s.radius : 0;                     // the reference's radius, whatever the footprint test says
+    a.radii[(size_t)view * (size_t)a.P + g] = vis ? s.radius : 0;                     // the reference's radius, whatever the footprint test says
     if (vis) {
       const float oraw = second ? a.opac_b[gl] : a.opac[gl];
       const float op = RAW ? act_sigmoid(oraw) : oraw;
@@ -1777,7 +1788,7 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
         cov2d_accurate(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, ca, cb, cc);
         needle_conic_to_float(ca, cb, cc, s.A, s.B, s.C);
       }
-      if (NDL && a.abc) a.abc[3 * (size_t)g] = ndl ? ca : __longlong_as_double(0x7FF8000000000000ll);   // K9's needle mark
+      if (NDL && a.abc) a.abc[3 * (vo + (size_t)g)] = ndl ? ca : __longlong_as_double(0x7FF8000000000000ll);   // K9's needle mark
       const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (a.cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, op, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
       s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
@@ -1786,12 +1797,12 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
         key = __float_as_uint(s.depth);
         const uint32_t rx = (uint32_t)s.rminx | ((uint32_t)s.rmaxx << 12) | ((uint32_t)(s.rminx - fminx) << 24);
         const uint32_t ry = (uint32_t)s.rminy | ((uint32_t)s.rmaxy << 12) | ((uint32_t)(s.rminy - fminy) << 24);
-        a.G0[REC * g] = make_float4((float)(s.pxd - (double)(fminx * TILE)), (float)(s.pyd - (double)(fminy * TILE)), s.A, s.B);
-        float* g1 = reinterpret_cast<float*>(&a.G1[REC * g]);
-        float* g2 = reinterpret_cast<float*>(&a.G2[REC * g]);
+        a.G0[REC * (vo + g)] = make_float4((float)(s.pxd - (double)(fminx * TILE)), (float)(s.pyd - (double)(fminy * TILE)), s.A, s.B);
+        float* g1 = reinterpret_cast<float*>(&a.G1[REC * (vo + g)]);
+        float* g2 = reinterpret_cast<float*>(&a.G2[REC * (vo + g)]);
         if (a.colors) {
-          a.G1[REC * g] = make_float4(s.C, op, a.colors[3 * g], a.colors[3 * g + 1]);
-          a.G2[REC * g] = make_float4(a.colors[3 * g + 2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
+          a.G1[REC * (vo + g)] = make_float4(s.C, op, a.colors[3 * g], a.colors[3 * g + 1]);
+          a.G2[REC * (vo + g)] = make_float4(a.colors[3 * g + 2], s.depth, __uint_as_float(rx), __uint_as_float(ry));
         } else {
           *reinterpret_cast<float2*>(g1) = make_float2(s.C, op);
           g2[1] = s.depth;
@@ -1799,13 +1810,15 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
         }
       }
     }
-    a.dkey[g] = key;
-    a.tcnt[g] = cnt;
+    a.dkey[vo + g] = key;
+    a.tcnt[vo + g] = cnt;
   } else if (g < a.Pfill) {
-    a.dkey[g] = 0xFFFFFFFFu;
-    a.tcnt[g] = 0u;
+    a.dkey[vo + g] = 0xFFFFFFFFu;
+    a.tcnt[vo + g] = 0u;
   }
-  pre_block_epilogue(a.bo, g, cnt, key);
+  PreBlockOut bo = a.bo;
+  if (bo.ranges != nullptr) bo.ranges += (size_t)view * (size_t)bo.ntiles;     // this view's tiles
+  pre_block_epilogue(bo, g, cnt, key);
 }
 
 // K1, colour half: SH -> RGB for the Gaussians that emit pairs, by FOUR LANES per Gaussian (see above), + d colour /
@@ -1891,6 +1904,110 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color(PreArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slots are rewritten by the next chunk
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+
+// K1, colour half, for a BATCH of views (ViewDev; raw parameters): the 192-byte SH row of a Gaussian that emits pairs in ANY
+// view is read ONCE, by its four lanes, and evaluated for every view that sees it -- the view's camera position is a scalar
+// load, the colour words go to the record of (view, Gaussian), the nine d colour / d direction values next to them.  B
+// single-view launches read the rows of the 66 % visible Gaussians B times: 1.0 GB per 8-view batch of S-nyc-1M, 0.17 GB here.
+struct PreColorBatchArgs {
+  int P, B, Ppad, deg;
+  const ViewDev* vpack;
+  const float* means;
+  const float* sh;        // _features_rest [P,15,3]
+  const float* sh_dc;     // _features_dc [P,1,3]
+  const uint32_t* tcnt;   // [B * Ppad] tiles touched by (view, Gaussian)
+  float4* G1;             // records of the virtual scene (G0 + 1, G0 + 2)
+  float4* G2;
+  float* D;               // [B * Ppad, 9] or null
+};
+__global__ void __launch_bounds__(PREF_BLOCK) k_pre_color_batch(PreColorBatchArgs a) {
+  __shared__ float slots[PREF_WAVES * 64 * 4];
+  __shared__ uint32_t smask[PREF_WAVES * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ws = &slots[wave * 64 * 4];
+  uint32_t* wm = &smask[wave * 64];
+  for (int chunk = blockIdx.x; chunk * PREF_BLOCK < a.P; chunk += gridDim.x) {
+    const int g = chunk * PREF_BLOCK + wave * 64 + lane;
+    uint32_t seen = 0;                                     // bit v: view v has pairs of this Gaussian
+    if (g < a.P) {
+#pragma unroll 4
+      for (int v = 0; v < a.B; ++v) seen |= (a.tcnt[(size_t)v * (size_t)a.Ppad + g] != 0u ? 1u : 0u) << v;
+    }
+    const bool ok = seen != 0u;
+    const uint64_t live = __ballot(ok);
+    const int nlive = __popcll(live);
+    if (nlive == 0) continue;
+    if (ok) {
+      const int si = __popcll(live & ((1ull << lane) - 1ull));
+      float* sl = ws + 4 * si;
+      sl[0] = a.means[3 * g]; sl[1] = a.means[3 * g + 1]; sl[2] = a.means[3 * g + 2]; sl[3] = __uint_as_float((uint32_t)g);
+      wm[si] = seen;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int q = lane & 3, grp = lane >> 2;
+    for (int r0 = 0; r0 < nlive; r0 += 16) {
+      const int si = r0 + grp;
+      if (si < nlive) {
+        const float4 slv = *reinterpret_cast<const float4*>(ws + 4 * si);
+        const uint32_t gg = __float_as_uint(slv.w);
+        const uint32_t mv = wm[si];
+        float sv[12];
+        load_sh12<true>(a.sh, a.sh_dc, gg, q, sv);
+#pragma unroll 1
+        for (int v = 0; v < a.B; ++v) {
+          if (!((mv >> v) & 1u)) continue;
+          const float* cam = a.vpack[v].cam;
+          const float dx = slv.x - cam[0], dy = slv.y - cam[1], dz = slv.z - cam[2];
+          const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+          const float x = dx * inv, y = dy * inv, z = dz * inv;
+          float b[16], gx[16], gy[16], gz[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) b[k] = 0.f;
+          sh_basis(a.deg, x, y, z, b);
+          float bs[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bs[j] = pick4(q, b[j], b[4 + j], b[8 + j], b[12 + j]);
+          float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { c0 = fmaf(bs[j], sv[3 * j], c0); c1 = fmaf(bs[j], sv[3 * j + 1], c1); c2 = fmaf(bs[j], sv[3 * j + 2], c2); }
+          c0 = quad_sum(c0) + 0.5f; c1 = quad_sum(c1) + 0.5f; c2 = quad_sum(c2) + 0.5f;
+          const size_t rec = (size_t)v * (size_t)a.Ppad + gg;
+          if (a.D) {
+            sh_basis_grad(a.deg, x, y, z, gx, gy, gz);
+            float d[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // d[3c + axis]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float ex = pick4(q, gx[j], gx[4 + j], gx[8 + j], gx[12 + j]);
+              const float ey = pick4(q, gy[j], gy[4 + j], gy[8 + j], gy[12 + j]);
+              const float ez = pick4(q, gz[j], gz[4 + j], gz[8 + j], gz[12 + j]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                d[3 * c] = fmaf(ex, sv[3 * j + c], d[3 * c]);
+                d[3 * c + 1] = fmaf(ey, sv[3 * j + c], d[3 * c + 1]);
+                d[3 * c + 2] = fmaf(ez, sv[3 * j + c], d[3 * c + 2]);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) d[i] = quad_sum(d[i]);
+            if (q < 3) {
+              const float dx_ = pick4(q, d[0], d[3], d[6], 0.f), dy_ = pick4(q, d[1], d[4], d[7], 0.f),
+                          dz_ = pick4(q, d[2], d[5], d[8], 0.f);
+              *reinterpret_cast<F3u*>(a.D + rec * 9 + 3 * q) = F3u{dx_, dy_, dz_};
+            }
+          }
+          if (q == 0) *reinterpret_cast<float2*>(reinterpret_cast<float*>(&a.G1[REC * rec]) + 2) = make_float2(clamp_flagged(c0), clamp_flagged(c1));
+          else if (q == 1) *reinterpret_cast<float*>(&a.G2[REC * rec]) = clamp_flagged(c2);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the slots are rewritten by the next chunk
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 

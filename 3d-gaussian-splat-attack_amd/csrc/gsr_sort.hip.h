@@ -206,10 +206,12 @@ __device__ __forceinline__ void resolve_digit(const DigitSpec& s, int& shift, ui
   }
 }
 
-// The depth keys' digit width from their range: three passes of w bits cover max - min.
-__device__ __forceinline__ uint32_t depth_digit_width(uint32_t kmin, uint32_t kmax) {
+// The depth keys' digit width from their range: `npass` passes of w bits cover max - min (three passes: w <= 11, the
+// 2048-bin kernels; four passes: w <= 8, the 256-bin kernels -- what a sort of several million keys runs faster with:
+// longer digit runs per block, a third of the LDS, seven waves per SIMD instead of two).
+__device__ __forceinline__ uint32_t depth_digit_width(uint32_t kmin, uint32_t kmax, uint32_t npass = 3u) {
   const uint32_t bits = kmax > kmin ? 32u - (uint32_t)__clz(kmax - kmin) : 1u;
-  return max(4u, (bits + 2u) / 3u);      // <= 11 for 32-bit keys; at least 16 bins so that tiny ranges stay sane
+  return max(4u, (bits + npass - 1u) / npass);   // at least 16 bins so that tiny ranges stay sane
 }
 
 template <int RS_ROUNDS, int BINS>

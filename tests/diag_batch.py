@@ -19,6 +19,7 @@ def main():
     scene = sys.argv[1] if len(sys.argv) > 1 else "nyc-1M"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    only = sys.argv[4] if len(sys.argv) > 4 else ""
     dev = torch.device("cuda:0")
     model, cams, spec = make_scene(scene, device=dev, n_views=max(B, 8))
     cams = cams[:B]
@@ -40,6 +41,8 @@ def main():
         render_batch(cams, model, pipe, bg)["render"].backward(gcb)
 
     for name, fn in (("sequential", seq), ("batched", bat)):
+        if only and name != only:
+            continue
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
