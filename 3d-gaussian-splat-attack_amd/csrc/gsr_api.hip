@@ -1015,8 +1015,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       (void)hipGetLastError();
       return e == hipSuccess ? SCHED_LDS_TILES : SCHED_LDS_TILES_DEFAULT;
     }();
-    hipLaunchKernelGGL(k_tile_schedule, dim3(c->segoff ? 2 : 1), dim3(1024), sched_lds_bytes(ntiles, sched_lds_cap), st, ntiles,
-                       sched_lds_cap, c->ranges, c->sched, c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC);
+    hipLaunchKernelGGL(k_tile_schedule, dim3((c->segoff ? 2 : 1) * B), dim3(1024), sched_lds_bytes(tpv, sched_lds_cap), st, tpv,
+                       sched_lds_cap, c->ranges, c->sched, c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC, B);
     F_LAUNCH("tile schedule");
     const int rk6 = launch_render_fwd(c, out_color, out_objects, st);
     if (rk6 != GSR_OK) return fail(rk6);

@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(256) k_storage_scan_hist(uint32_t P, const uin
       const bool ovf = n64 > cap;
       dv[DV_N] = ovf ? 0u : (uint32_t)n64;
       dv[DV_KMIN] = kmin; dv[DV_W] = w; dv[DV_OVF] = ovf ? 1u : 0u;
+      dv[DV_NREC] = 0u;                                      // (a batch's tile schedule counts the boundary records up from here)
       dv[DV_N64] = (uint32_t)n64; dv[DV_N64 + 1] = (uint32_t)(n64 >> 32);
       if (host_slot) {
         // pinned, device-mapped host memory: count and flag first, then -- behind a system-scope fence -- the token the
@@ -602,15 +603,26 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* w
 // raised (gfx950: 160 KB per workgroup), SCHED_LDS_TILES_DEFAULT otherwise; tiles beyond it are re-read from `ranges`.
 constexpr int SCHED_LDS_TILES_DEFAULT = 23552;       // 46 KB of 16-bit lengths + the 16 KB histogram + scalars < 64 KB
 inline size_t sched_lds_bytes(int ntiles, int lds_cap) { return 2u * (size_t)((std::min(ntiles, lds_cap) + 7) & ~7); }
+// A batch of B views (ViewDev): the launch has B workgroups per role -- workgroup = (role, view) -- each working on its view's
+// `ntiles` tiles [view * ntiles, (view + 1) * ntiles) exactly as the single-view launch does on its image; the B
+// longest-first orders are interleaved (rank r of view v goes to position r * B + v: the views of one scene have similar
+// length distributions, and only the order of the last few rounds of waves matters), priorities are relative to the view's
+// own longest list, and the boundary records of a view's split tiles are numbered from a base the view takes from the shared
+// counter *nrec_out by one atomic add (the caller -- K2 -- zeroed it; records need unique ranges, not tile order).
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
-                                                        uint32_t rec_cap, uint32_t* __restrict__ nrec_out) {
+                                                        uint32_t rec_cap, uint32_t* __restrict__ nrec_out, int B) {
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
+  __shared__ uint32_t sbase;
   extern __shared__ unsigned short slen[];
   const int t = threadIdx.x, lane = t & 63;
+  const int view = (int)(blockIdx.x % (uint32_t)B), role = (int)(blockIdx.x / (uint32_t)B);
+  const int tile0 = view * ntiles;                       // this workgroup's tiles: tile0 + [0, ntiles)
+  ranges += tile0;
+  if (segoff != nullptr) segoff += tile0;
   const int lds_tiles = min(ntiles, lds_cap);
   // list length of tile i, exact (segment plan) / clamped to 65535 (bins and priorities: both saturate far below)
   auto tile_len = [&](int i) -> uint32_t {
@@ -626,10 +638,10 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap,
     const uint2 r = ranges[i];
     return min(r.y - r.x, 0xFFFFu);
   };
-  // Two workgroups when tiles can be split (segoff != null): block 0 makes the schedule, block 1 the segment plan --
+  // Two roles when tiles can be split (segoff != null): role 0 makes the schedule, role 1 the segment plan --
   // both from the list lengths, which each reads for itself (two CUs instead of one workgroup's phases back to back).
-  const bool do_sched = blockIdx.x == 0;
-  const bool do_plan = segoff != nullptr && blockIdx.x == gridDim.x - 1;
+  const bool do_sched = role == 0;
+  const bool do_plan = segoff != nullptr && role == (int)(gridDim.x / (uint32_t)B) - 1;
 #pragma unroll
   for (int k = 0; k < SCHED_BINS / 1024; ++k) hist[t + k * 1024] = 0;
   if (t == 0) smax = 0;
@@ -688,7 +700,7 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap,
       const int i = i0 + k * 1024;
       if (i < ntiles) {
         const uint32_t prio = min(3u, (uint32_t)((float)len[k] * prio_scale));    // 0..3: length relative to the longest list
-        sched[p[k]] = (uint32_t)i | (prio << 28);
+        sched[(size_t)p[k] * (size_t)B + view] = (uint32_t)(tile0 + i) | (prio << 28);
       }
     }
   }
@@ -708,6 +720,11 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap,
     }
   uint32_t total;
   uint32_t run = block_excl_scan_1024(mine, wsum, total);
+  if (B > 1) {                                             // a batch: this view's records start at a base of its own
+    if (t == 0) sbase = atomicAdd(nrec_out, total);
+    __syncthreads();
+    run += sbase;
+  }
   for (int i = i_lo; i < i_hi; ++i) {
     const uint32_t len = tile_len(i);
     uint32_t nseg = 0;
@@ -715,13 +732,13 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap,
     uint32_t off = SEG_NONE;
     if (nseg != 0u && run + nseg <= rec_cap) {
       off = run;
-      for (uint32_t j = 1; j < nseg; ++j) rec_item[run + j - 1u] = make_uint2((uint32_t)i, j);
-      rec_item[run + nseg - 1u] = make_uint2((uint32_t)i, 0u);
+      for (uint32_t j = 1; j < nseg; ++j) rec_item[run + j - 1u] = make_uint2((uint32_t)(tile0 + i), j);
+      rec_item[run + nseg - 1u] = make_uint2((uint32_t)(tile0 + i), 0u);
     }
     segoff[i] = off;
     run += nseg;
   }
-  if (t == 0) *nrec_out = min(total, rec_cap);
+  if (B == 1 && t == 0) *nrec_out = min(total, rec_cap);
 }
 __device__ __forceinline__ void set_wave_priority(uint32_t prio) {
   if (prio == 3u) __builtin_amdgcn_s_setprio(3);
