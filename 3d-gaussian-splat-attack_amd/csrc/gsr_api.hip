@@ -366,10 +366,12 @@ static hipStream_t comp_enter(int dev, hipStream_t st, CompStream& cs, bool& use
   }
   return cs.comp;
 }
-static void comp_leave(hipStream_t st, const CompStream& cs, bool used) {
-  if (!used) return;
-  (void)hipEventRecord(cs.out, cs.comp);
-  (void)hipStreamWaitEvent(st, cs.out, 0);
+// (false: the join failed -- the caller's stream is NOT ordered behind the compositor stream, which is an error to report)
+static bool comp_leave(hipStream_t st, const CompStream& cs, bool used) {
+  if (!used) return true;
+  const bool ok = hipEventRecord(cs.out, cs.comp) == hipSuccess && hipStreamWaitEvent(st, cs.out, 0) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  return ok;
 }
 
 // Count slots of forwards whose context was released before the copy landed (forward-only calls with an asynchronous
@@ -470,7 +472,7 @@ struct GsrCtx {
   size_t keep_bytes = 0;
   float4 *G0 = nullptr, *G1 = nullptr, *G2 = nullptr;   // splat records, storage order (the compositors gather them)
   float* D = nullptr;             // [P,9] d rgb / d view direction (lane-group kernels, SH input, backward expected)
-  double* abc = nullptr;          // [P,3] the dilated 2D covariance from the double chain (K1 -> K9; backward expected)
+  double* abc = nullptr;          // [P] needle marks under GSR_FLAG_NEEDLE_DOUBLE (K1 -> K9; backward expected)
   bool lanegroup = false;         // K1 ran as k_pre_geom + k_pre_color: K8+K9 runs as k_pre_bwd
   uint32_t *order = nullptr, *off = nullptr, *offg = nullptr, *pair_rank = nullptr;
   uint2* ranges = nullptr;
@@ -603,7 +605,10 @@ static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hi
   } else {
     if (out_objects) {
       hipError_t e = hipMemsetAsync(out_objects, 0, sizeof(float) * NUM_OBJ * HW, st);
-      if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "objects: %s", hipGetErrorString(e));
+      if (e != hipSuccess) {
+        (void)comp_leave(st_main, comp_s, comp_used);
+        return set_err(GSR_ERR_DEVICE, "objects: %s", hipGetErrorString(e));
+      }
     }
     if (fwd_npx == 4) hipLaunchKernelGGL((k_render_fwd<false, 4>), gridT, blkT, 0, st, ra);
     else if (fwd_npx == 2 && k6_shared) hipLaunchKernelGGL((k_render_fwd<false, 2, 2>), gridS, blkS2, 0, st, ra);
@@ -612,8 +617,9 @@ static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hi
     else hipLaunchKernelGGL((k_render_fwd<false, 1>), gridT, blkT, 0, st, ra);
   }
   hipError_t e = hipGetLastError();
-  comp_leave(st_main, comp_s, comp_used);
+  const bool joined = comp_leave(st_main, comp_s, comp_used);
   if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "render forward: launch failed: %s", hipGetErrorString(e));
+  if (!joined) return set_err(GSR_ERR_DEVICE, "render forward: joining the compositor stream failed");
   return GSR_OK;
 }
 
@@ -700,7 +706,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   if (want_D) kp.add<float>(9 * Pp);
   const bool needle_double = (s->flags & GSR_FLAG_NEEDLE_DOUBLE) != 0u;
   const bool want_abc = needle_double && c->lanegroup && ctx_out != nullptr && !fwd_only;
-  if (want_abc) kp.add<double>(3 * Pp);
+  if (want_abc) kp.add<double>(Pp);
   if (B > 1) kp.add<ViewDev>((size_t)B);
   c->keep_bytes = kp.bytes + 256;
   c->keep_blk = pool_alloc(dev, c->keep_bytes, st);
@@ -732,7 +738,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   c->dv = ks.take<uint32_t>(DV_WORDS);
   c->sched = ks.take<uint32_t>(ntiles);
   if (want_D) c->D = ks.take<float>(9 * Pp);
-  if (want_abc) c->abc = ks.take<double>(3 * Pp);
+  if (want_abc) c->abc = ks.take<double>(Pp);
   if (B > 1) c->vpack = ks.take<ViewDev>((size_t)B);
   Slab ss{static_cast<char*>(scratch_blk), sp.bytes + 256, 0};
   float4* G0 = c->G0; float4* G1 = c->G1; float4* G2 = c->G2;
@@ -1150,6 +1156,7 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
   // every argument check has passed: only now does the kept context take the call's pointers and follow its stream (a
   // rejected call leaves the context exactly as it was)
   pool_retag(c->dev, c->keep_blk, st); pool_retag(c->dev, c->rank_blk, st); pool_retag(c->dev, c->seg_blk, st);
+  c->sumsq_out = nullptr;                // a request armed for a backward of the previous render does not carry over
   if (features_rest) c->shs = features_rest;
   if (features_dc) c->sh_dc = features_dc;
   if (features_rest_b) c->b.features_rest = features_rest_b;
@@ -1181,11 +1188,20 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
 
 }  // extern "C"
 
+static bool batch_k9_fused() {
+  static const int env = [] { const char* e = getenv("GSR_BATCH_K9"); return e ? atoi(e) : 1; }();
+  return env != 0;
+}
+
 static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
                          float* dshs, float* dsh_dc, float* dsh_objs, float* dcolors_precomp, float* dopacities,
                          float* dscales, float* drotations, float* dcov3D, void* stream, bool accumulate = false,
                          int nchunks = 1, gsr_chunk_fn chunk_done = nullptr, void* chunk_user = nullptr) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_backward: null context");
+  // gsr_ctx_request_sumsq is one-shot: the request is taken (and the context disarmed) here, whatever this call's fate --
+  // a backward that fails early must not leave the next one writing six doubles to a buffer that may be gone by then
+  double* ss_out = c->sumsq_out;
+  c->sumsq_out = nullptr;
   if (!grad_color) return set_err(GSR_ERR_INVALID, "gsr_backward: grad_color is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int dev = c->dev;
@@ -1278,8 +1294,9 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     }
 #undef LAUNCH_K7
     hipError_t e = hipGetLastError();
-    comp_leave(st, comp_s, comp_used);
+    const bool joined = comp_leave(st, comp_s, comp_used);
     if (e != hipSuccess) return done(set_err(GSR_ERR_DEVICE, "render backward: launch failed: %s", hipGetErrorString(e)));
+    if (!joined) return done(set_err(GSR_ERR_DEVICE, "render backward: joining the compositor stream failed"));
   }
   {
     StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
@@ -1310,12 +1327,9 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     const int per = (((P + nchunks - 1) / nchunks) + 63) / 64 * 64;
     // gsr_ctx_request_sumsq (one-shot): the overwriting raw-parameter kernel also leaves per-workgroup sums of squares of
     // what it writes; one small launch behind it adds them up per tensor (fixed order) into the caller's six doubles
-    double* ss_out = c->sumsq_out;
-    c->sumsq_out = nullptr;
     // a batch of views: ONE launch of k_pre_bwd_batch per range walks the B views and writes the gradients once
     // (GSR_BATCH_K9=0: one k_pre_bwd launch per view instead, the others in accumulate mode -- the A/B and the bit-exact form)
-    static const int batch_k9_env = [] { const char* e = getenv("GSR_BATCH_K9"); return e ? atoi(e) : 1; }();
-    const bool batch_fused = c->B > 1 && c->raw && c->lanegroup && batch_k9_env != 0;
+    const bool batch_fused = c->B > 1 && c->raw && c->lanegroup && batch_k9_fused();
     void* ss_blk = nullptr;
     const int ss_blocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
     pa.sumsq = nullptr;
@@ -1355,7 +1369,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
         if (c->B > 1) {
           pa.va = view_args(c->views[v]);
           pa.offg = c->offg + o; pa.G0 = c->G0 + REC * o; pa.G1 = c->G1 + REC * o; pa.G2 = c->G2 + REC * o;
-          pa.D = c->D ? c->D + 9 * o : nullptr; pa.abc = c->abc ? c->abc + 3 * o : nullptr;
+          pa.D = c->D ? c->D + 9 * o : nullptr; pa.abc = c->abc ? c->abc + o : nullptr;
           pa.dmeans2D = dmeans2D ? dmeans2D + 3 * (size_t)v * (size_t)P : nullptr;
           pa.accumulate = acc_v ? 1 : 0;
         }
@@ -1531,6 +1545,8 @@ int gsr_ctx_request_sumsq(GsrCtx* c, double* out6) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_request_sumsq: null context");
   if (!c->raw || !c->lanegroup)
     return set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: only contexts of gsr_forward_raw (raw parameters) produce the sums");
+  if (c->B > 1 && !batch_k9_fused())
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_request_sumsq: a batch context under GSR_BATCH_K9=0 runs one accumulating launch per view");
   c->sumsq_out = out6;
   return GSR_OK;
 }

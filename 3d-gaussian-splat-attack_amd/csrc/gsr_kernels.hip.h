@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
     if (ok) {
       const float o = opac[g];
       if ((cull & 2) && is_needle(s.ca, s.cb, s.cc)) {       // cull bit 1: GSR_FLAG_NEEDLE_DOUBLE
-        // a needle's conic (compositors and footprint tests): the same chain in double (gsr_math.h conic_accurate)
+        // a needle's conic (compositors and footprint tests): the same chain in double (gsr_math.h cov2d_accurate)
         float scd[3] = {0.f, 0.f, 0.f}, qd[4] = {0.f, 0.f, 0.f, 0.f};
         if (!cov3d) {
           scd[0] = scales[3 * g]; scd[1] = scales[3 * g + 1]; scd[2] = scales[3 * g + 2];
@@ -1209,9 +1209,9 @@ __global__ void __launch_bounds__(64, (!OBJ && NPX == 4) ? 6 : 1) k_render_bwd(R
   }
   const bool clocked = a.wave_clock != nullptr && seg == 0u;
   if (clocked && lane == 0) a.wave_clock[2 * item] = wall_clock64();
-  // Where this lane parks its partials: a register is eight 8-float chunks at a stride of 12 floats (bank starts
-  // 0,12,24,4,16,28,8,20): the even chunks cover the 32 banks exactly once and so do the odd ones, so lanes 0..31 fill
-  // the even chunks and lanes 32..63 the odd ones -- each half-wave pass of a ds_write_b32 is conflict free.
+  // Where this lane parks its partials inside a 64-float register (layout: RED_REG above): lanes 0..31 fill the even chunks
+  // (floats 0..31), lanes 32..63 the odd ones (floats 32..63, their 16-byte halves swapped) -- each half-wave pass of a
+  // ds_write_b32 touches every bank once.
   const int red_wofs = ((lane >> 5) * 4 + ((lane & 31) >> 3)) * 8 + ((lane & 7) ^ ((lane >> 5) << 2));
   // transposed-sum roles: lane = (entry e, register rr, chunk ch of 8 floats).  The joins leave in chunks >= 4 first
   // the total of the chunks of the same parity, then the total of all eight.  Row word this lane stores: chunk 4 of
@@ -1485,7 +1485,7 @@ struct PreBwdArgs {
   const float* sh;        // RAW: _features_rest
   const float* sh_dc;     // RAW: _features_dc
   const float* D;         // [P,9] d rgb / d view direction left by k_pre_color (lane-group kernels only)
-  const double* abc;      // [P,3] k_pre_geom's needle marks under GSR_FLAG_NEEDLE_DOUBLE (first word: a number = needle, NaN = not)
+  const double* abc;      // [P] k_pre_geom's needle marks under GSR_FLAG_NEEDLE_DOUBLE (a number = needle, NaN = not)
   float* dmeans3D;
   float* dmeans2D;
   float* dsh;             // RAW: gradient of _features_rest
@@ -1732,7 +1732,7 @@ struct PreArgs {
   float4* G1;
   float4* G2;
   float* D;               // [P,9] d rgb_c / d dir_axis (before the clamp), or null: not wanted (no backward follows)
-  double* abc;            // [P,3] k_pre_geom<., NDL>: needle marks for K9 (first word: the needle's 2D covariance a, or NaN), or null
+  double* abc;            // [P] k_pre_geom<., NDL>: needle marks for K9 (the needle's 2D covariance entry a, or NaN: not a needle), or null
   uint32_t* dkey;         // float bits of the view depth; 0xFFFFFFFF for a Gaussian that emits no pair
   uint32_t* tcnt;         // tiles of the (tightened) rect
   const uint32_t* offg;   // colour kernel with tcnt == null (re-render of a kept context): a Gaussian emits pairs iff
@@ -1805,7 +1805,7 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
         cov2d_accurate(v, p, sc, a.va.mod, q, a.cov3d ? c6 : nullptr, ca, cb, cc);
         needle_conic_to_float(ca, cb, cc, s.A, s.B, s.C);
       }
-      if (NDL && a.abc) a.abc[3 * (vo + (size_t)g)] = ndl ? ca : __longlong_as_double(0x7FF8000000000000ll);   // K9's needle mark
+      if (NDL && a.abc) a.abc[vo + (size_t)g] = ndl ? ca : __longlong_as_double(0x7FF8000000000000ll);   // K9's needle mark
       const int fminx = s.rminx, fminy = s.rminy;      // first tile of the reference's rect: the origin of the stored centre
       if (a.cull) tighten_rect(s.px, s.py, s.A, s.B, s.C, op, v.gridx, v.gridy, s.rminx, s.rminy, s.rmaxx, s.rmaxy);
       s.rminx = min(s.rminx, fminx + RECT_OFF_MAX); s.rminy = min(s.rminy, fminy + RECT_OFF_MAX);
@@ -2124,6 +2124,9 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   // the kernel that produces the gradients instead of a second pass over them (a Gaussian without pairs writes zeros)
   float ssq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_ss = RAW && !ACC && a.sumsq != nullptr;
+  // (a wave without Gaussians returns above without writing its slot of the partial sums: with one wave per workgroup
+  // there is no such wave inside the grid -- k_sumsq_reduce reads ss_blocks * PRE_WAVES slots)
+  static_assert(PRE_WAVES == 1, "more waves per workgroup: empty waves must zero their sum-of-squares slot");
   auto flush_sumsq = [&]() {
     if (!want_ss) return;
 #pragma unroll
@@ -2221,7 +2224,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         float dc6[6];
         float ds[3], dq[4];
         bool needle = false;
-        if (NDL && a.abc) { const double m0 = a.abc[3 * (size_t)g]; needle = m0 == m0; }      // NaN: an ordinary splat
+        if (NDL && a.abc) { const double m0 = a.abc[(size_t)g]; needle = m0 == m0; }      // NaN: an ordinary splat
         if (NDL && needle) {
           // a needle: the whole chain rule in double on the float32 inputs (like its forward), activations included
           double dpd[3] = {(double)dp[0], (double)dp[1], (double)dp[2]}, dsd[3], dqd[4], dS6[6];

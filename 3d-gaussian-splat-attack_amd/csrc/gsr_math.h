@@ -95,10 +95,6 @@ struct Splat {
   float px, py;      // pixel-space centre, the published float32 arithmetic: every INTEGER decision (radius, tile rect, culls)
                      // is taken from these, like the reference's
   float ca, cb, cc;  // the dilated 2D covariance of the float32 chain (what A, B, C were inverted from)
-  double Ad, Bd, Cd; // the conic from the same chain (covariance -> J W Sigma W^T J^T + 0.3 I -> inverse) evaluated in double on
-                     // the float32 inputs (conic_accurate): for a strongly elongated splat det = a c - b^2 cancels by the
-                     // eigenvalue ratio, and the float32 chain leaves 1e-7 x that ratio in every conic entry (1.5e-4 for a
-                     // 1500:1 needle whose exponent sums terms of 1e4) -- in the reference's kernels as much as anywhere
   double pxd, pyd;   // the same centre from double-precision dot products of the float32 inputs: what the compositors measure
                      // distances from (round 5).  A float32 coordinate beyond 2048 resolves 2.4e-4 px, and d ln(alpha) / d centre
                      // of a one-pixel splat is O(1): at 4K the published float32 centre alone costs up to 2e-4 in a pixel's
@@ -211,7 +207,7 @@ GSR_HD bool is_needle(float a, float b, float c) { const float tr = a + c; retur
 // quaternion AS GIVEN, or the precomputed covariance; t = p V with t.x/t.z, t.y/t.z clamped to +-1.3 tan(fov/2); J; cov2D =
 // J W Sigma W^T J^T + 0.3 I; conic = cov2D^-1 -- with every product in double, from the same float32 inputs the float32
 // chain of project_splat() reads.  Nothing INTEGER comes from it: radius, rect and culls stay project_splat()'s.
-// (cov2d_accurate: the dilated 2D covariance (a, b, c) of that chain; conic_accurate: its inverse, into the Splat)
+// (cov2d_accurate: the dilated 2D covariance (a, b, c) of that chain; needle_conic_to_float: its inverse as the record's three floats)
 GSR_HD void cov2d_accurate(const View& v, const float p[3], const float* sc, float mod, const float* q, const float* c6pre,
                            double& a, double& b, double& c) {
   double S[6];
@@ -296,13 +292,6 @@ GSR_HD void needle_conic_to_float(double a, double b, double c, float& A, float&
       }
     }
   A = gsr_step_ulps(A0, bi - 2); B = gsr_step_ulps(B0, bj - 2); C = gsr_step_ulps(C0, bk - 2);
-}
-
-GSR_HD void conic_accurate(const View& v, const float p[3], const float* sc, float mod, const float* q, const float* c6pre, Splat& s) {
-  double a, b, c;
-  cov2d_accurate(v, p, sc, mod, q, c6pre, a, b, c);
-  const double dinv = 1.0 / (a * c - b * b);       // >= 0.09 in exact arithmetic: a PSD matrix + 0.3 I
-  s.Ad = c * dinv; s.Bd = -b * dinv; s.Cd = a * dinv;
 }
 
 // ---------------------------------------------------------------------------------------------

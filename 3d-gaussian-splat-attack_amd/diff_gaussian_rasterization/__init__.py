@@ -839,9 +839,10 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, settings_list, keep=True,
-                bucket=None):
+                bucket=None, norms=None):
         lib = _load()
         ctx.bucket = bucket
+        ctx.norms = norms
         if not xyz.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
                                f"{xyz.device}); there is no CPU path")
@@ -894,7 +895,7 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
             s = ctx.shapes
             dev0 = ctx.packs[0].device
             z = lambda i, shp: torch.zeros(shp, dtype=torch.float32, device=dev0) if (need[i] and shp is not None) else None
-            return (z(0, s[0]), z(1, s[1]), z(2, s[2]), z(3, s[3]), z(4, s[4]), z(5, s[5]), z(6, s[6]), None, None, None)
+            return (z(0, s[0]), z(1, s[1]), z(2, s[2]), z(3, s[3]), z(4, s[4]), z(5, s[5]), z(6, s[6]), None, None, None, None)
         lib = ctx.holder.lib
         device = x.device
         P, B = int(x.shape[0]), ctx.B
@@ -925,12 +926,43 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
             d_sc = out(need[5], P, 3)
             d_ro = out(need[6], P, 4)
         d_m2 = out(need[1], B, P, 3)
+        norms = getattr(ctx, "norms", None)
+        if norms is not None:
+            # the batch's ONE backward writes the summed gradient: its sums of squares are the L2 steps' norms (GradNorms)
+            norms.writes += 1
+            overwrites = (bucket is None or bucket.fresh) and not (bucket is not None and bucket.chunks > 1)
+            if norms.writes == 1 and overwrites and P > 0:
+                if lib.gsr_ctx_request_sumsq(ctx.holder.handle, ctypes.c_void_p(norms.sumsq.data_ptr())) != 0:
+                    norms.invalidate()              # (a build or a mode that cannot serve it: the step sums the gradient itself)
+                else:
+                    norms.names = tuple(n for n, w in zip(GradNorms.NAMES, (need[0], want_sh, want_sh, need[4], need[5], need[6])) if w)
+            elif not overwrites:
+                norms.invalidate()
         if P > 0:
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-                rc = lib.gsr_backward_raw_batch_into(ctx.holder.handle, _ptr(gcol), _ptr(d_x), _ptr(d_m2), _ptr(d_dc), _ptr(d_rest),
-                                                     _ptr(d_op), _ptr(d_sc), _ptr(d_ro),
-                                                     1 if (bucket is not None and not bucket.fresh) else 0, stream)
+                acc = 1 if (bucket is not None and not bucket.fresh) else 0
+                if bucket is not None and bucket.chunks > 1:
+                    # the per-Gaussian stage in ranges, each announced as soon as its launch is enqueued (all-reduce overlap)
+                    hook, bucket.on_chunk = bucket.on_chunk, None
+                    errs = []
+
+                    def _done(_user, chunk, g0, g1):
+                        try:
+                            if hook is not None:
+                                hook(int(chunk), int(g0), int(g1))
+                        except BaseException as e:       # an exception must not unwind through the C frames
+                            errs.append(e)
+                    cb = _CHUNK_FN(_done)
+                    rc = lib.gsr_backward_raw_chunked(ctx.holder.handle, _ptr(gcol), None, _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
+                                                      _ptr(d_rest), None, _ptr(d_op), _ptr(d_sc), _ptr(d_ro), acc,
+                                                      int(bucket.chunks), cb, None, stream)
+                    bucket.chunks = 1
+                    if errs:
+                        raise errs[0]
+                else:
+                    rc = lib.gsr_backward_raw_batch_into(ctx.holder.handle, _ptr(gcol), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
+                                                         _ptr(d_rest), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), acc, stream)
             if rc != 0:
                 raise (PairCapacityExceeded if rc == 5 else RuntimeError)(_err(lib))
         else:
@@ -940,16 +972,16 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
         s = ctx.shapes
         if bucket is not None:
             bucket.fresh, bucket.used = False, True
-            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None)
+            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None)
 
         def shaped(t, shape, wanted=True):
             return None if (t is None or not wanted) else t.reshape(shape)
         return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
-                shaped(d_op, s[4]), shaped(d_sc, s[5]), shaped(d_ro, s[6]), None, None, None)
+                shaped(d_op, s[4]), shaped(d_sc, s[5]), shaped(d_ro, s[6]), None, None, None, None)
 
 
 def rasterize_gaussians_raw_batch(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, settings_list,
-                                  grad_bucket: Optional["GradBucket"] = None):
+                                  grad_bucket: Optional["GradBucket"] = None, grad_norms: Optional["GradNorms"] = None):
     """(color[B,3,H,W], radii[B,P]) of B views (a list of GaussianRasterizationSettings that agree in image size, scale
     modifier and SH degree) of one set of RAW parameters, through one launch chain: every image and radius is bit for bit
     what rasterize_gaussians_raw gives for that view alone, and the backward leaves the SUM over the views of the
@@ -957,7 +989,7 @@ def rasterize_gaussians_raw_batch(xyz, means2D, features_dc, features_rest, opac
     (viewspace_points.grad of the reference, one slice per view), or None.  No object channels."""
     keep = _wants_backward(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation)
     return _RasterizeGaussiansRawBatch.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
-                                             list(settings_list), keep, grad_bucket)
+                                             list(settings_list), keep, grad_bucket, grad_norms)
 
 
 def _wants_backward(*tensors) -> bool:

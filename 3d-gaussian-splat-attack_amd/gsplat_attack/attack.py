@@ -32,7 +32,7 @@ from torch import nn
 from . import dist as gdist
 from . import pgd
 from .streams import StreamRing
-from .renderer import PipelineParams, render, render_pair, takes_fused_path
+from .renderer import PipelineParams, can_batch, render, render_batch, render_pair, takes_fused_path
 
 GROUPS = ("color", "position", "scaling", "rotation", "opacity")
 
@@ -164,7 +164,7 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                success_fn: Optional[Callable[[torch.Tensor, int], bool]] = None, save_path: Optional[str] = None,
                originals: Optional[dict] = None, use_buckets: bool = True,
                timer: Optional["PhaseTimer"] = None, overlap_success: bool = True,
-               cache_binning: bool = True, fused_norms: bool = True) -> List[float]:
+               cache_binning: bool = True, fused_norms: bool = True, batched: bool = True) -> List[float]:
     """Runs up to `iters` PGD iterations over the batch `cameras` (sharded over ranks when torch.distributed is
     initialised).  Returns the per-iteration global loss (sum over the batch's views).  The rank's views are
     pipelined over `streams` HIP streams (gsplat_attack.streams); 1 = the reference's strictly sequential order.
@@ -202,6 +202,13 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         at 1 M Gaussians) and later renders of it, the attack's and the success check's, run the colour
                         kernel and the compositor only.  Losses, flags and the saved model are bit for bit those of the
                         uncached loop (tests/test_gpu_rerender.py).
+      batched           (default on; device, fused path without object channels, a rank with two or more views, no kept
+                        binning) the rank's views go through ONE launch chain per iteration (render_batch ->
+                        gsr_forward_raw_batch / gsr_backward_raw_batch_into): one scan, one depth sort, one emission, one tile
+                        sort and one schedule for all of them, every SH row read once, and the 59 gradient floats per Gaussian
+                        written once instead of read and rewritten per view.  Images bit for bit those of the per-view
+                        renders; the summed gradient within float32 rounding of the per-view accumulation
+                        (tests/test_gpu_batch.py).  The per-view losses are summed and differentiated by ONE backward.
       fused_norms       (default on; L2 steps on one GPU, one view per iteration) the step's global gradient norms are the
                         sums of squares the raster backward leaves next to the gradients it writes (GradNorms /
                         gsr_ctx_request_sumsq): one launch per tensor and one read of the gradient instead of two.  With
@@ -235,11 +242,15 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             and takes_fused_path(model, pipe)):
         from diff_gaussian_rasterization import RenderCache
         pipe.render_cache = RenderCache(max_entries=4 * max(len(mine), 1) + 8)      # pipe is this call's own copy here
+    # the rank's views through one launch chain (see `batched`); a colour-only attack with kept binning re-renders each camera
+    # from its kept context instead (two kernels per view), which a batch would redo
+    use_batch = bool(batched and dev.type == "cuda" and len(mine) >= 2 and getattr(pipe, "render_cache", None) is None
+                     and can_batch(mine, model, pipe))
     reduce_names = ("_features_dc", "_features_rest") if frozen else gdist.ATTACK_PARAMS
     running = {}                                           # accumulate_grads with world > 1: the running sums
     try:
         history = []
-        ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" and not batch_loss else None
+        ring = StreamRing(min(streams, max(len(mine), 1)), dev) if dev.type == "cuda" and not batch_loss and not use_batch else None
         # Gradient buckets (fused path, all five groups differentiated): the rasteriser's backward writes a view's 59
         # attribute gradients per Gaussian straight into a caller-owned flat buffer -- the first view of the iteration
         # overwrites it, the others add -- instead of allocating 236 bytes per Gaussian per view and leaving the
@@ -258,6 +269,7 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
         # L2 steps: the global norms come out of the raster backward (GradNorms) while one backward per iteration writes the
         # gradients the step uses -- one view per iteration on one GPU without the running-sum quirk (BASELINE config 3)
         norms = None
+        # (or one BATCH per iteration: its one backward writes the summed gradient)
         if (fused_norms and norm == "l2" and dev.type == "cuda" and world == 1 and not accumulate_grads and takes_fused_path(model, pipe)
                 and getattr(pipe, "grad_norms", None) is None):
             from diff_gaussian_rasterization import GradNorms
@@ -319,7 +331,37 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             if cleared:
                 clear_gradients()
             losses = []
-            if batch_loss:
+            if use_batch:
+                imgs_b = render_batch(mine, model, pipe, bg)["render"]
+                if pending is not None:
+                    # the previous iteration's success renders ran beside this forward: now read their flags
+                    stopped = finish_iteration(*pending)
+                    pending = None
+                    if stopped:
+                        del imgs_b                         # speculative: never differentiated, nothing accumulated
+                        break
+                if not cleared:
+                    clear_gradients()
+                    cleared = True
+                if timer is not None:
+                    timer.lap("render")
+                if batch_loss:
+                    loss = loss_fn(imgs_b)
+                    if loss_reduction == "mean":
+                        loss = loss * (len(mine) / len(cameras))
+                    losses.append(loss.detach())
+                else:
+                    per_view = [loss_fn(imgs_b[v:v + 1]) for v in range(len(mine))]
+                    if loss_reduction == "mean":
+                        per_view = [l_ / len(cameras) for l_ in per_view]
+                    losses.extend(l_.detach() for l_ in per_view)
+                    loss = torch.stack(per_view).sum()
+                if timer is not None:
+                    timer.lap("loss")
+                loss.backward()                            # ONE raster backward for the rank's views
+                if timer is not None:
+                    timer.lap("backward")
+            elif batch_loss:
                 if mine:
                     renders = torch.stack([render(cam, model, pipe, bg)["render"] for cam in mine])
                     loss = loss_fn(renders)

@@ -236,7 +236,8 @@ def render_batch(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
     if callable(bucket):
         bucket = bucket()
     image, radii = rasterize_gaussians_raw_batch(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
-                                                 pc._scaling, pc._rotation, sts, grad_bucket=bucket)
+                                                 pc._scaling, pc._rotation, sts, grad_bucket=bucket,
+                                                 grad_norms=getattr(pipe, "grad_norms", None))
     objects = _zero_scalar(image.device).unsqueeze(0).expand(B, 16, image.shape[2], image.shape[3])
     return _result(image, screenspace_points, radii, objects)
 

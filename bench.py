@@ -263,6 +263,10 @@ def main():
                          "while K9 still computes the next (1 = one collective after the backward)")
     ap.add_argument("--independent-views", action="store_true",
                     help="N > 1: round-2 behaviour (views pipelined across steps, all-reduce but no parameter update)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="N = 1: views per batch of the `batched` block (one launch chain per batch, gsr_forward_raw_batch); "
+                         "0 = skip.  N > 1: the rank's --views-per-rank views go through one launch chain unless --no-batch")
+    ap.add_argument("--no-batch", action="store_true", help="N > 1: one render() + backward per view, as in round 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (dense point, forward-only, PGD blocks)")
     ap.add_argument("--scale-modifier", type=float, default=1.0,
@@ -290,7 +294,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the raster path has no CPU fallback")
     from gsplat_attack import dist as gdist
     from gsplat_attack import pgd as gpgd
-    from gsplat_attack.renderer import PipelineParams, render
+    from gsplat_attack.renderer import PipelineParams, can_batch, render, render_batch
     from gsplat_attack.scenes import make_scene
     import diff_gaussian_rasterization as D
 
@@ -380,8 +384,37 @@ def main():
         pipe_b = PipelineParams(skip_objects=not args.objects, grad_bucket=lambda: buckets[ring.current])
         originals = {n_: getattr(model, n_).detach().clone() for n_ in gdist.ATTACK_PARAMS}
         rank_cams = [cams[(rank * B + v) % n_views] for v in range(B)]
+        batch_views = (not args.no_batch) and B >= 2 and can_batch(rank_cams, model, pipe_b)
+        gcb_rank = gc.unsqueeze(0).expand(B, 3, H, W).contiguous() if batch_views else None
+        pipe_one = PipelineParams(skip_objects=not args.objects, grad_bucket=buckets[0])
+
+        def pgd_step_batched():
+            # the rank's B views through ONE launch chain (gsr_forward_raw_batch / gsr_backward_raw_batch_into): the bucket
+            # receives the summed gradient of the B views, written once
+            buckets[0].reset()
+            ar = None
+            out_ = render_batch(rank_cams, model, pipe_one, bg, scale_mod[0])["render"]
+            if args.ar_chunks > 1:
+                ar = gdist.BucketAllReduce(buckets[0], args.ar_chunks)
+            out_.backward(gcb_rank)
+            return ar
 
         def pgd_step():
+            if batch_views:
+                ar = pgd_step_batched()
+                tot = buckets[0]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if ar is None:
+                    ar = gdist.BucketAllReduce(tot, 1)
+                bytes_reduced[0] = ar.wait()
+                e1.record()
+                ar_events.append((e0, e1))
+                tot.assign_to(model)
+                for n_ in gdist.ATTACK_PARAMS:
+                    p_ = getattr(model, n_)
+                    gpgd.l2_step_(p_, p_.grad, 0.5, 5.0, originals[n_])
+                return
             for b_ in buckets:
                 b_.reset()
             ar = None
@@ -513,6 +546,55 @@ def main():
                "what": "the same fwd+bwd views strictly one after another on ONE stream: what the reference's default "
                        "loop (configs/config.yaml:56 batch_mode false, attack.py:486-494) and config 4's one view per "
                        "rank per step see"}
+    # A batch of views through ONE launch chain (gsr_forward_raw_batch / gsr_backward_raw_batch_into): what the reference's
+    # batch loop (attack.py:476-494: B render() calls, B backward passes summed in .grad) becomes when the B views are one
+    # virtual scene -- one scan, one depth sort, one emission, one tile sort, one schedule, one forward and one backward
+    # composite for all of them, every SH row read once, the 59 gradient floats per Gaussian written once.  ONE stream.
+    batched = None
+    if world == 1 and args.batch >= 2 and not args.classic and not args.objects and not args.color_only:
+        Bb = min(args.batch, len(cams), D.MAX_BATCH)
+        bcams = cams[:Bb]
+        bucket_b = D.GradBucket(P, dev)
+        pipe_bb = PipelineParams(skip_objects=True, grad_bucket=bucket_b)
+        gcb = gc.unsqueeze(0).expand(Bb, 3, H, W).contiguous()
+
+        def batch_step():
+            bucket_b.reset()
+            out_b = render_batch(bcams, model, pipe_bb, bg, scale_mod[0])
+            out_b["render"].backward(gcb)
+            bucket_b.assign_to(model)                      # .grad = views of the bucket (no copy)
+            return out_b
+        D.profile(False)
+        nbt = max(args.steps // Bb, 3)
+        for _ in range(3):
+            ob = batch_step()
+        torch.cuda.synchronize()
+        n_batch = D.last_num_rendered(ob["render"])
+        del ob
+        tb = []
+        for _ in range(args.regions):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nbt):
+                batch_step()
+            torch.cuda.synchronize()
+            tb.append(time.perf_counter() - t0)
+        mb = sorted(tb)[len(tb) // 2]
+        D.profile(True)
+        for _ in range(3):
+            batch_step()
+        torch.cuda.synchronize()
+        st_b = {k: round(ms / 3 / Bb, 4) for k, (ms, _) in D.profile_read().items()}
+        D.profile(False)
+        batched = {"value": round(Bb * nbt / mb, 2), "unit": "views/s", "views_per_batch": Bb, "batches_per_region": nbt,
+                   "ms_per_batch": round(mb / nbt * 1e3, 4), "ms_per_view": round(mb / nbt / Bb * 1e3, 4),
+                   "regions_ms": [round(x * 1e3, 2) for x in tb], "streams": 1, "N_pairs_per_batch": n_batch,
+                   "stages_ms_per_view": st_b,
+                   "what": f"the {Bb} ring cameras as ONE batch per step on ONE stream: gsr_forward_raw_batch + "
+                           "gsr_backward_raw_batch_into from a fixed dL/dC per view, the gradients of the batch's views summed "
+                           "into one 59-float-per-Gaussian bucket (what reference attack.py:476-494 accumulates in .grad); "
+                           "every image bit for bit the single-view render (tests/test_gpu_batch.py)"}
+        model.zero_grad()
     # Untimed extra pass with every stage bracketed: the per-stage breakdown reported under "stages".
     D.profile(True)
     nb = max(3, min(args.steps, 10))
@@ -646,6 +728,8 @@ def main():
                 "note": "render_fwd includes the tile-schedule kernel; one-stream stage durations of the untimed pass"}
         if seq is not None:
             result["sequential"] = seq
+        if batched is not None:
+            result["batched"] = batched
         if world > 1:
             result["ranks_seen"] = ranks_seen
             try:
@@ -829,9 +913,10 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
     det = SurrogateDetector().to(dev)
     never = lambda im, i: False                            # noqa: E731 -- the success check runs, the loop never stops on it
 
-    def measure(name, views, groups, iters, n_streams, rerender, cache_binning=True):
+    def measure(name, views, groups, iters, n_streams, rerender, cache_binning=True, batched=True):
         m = model.clone()
-        kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0, cache_binning=cache_binning)
+        kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0, cache_binning=cache_binning,
+                  batched=batched)
         if rerender:
             kw.update(success_fn=never, background=None)
         pgd_attack(m, views, iters=3, **kw)                # warm-up
@@ -845,7 +930,9 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
                "views": len(views), "groups": list(groups), "streams": n_streams, "what": name,
                # colour-only attacks: each camera's rasteriser context (projection, sorts, tile lists) kept in HBM after its
                # first render and re-used while the geometry tensors are untouched (gsr_ctx_rerender); same bits
-               "binning_kept": bool(cache_binning and tuple(groups) == ("color",))}
+               "binning_kept": bool(cache_binning and tuple(groups) == ("color",)),
+               # all-attribute attacks on two or more views: the views of an iteration go through one launch chain
+               "views_batched": bool(batched and len(views) >= 2 and not (cache_binning and tuple(groups) == ("color",)))}
         if n_streams == 1:
             # phase split on one stream: HIP events at the phase boundaries + the library's own stage events
             tm = PhaseTimer()
@@ -883,10 +970,13 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         "cfg3_8views_rebinned_every_render": measure("the same, every render the whole forward", cams[:8], ("color",), 6,
                                                      max(args.streams, 1), True, cache_binning=False),
         "cfg4_one_gpu": measure("BASELINE config 4 on one GPU: 8 views per iteration, L2 on {colour, position, scaling, "
-                                "rotation, opacity}, one stream", cams[:8],
+                                "rotation, opacity}, one stream, the 8 views as ONE batch (gsr_forward_raw_batch)", cams[:8],
                                 ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False),
-        "cfg4_one_gpu_pipelined": measure("the same with the 8 views dealt over 4 streams", cams[:8],
-                                          ("color", "position", "scaling", "rotation", "opacity"), 6, max(args.streams, 1), False),
+        "cfg4_one_gpu_pipelined": measure("the same with the 8 views dealt over 4 streams, one render() per view", cams[:8],
+                                          ("color", "position", "scaling", "rotation", "opacity"), 6, max(args.streams, 1), False,
+                                          batched=False),
+        "cfg4_one_gpu_per_view": measure("the same on one stream with one render() + backward per view (round 5's loop)", cams[:8],
+                                         ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False, batched=False),
     }
     return extras, pgd
 

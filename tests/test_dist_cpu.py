@@ -253,9 +253,13 @@ def test_bench_fan_out_parent_reports_a_failing_rank():
                          text=True, timeout=300)
     assert out.returncode != 0 and "HIP device" in out.stderr
     # a rank that does not act on SIGTERM (stuck in a collective) is ended by its exact PID after a bounded grace period
-    import time
+    # (no wall-clock bound on the run itself: three cold interpreter starts importing torch take what the machine's load
+    # makes them take -- round 5's `< 60 s` failed once in three runs of the suite.  What is asserted is the ORDER of
+    # events the parent reports: the failing rank, the SIGTERM, and the SIGKILL of the exact PID after the 2 s grace period;
+    # a parent that never kills the hanging rank runs into subprocess's own 300 s timeout, which fails the test.)
     env.update(BENCH_REHEARSE_GLOO="1", BENCH_FANOUT_GRACE_S="2", BENCH_TEST_HANG_RANK="1")
-    t0 = time.monotonic()
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
-                         text=True, timeout=120)
-    assert out.returncode != 0 and "SIGKILL" in out.stderr and time.monotonic() - t0 < 60
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "SIGKILL" in out.stderr
+    assert "still running 2 s after SIGTERM" in out.stderr
+    assert out.stderr.index("stopping the other ranks") < out.stderr.index("SIGKILL")

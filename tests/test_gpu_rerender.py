@@ -197,9 +197,11 @@ def test_colour_attack_with_kept_contexts_equals_the_plain_loop(streams, with_ba
             return len(calls) > 3 * len(cams)         # fooled from the fourth iteration on
         recs = []
         path = str(tmp_path / f"m_{cache_on}.ply")
+        # (batched=False: without kept contexts the rank's views would go through one launch chain per iteration, whose
+        # summed gradient equals the per-view accumulation within rounding, not bit for bit -- tests/test_gpu_batch.py)
         hist = pgd_attack(m, cams, iters=6, groups=("color",), streams=streams, success_fn=success,
                           background=back if with_background else None, log=recs.append, save_path=path,
-                          cache_binning=cache_on)
+                          cache_binning=cache_on, batched=False)
         torch.cuda.synchronize()
         runs.append((hist, [r.get("successes") for r in recs], calls,
                      {n: getattr(m, n).detach().clone() for n in COL}, open(path, "rb").read()))
@@ -217,8 +219,9 @@ def test_attack_on_all_groups_makes_no_cache():
     dev, model, cams, bg = _scene(6000, 128, 96, n_views=2)
     cache = RenderCache()
     m0, m1 = model.clone(), model.clone()
-    h0 = pgd_attack(m0, cams, iters=3, groups=("color", "position"), streams=1)
-    h1 = pgd_attack(m1, cams, iters=3, groups=("color", "position"), streams=1,
+    # (batched=False on both sides: a pipe that carries a cache keeps the per-view loop, and the comparison is bit for bit)
+    h0 = pgd_attack(m0, cams, iters=3, groups=("color", "position"), streams=1, batched=False)
+    h1 = pgd_attack(m1, cams, iters=3, groups=("color", "position"), streams=1, batched=False,
                     pipe=PipelineParams(skip_objects=True, render_cache=cache))
     assert h0 == h1 and cache.hits == 0
     assert torch.equal(m0._xyz, m1._xyz)

@@ -78,8 +78,9 @@ def test_pgd_attack_same_history_with_and_without_streams():
     from gsplat_attack.attack import pgd_attack
     dev, model, cams, pipe, bg, _ = _setup(P=8000, W=160, H=128, n_views=4)
     m1, m3 = model.clone(), model.clone()
-    h1 = pgd_attack(m1, cams, iters=3, groups=("color", "position"), streams=1)
-    h3 = pgd_attack(m3, cams, iters=3, groups=("color", "position"), streams=3)
+    # (batched=False: the stream ring deals the per-view loop's views; a batch goes through one launch chain on one stream)
+    h1 = pgd_attack(m1, cams, iters=3, groups=("color", "position"), streams=1, batched=False)
+    h3 = pgd_attack(m3, cams, iters=3, groups=("color", "position"), streams=3, batched=False)
     torch.cuda.synchronize()
     for a, b in zip(h1, h3):
         assert abs(a - b) <= 1e-4 * max(abs(a), 1.0)
@@ -113,8 +114,10 @@ def test_overlapped_success_check_equals_the_serial_loop(n_views, streams, tmp_p
                 return stop_at is not None and it >= stop_at
             recs = []
             path = str(tmp_path / f"m_{overlap}_{stop_at}.ply")
+            # (one stream: the views of an iteration as ONE batch; more: the per-view loop dealt over the stream ring)
             hist = pgd_attack(m, cams, iters=5, groups=("color", "position"), streams=streams, success_fn=success,
-                              background=bg_model, overlap_success=overlap, log=recs.append, save_path=path)
+                              background=bg_model, overlap_success=overlap, log=recs.append, save_path=path,
+                              batched=streams == 1)
             torch.cuda.synchronize()
             runs.append((hist, [r.get("successes") for r in recs], {n: getattr(m, n).detach().clone() for n in
                                                                       ("_xyz", "_features_dc", "_features_rest")},
