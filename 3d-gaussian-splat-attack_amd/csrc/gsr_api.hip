@@ -647,7 +647,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                    s->sh_degree, (s->sh_degree + 1) * (s->sh_degree + 1), K);
   if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
     return set_err(GSR_ERR_INVALID, "gsr_forward: settings tensors (bg, viewmatrix, projmatrix, campos) must be device pointers");
-  if (out_objects == nullptr && sh_objs != nullptr) sh_objs = nullptr;   // objects not wanted
+  // objects not wanted -- unless the features are to be kept for the backward (GSR_FLAG_OBJECTS_FOR_BACKWARD_ONLY)
+  if (out_objects == nullptr && sh_objs != nullptr && !(s->flags & GSR_FLAG_OBJECTS_FOR_BACKWARD_ONLY)) sh_objs = nullptr;
 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int dev = cur_dev();

@@ -351,7 +351,8 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         loss = loss * (len(mine) / len(cameras))
                     losses.append(loss.detach())
                 else:
-                    per_view = [loss_fn(imgs_b[v:v + 1]) for v in range(len(mine))]
+                    # (unbind, not slices: a slice's backward materialises a zero [B,3,H,W] tensor per view and adds it in)
+                    per_view = [loss_fn(im[None]) for im in imgs_b.unbind(0)]
                     if loss_reduction == "mean":
                         per_view = [l_ / len(cameras) for l_ in per_view]
                     losses.extend(l_.detach() for l_ in per_view)

@@ -874,37 +874,57 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         pipe_d = PipelineParams(skip_objects=False, fused_activations=False)
         n_d = min(args.steps, 60)
 
+        dmodel = [model]
+
         def dropin_steps(n, sts):
+            m_ = dmodel[0]
             for s_ in (sts or []):
                 s_.wait_stream(torch.cuda.current_stream(dev))
             for i in range(n):
                 ctx_ = torch.cuda.stream(sts[i % len(sts)]) if sts else contextlib.nullcontext()
                 with ctx_:
-                    model.zero_grad()
-                    render(cams[i % len(cams)], model, pipe_d, bg)["render"].backward(gc)
+                    m_.zero_grad()
+                    render(cams[i % len(cams)], m_, pipe_d, bg)["render"].backward(gc)
             for s_ in (sts or []):
                 torch.cuda.current_stream(dev).wait_stream(s_)
-        rates = []
-        for sts in (streams, None):
-            dropin_steps(8, sts)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                dropin_steps(n_d, sts)
+
+        def dropin_rates():
+            rates_ = []
+            for sts in (streams, None):
+                dropin_steps(8, sts)
                 torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            rates.append(n_d / sorted(ts)[1])
-        D.profile(True)
-        dropin_steps(6, None)
-        torch.cuda.synchronize()
-        st_d = {k: round(ms / 6, 4) for k, (ms, _) in D.profile_read().items()}
-        D.profile(False)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    dropin_steps(n_d, sts)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                rates_.append(n_d / sorted(ts)[1])
+            D.profile(True)
+            dropin_steps(6, None)
+            torch.cuda.synchronize()
+            st_ = {k: round(ms / 6, 4) for k, (ms, _) in D.profile_read().items()}
+            D.profile(False)
+            return rates_, st_
+        rates, st_d = dropin_rates()
+        # the attack's case: every object feature zero (reference scene/gaussian_model.py:528, combine_splats) -- the classic
+        # binding then composites without the object channels (GSR_FLAG_OBJECTS_FOR_BACKWARD_ONLY), same image and gradients
+        dmodel[0] = model.clone()
+        with torch.no_grad():
+            dmodel[0]._objects_dc.zero_()
+        rates_z, st_z = dropin_rates()
+        dmodel[0] = model
         extras["dropin"] = {"value": round(rates[0], 1), "sequential_views_per_s": round(rates[1], 1), "unit": "views/s",
                             "steps": n_d, "streams": len(streams) if streams else 1, "stages_ms": st_d,
                             "what": "render() on the classic surface with object channels on (--classic --objects): the "
                                     "configuration the reference's unchanged gaussian_renderer.render() reaches; median "
-                                    "of 3 regions; `value` pipelined over the streams, `sequential` on one"}
+                                    "of 3 regions; `value` pipelined over the streams, `sequential` on one",
+                            "zero_object_features": {
+                                "value": round(rates_z[0], 1), "sequential_views_per_s": round(rates_z[1], 1), "stages_ms": st_z,
+                                "what": "the same with every object feature zero, as in the attack's combined scenes "
+                                        "(reference scene/gaussian_model.py:528): the binding finds that out once per tensor "
+                                        "version and composites without the 16 object channels; image, object map (zeros) "
+                                        "and gradients equal the object variant's (tests/test_gpu_zero_objects.py)"}}
     if col_rate is not None:
         extras["sh_grads_only_ring_views_per_s"] = round(ring_rates[0], 1)
         extras["sh_grads_only_ring_binning_kept_views_per_s"] = round(ring_rates[1], 1)

@@ -84,6 +84,15 @@ enum {
  * 1.3 % (one stream) to 2.8 % (four) on S-nyc-1M, whose splats are not needles (EXPERIMENTS.md, round 5). */
 #define GSR_FLAG_NEEDLE_DOUBLE (1u << 20)
 
+/* GSR_FLAG_OBJECTS_FOR_BACKWARD_ONLY: gsr_forward / gsr_forward_raw are given sh_objs but out_objects == NULL -- the object
+ * channels are not composited (the caller knows they come out as zeros: all features are zero, which is what the reference's
+ * combine_splats gives every Gaussian of an attack scene, scene/gaussian_model.py:528 -- or does not look at them), but the
+ * context keeps the features, so that a gsr_backward WITH grad_objects still produces dL/dsh_objs (and the features'
+ * share of dL/dalpha) exactly as after a forward that composited them.  Without the flag, sh_objs without out_objects is
+ * ignored altogether (no object gradients).  The forward then runs the compositor without object channels: 0.16 ms
+ * instead of 0.27 at 1 M Gaussians / 1080p, and 133 MB of output less. */
+#define GSR_FLAG_OBJECTS_FOR_BACKWARD_ONLY (1u << 21)
+
 /* Mirrors the 12 fields of GaussianRasterizationSettings in call-site order
  * (reference gaussian_renderer/__init__.py:36-49).  Tensor-valued fields are DEVICE pointers, read by the
  * kernels themselves (no host copy, no sync):
