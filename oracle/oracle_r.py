@@ -23,13 +23,20 @@ the 3D covariance construction (``utils/general_utils.py:78-110``,
 with max(0.1, .), 16x16 tiles, alpha cap 0.99, alpha floor 1/255, T stop 1e-4,
 +1e-7 w-guard, pixel centre ((ndc+1)*S-1)/2.
 
-Gradients come from autograd over this restatement, with two deliberate
-straight-through constructions so that they equal what the reference
-extension's hand-written backward produces rather than the "true" derivative:
+Gradients come from autograd over this restatement, with three deliberate
+constructions so that they equal what the reference extension's hand-written
+backward produces rather than the "true" derivative:
   * ``alpha = min(0.99, o*G)``: the backward treats the cap as transparent
     (dalpha/dG = o even when capped);
   * the 1.3*tanfov clamp of t.x/t.z: when clamped, t.x is treated as a constant
-    (zero gradient to t.x, and no t.z dependence through the clamp).
+    (zero gradient to t.x, and no t.z dependence through the clamp);
+  * the inversion of the 2D covariance: the published backward divides by
+    ``det^2 + 1e-7`` (a float32 literal) where the exact derivative of
+    conic = (c, -b, a) / det divides by ``det^2`` (``_Conic`` below;
+    ``DET_GUARD = 0.0`` gives the exact derivative).  With the 0.3 px^2
+    dilation det >= 0.09, so the two differ by at most 1.2e-5 relative in
+    dL/d(cov2D) -- measured on BASELINE configs 3 and 5 in
+    profiles/r06_parity_notes.txt.
 Everything else is the exact derivative.
 
 Works in float32 or float64 (``dtype=``); float64 is the parity reference.
@@ -156,6 +163,31 @@ class Geom(NamedTuple):
     e_depth: torch.Tensor    # [P]        and the view depth
 
 
+# The published backward of the 2D covariance inversion: 1 / (det^2 + 0.0000001f).  0.0: the exact derivative.
+DET_GUARD = 1.0000000116860974e-07       # = float32(1e-7), the literal as the float32 kernels see it
+
+
+class _Conic(torch.autograd.Function):
+    """conic = (c, -b, a) / det of the dilated 2D covariance [[a, b], [b, c]]; the backward is the exact derivative with
+    1 / det^2 replaced by 1 / (det^2 + DET_GUARD) -- what the published hand-written backward computes (dL/dB counted once
+    for the single off-diagonal entry, as everywhere in this file)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, det_safe):
+        ctx.save_for_backward(a, b, c, det_safe)
+        return torch.stack([c / det_safe, -b / det_safe, a / det_safe], dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, c, det = ctx.saved_tensors
+        dA, dB, dC = g[:, 0], g[:, 1], g[:, 2]
+        d2 = 1.0 / (det * det + DET_GUARD)
+        da = (-c * c * dA + b * c * dB - b * b * dC) * d2
+        db = (2.0 * b * c * dA - (det + 2.0 * b * b) * dB + 2.0 * a * b * dC) * d2
+        dc = (-b * b * dA + a * b * dB - a * a * dC) * d2
+        return da, db, dc, None
+
+
 def _project(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=None):
     """The arithmetic of K1 in the dtype of its inputs.
     -> dict(tz, in_front, det_ok, conic [P,3], rr (un-rounded radius 3 sqrt(lambda)), px, py)."""
@@ -202,7 +234,7 @@ def _project(means3D, scales, rotations, cov3D_precomp, st: Settings, means2D=No
     det = a * c - b * b
     det_ok = det != 0
     det_safe = torch.where(det_ok, det, torch.ones_like(det))
-    conic = torch.stack([c / det_safe, -b / det_safe, a / det_safe], dim=1)
+    conic = _Conic.apply(a, b, c, det_safe.detach())
     mid = 0.5 * (a + c)
     disc = torch.clamp_min(mid * mid - det, 0.1)
     lam = mid + torch.sqrt(disc)

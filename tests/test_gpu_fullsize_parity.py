@@ -24,7 +24,7 @@ RGB_TOL = 1e-4
 GRAD_TOL = 1e-3
 RAW = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")
 # share of the FRAGILE window pixels that may sit on neither clause of the float32 yardstick (util.pixel_yardstick)
-NEITHER_CAP = float(os.environ.get("PARITY_NEITHER_CAP", "0.005"))
+NEITHER_CAP = 0.005           # a constant (round 6): a tolerance that the environment could loosen is not a tolerance
 _R32 = {}          # id(float64 RenderOut) -> the float32 oracle's RenderOut of the same windows
 _ALLPX = {}        # id(float64 RenderOut) -> the all-pixel loss (fragile pixels INCLUDED) and both oracles' gradients of it
 
@@ -327,6 +327,36 @@ def test_cfg3_windows_with_the_oracles_own_depth_order():
     # (no all-pixel pass here: with the oracle's own depth order the fragile pixels include every pixel two near-tied
     # splats share -- the float32 oracle sorts them its way, the implementation its own)
     print("own-order windows", wins, rep)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg5"])
+def test_cfg2_and_cfg5_windows_with_the_oracles_own_depth_order(cfg):
+    """Configs 2 and 5 once each WITHOUT the HIP path's depth keys: the oracle sorts on its own
+    float32(float64 depth) keys, flags the pixels whose list neighbours may swap in another float32 arithmetic, and the
+    solid pixels -- image and the gradients of a loss over them -- must agree all the same.  Fewer windows than the
+    keyed tests (the own-order oracle flags more pixels fragile; what is checked is that agreement does not hinge on
+    borrowed keys)."""
+    D = _hip()
+    if cfg == "cfg2":
+        key, view, H, W = "hydrant-full", 0, 800, 800
+        bg = torch.tensor([0.0, 0.0, 0.0])
+        dev, model, cams = _scene_on_gpu(key, 1)
+    else:
+        key, view, H, W = "airport-4K", 1, 2160, 3840
+        bg = torch.tensor([0.0, 0.0, 0.0])
+        dev, model, cams = _scene_on_gpu(key, 2)
+    cam = cams[view]
+    wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
+    wins = wins[1:4]
+    m = window_mask(wins, H, W)
+    gc = torch.randn(3, H, W, generator=torch.Generator().manual_seed(23)) * m
+    ro, rgrads, gc, _ = oracle_raw(key, view, bg, gc, wins, keys=None, n_views=view + 1)
+    out, grads = hip_raw(model, cam, bg.to(dev), gc.to(dev))
+    # (observed fragile shares: cfg 2 0.59 -- a dense blob: most pixels see two near-tied splats somewhere in their list --,
+    # cfg 5 see profiles/r06_parity_notes.txt; the solid AND the fragile pixels agree to 5e-7 on cfg 2 all the same)
+    rep = compare(out, grads, ro, rgrads, m, frag_frac=0.75 if cfg == "cfg2" else 0.5, tag=f"{cfg} {key}, oracle's own depth order")
+    _note(f"[own depth order] {cfg} {key}: windows {wins}, longest list {longest}, {rep}")
+    print(cfg, "own-order windows", wins, rep)
 
 
 def test_dense_10m_pairs_vs_windowed_oracle():
