@@ -165,10 +165,10 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_preprocess(int P, int K, ViewArg
       cov3d_from_scale_rot(sc, va.mod, q, c6);
     }
     Splat s;
-    const bool ok = project_splat(v, p, c6, s);
+    const float o = opac[g];
+    const bool ok = project_splat(v, p, c6, s) && opacity_ok(o);
     radii[g] = ok ? s.radius : 0;
     if (ok) {
-      const float o = opac[g];
       if ((cull & 2) && is_needle(s.ca, s.cb, s.cc)) {       // cull bit 1: GSR_FLAG_NEEDLE_DOUBLE
         // a needle's conic (compositors and footprint tests): the same chain in double (gsr_math.h cov2d_accurate)
         float scd[3] = {0.f, 0.f, 0.f}, qd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1790,11 +1790,11 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
       cov3d_from_scale_rot(sc, a.va.mod, q, c6);
     }
     Splat s;
-    const bool vis = project_splat(v, p, c6, s);
+    const float oraw = second ? a.opac_b[gl] : a.opac[gl];
+    const float op = RAW ? act_sigmoid(oraw) : oraw;
+    const bool vis = project_splat(v, p, c6, s) && opacity_ok(op);
     a.radii[(size_t)view * (size_t)a.P + g] = vis ? s.radius : 0;                     // the reference's radius, whatever the footprint test says
     if (vis) {
-      const float oraw = second ? a.opac_b[gl] : a.opac[gl];
-      const float op = RAW ? act_sigmoid(oraw) : oraw;
       // NDL (GSR_FLAG_NEEDLE_DOUBLE): a needle's conic -- what the compositors and the footprint tests use -- comes from the
       // same chain in double, on the same float32 (activated) inputs (gsr_math.h is_needle / cov2d_accurate); every other
       // splat, and every splat without the flag, keeps the published float32 conic.  Radius, rect and culls above are the

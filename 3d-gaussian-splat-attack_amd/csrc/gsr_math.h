@@ -32,6 +32,7 @@ constexpr float DILATE = 0.3f;      // px^2 added to the 2D covariance diagonal
 constexpr float ALPHA_CAP = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_STOP = 1e-4f;
+constexpr int RADIUS_MAX = 1 << 24;   // pixels: a larger footprint covers every image this library accepts (65520 px per side)
 // the published backward of the 2D covariance inversion: 1 / (det^2 + 0.0000001f); -DGSR_DET_GUARD=0.0f: the exact derivative
 #ifndef GSR_DET_GUARD
 #define GSR_DET_GUARD 0.0000001f
@@ -176,9 +177,17 @@ GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Sp
   s.ca = a; s.cb = b; s.cc = c;
   const float mid = 0.5f * (a + c);
   const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-  const int radius = (int)ceilf(3.0f * sqrtf(lam));
   s.px = ((ndcx + 1.0f) * (float)v.W - 1.0f) * 0.5f;
   s.py = ((ndcy + 1.0f) * (float)v.H - 1.0f) * 0.5f;
+  // Non-finite and extreme inputs (include/gsraster.h, "Non-finite inputs"): a splat whose conic, centre or depth is not a
+  // finite number -- NaN or +-inf in its mean, scale, rotation or covariance, or finite values whose products overflow -- is
+  // culled like one behind the camera (radius 0, no pairs, zero gradients): x * 0 is 0 for every finite x and NaN
+  // otherwise.  A finite but enormous footprint keeps the published behaviour (a rect clamped to the image) with the
+  // radius saturated at RADIUS_MAX instead of a float -> int conversion that is undefined beyond 2^31.
+  if (!((s.A + s.B + s.C) * 0.0f + (s.px + s.py + t[2]) * 0.0f == 0.0f)) return false;
+  const float r3 = 3.0f * sqrtf(lam);                      // (NaN lam: mid^2 overflowed although the conic is finite)
+  if (!(r3 == r3)) return false;
+  const int radius = r3 < (float)RADIUS_MAX ? (int)ceilf(r3) : RADIUS_MAX;
   {
     const double x = (double)p[0], y = (double)p[1], z = (double)p[2];
     const double h0 = x * (double)v.PV[0] + y * (double)v.PV[4] + z * (double)v.PV[8] + (double)v.PV[12];
@@ -198,6 +207,11 @@ GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Sp
   s.radius = radius;
   return true;
 }
+
+// An opacity that is not a number emits nothing (a NaN alpha would pass min(0.99, .) as 0.99 on this hardware as in the
+// published kernels -- garbage in, a fully opaque splat out; here the Gaussian is culled instead, with and without the
+// footprint cull): include/gsraster.h, "Non-finite inputs".
+GSR_HD bool opacity_ok(float o) { return o == o; }
 
 // A splat is a NEEDLE for the purposes below when the eigenvalues of its dilated 2D covariance are more than
 // NEEDLE_RATIO apart ((a + c)^2 / det = r + 2 + 1/r): the float32 chain leaves about 1e-7 x that ratio in every conic

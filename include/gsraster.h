@@ -19,6 +19,21 @@
  *     gsr_forward alive and unmodified until gsr_backward / gsr_ctx_free for that context;
  *     the library owns an internal caching workspace pool per device and the opaque GsrCtx.
  *   - gradient outputs are fully written (zeros for culled Gaussians): no pre-zeroing needed.
+ *
+ * Non-finite and extreme inputs (a position or scale step of the attack can produce them: reference attack.py:500-511).
+ * The published kernels turn them into undefined float -> int conversions and fully opaque garbage splats; here:
+ *   - a Gaussian whose projected conic, pixel centre or view depth is not finite -- NaN or +-inf in its mean, scale,
+ *     rotation or covariance, or finite values whose products overflow float32 (exp(log_scale) beyond ~1e19) -- and a
+ *     Gaussian whose (activated) opacity is NaN is CULLED: radius 0, no pairs, zero gradients, exactly as if it were behind
+ *     the camera.  Every other Gaussian renders and differentiates bit for bit as if the bad one were not in the scene;
+ *   - a finite but enormous footprint keeps the published behaviour (its tile rect is the rect clamped to the image: it
+ *     reaches every tile) with the radius saturated at 2^24 pixels; num_rendered never exceeds (Gaussians with radius > 0)
+ *     x (tiles of the image), and more than 2^31 - 1 pairs in one forward is GSR_ERR_NOMEM, not a wrapped counter;
+ *   - a NaN colour (NaN spherical-harmonics coefficients) composites as 0; an infinite one reaches the pixels of the tiles
+ *     that Gaussian touches and nothing else; a zero quaternion is the identity rotation times zero (a point: the 0.3 px^2
+ *     dilation renders it), as F.normalize's 1e-12 floor makes it in the reference.
+ * tests/test_gpu_nonfinite.py; the scalar arithmetic also runs under -fsanitize=undefined,float-cast-overflow on the host
+ * (tests/test_host_math.py).
  */
 #ifndef GSRASTER_H_
 #define GSRASTER_H_
