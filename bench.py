@@ -45,197 +45,12 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+from benchparts.common import HBM_PEAK_GBS, log, sources_digest, stage_bytes  # noqa: E402
+from benchparts.cpu import cpu_baseline, parity_and_cfg1  # noqa: E402
+from benchparts.extras import extras_and_pgd, masked_streams  # noqa: E402
+from benchparts.fanout import fan_out  # noqa: E402
+
 PMC_FILE = "r05_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r05.sh)
-
-
-def sources_digest() -> str:
-    """SHA-256 over the library's sources (csrc/*, include/gsraster.h).  profiles/collect_r05.sh stores it next to the PMC
-    counters it collects; a bench line quotes those counters as `roofline.traffic` only while the digest still matches --
-    a kernel change silently keeping the old traffic figure was possible before."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "3d-gaussian-splat-attack_amd", "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
-    files.append(os.path.join(ROOT, "include", "gsraster.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
-        h.update(open(f, "rb").read())
-    return h.hexdigest()
-
-
-def log(msg: str) -> None:
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-
-def stage_bytes(P: int, V: int, N: int, HW: int) -> dict:
-    """Algorithmic bytes per launch of each stage (SURVEY.md section 8d derivation; objects off)."""
-    return {
-        "preprocess": 48 * P + 240 * V,          # K1: 44P in + 192V SH in, 48V geometry + 4P radii out
-        "depth_sort": 0,                         # (the reference's single 64-bit pair sort is priced under tile_sort)
-        "bin": 8 * P + 12 * N,                   # K2 scan + K3 emit
-        "tile_sort": 24 * N,                     # K4 counted as ONE read + one write of the pairs (lower bound)
-        "render_fwd": 40 * N + 20 * HW,          # K6
-        "render_bwd": 20 * HW + 40 * N + 36 * V,  # K7
-        "preprocess_bwd": 272 * V + 248 * P,     # K8+K9
-    }
-
-
-def _cpu_model() -> str:
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "unknown"
-
-
-def cpu_baseline(sample_P: int, sample_W: int, sample_H: int) -> dict:
-    """oracle-R (the checker, a CPU port -- never the product path) timed on the host cores of this node."""
-    from gsplat_attack.scenes import make_scene
-    from oracle import oracle_r as O
-    import math
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    avail, machine = cores, os.cpu_count() or cores
-    cores = max(1, min(cores, 16))      # a 1-GPU box shares its host: 16 worker threads is this pool's CPU share
-    torch.set_num_threads(cores)
-    model, cams, _ = make_scene("nyc-1M", device="cpu", P=sample_P, width=sample_W, height=sample_H, n_views=1)
-    cam = cams[0]
-    st = O.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
-                    torch.zeros(3), 1.0, cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center,
-                    False, False)
-    inp = dict(means3D=model.get_xyz.detach(), shs=model.get_features.detach(), opacities=model.get_opacity.detach(),
-               scales=model.get_scaling.detach(), rotations=model.get_rotation.detach())
-    gc = torch.randn(3, sample_H, sample_W, generator=torch.Generator().manual_seed(99))
-    t0 = time.perf_counter()
-    out, _ = O.forward_backward(inp, st, gc, dtype=torch.float32)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cores": machine, "host_cores_available_to_this_process": avail, "cpu_model": _cpu_model(),
-            "seconds": dt,
-            "sample": f"oracle-R float32 fwd+bwd, ONE view of S-nyc-1M subsampled to {sample_P} Gaussians at "
-                      f"{sample_W}x{sample_H} (N={out.num_rendered} pairs); not extrapolated to 1M/1080p"}
-
-
-def parity_and_cfg1(dev) -> dict:
-    """Second half of BASELINE.json's metric, measured in the same job: the HIP path against oracle-R (float64, the
-    checker) on S-hydrant-1k @128x128 (BASELINE config 1), plus oracle-R's float32 CPU time on that config (median of
-    5 after one warm-up)."""
-    import math
-    from gsplat_attack.renderer import PipelineParams, render
-    from gsplat_attack.scenes import make_scene
-    from oracle import oracle_r as O
-    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=1)
-    cam = cams[0]
-    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
-    gc = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(99))
-    out = render(cam, model, PipelineParams(skip_objects=True), bg)
-    out["render"].backward(gc.to(dev))
-    torch.cuda.synchronize()
-    cpu = lambda t: t.detach().cpu()
-    st = O.Settings(cam.image_height, cam.image_width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), cpu(bg), 1.0,
-                    cpu(cam.world_view_transform), cpu(cam.full_proj_transform), 3, cpu(cam.camera_center), False, False)
-    ref, _, _ = make_scene("hydrant-1k", device="cpu", n_views=1)
-    ro = O.rasterize(ref.get_xyz, None, ref.get_opacity, st, shs=ref.get_features, scales=ref.get_scaling,
-                     rotations=ref.get_rotation)
-    (ro.color * gc.double()).sum().backward()
-    solid = ~ro.fragile_px
-    rgb = (cpu(out["render"]).double() - ro.color.detach()).abs().max(dim=0).values[solid].max().item()
-    rel = 0.0
-    for p_hip, p_ref in zip(model.parameters(), ref.parameters()):
-        if p_ref.grad is None or p_hip.grad is None or p_ref.grad.abs().max().item() == 0.0:
-            continue
-        rel = max(rel, ((cpu(p_hip.grad).double() - p_ref.grad).abs().max() / p_ref.grad.abs().max()).item())
-    inp = dict(means3D=ref.get_xyz.detach(), shs=ref.get_features.detach(), opacities=ref.get_opacity.detach(),
-               scales=ref.get_scaling.detach(), rotations=ref.get_rotation.detach())
-    st32 = O.Settings(st.image_height, st.image_width, st.tanfovx, st.tanfovy, st.bg.float(), 1.0, st.viewmatrix,
-                      st.projmatrix, 3, st.campos, False, False)
-    times = []
-    for i in range(6):
-        t0 = time.perf_counter()
-        O.forward_backward(inp, st32, gc, dtype=torch.float32)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[2]
-    return {"parity": {"scene": "S-hydrant-1k 128x128 (BASELINE config 1) vs oracle-R float64",
-                       "rgb_max_abs_err": rgb, "grad_max_rel_err": rel,
-                       "tolerance": {"rgb_abs": 1e-4, "grad_rel": 1e-3}},
-            "cfg1_cpu": {"value": 1.0 / med, "unit": "views/s", "seconds_median_of_5": med,
-                         "sample": "oracle-R float32 fwd+bwd, S-hydrant-1k 128x128"}}
-
-
-def _free_port() -> int:
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def fan_out(n: int) -> int:
-    """`python bench.py --gpus N` started as a PLAIN process (no torchrun: WORLD_SIZE unset): this parent starts the N
-    ranks itself -- one child per GPU running this same command line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
-    exactly what `python -m torch.distributed.run --nproc-per-node N` would give them -- touches no GPU, lets rank 0's
-    JSON line through on the inherited stdout, and returns non-zero if any child fails (the others are then stopped by
-    their exact PIDs: SIGTERM, then SIGKILL after a bounded grace period).  Under torchrun this function is never reached."""
-    import signal
-    import subprocess
-    # (the parent asks the runtime NOTHING about devices -- on ROCm builds without amdsmi even device_count() initialises
-    # HIP/HSA in this process before it forks; each rank checks its own LOCAL_RANK against the device count in main())
-    port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    pending = set(range(n))
-    kill_at = None                                         # after a failure: when the survivors' grace period ends
-    grace = float(os.environ.get("BENCH_FANOUT_GRACE_S", "20"))
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                print(f"[bench] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
-                for q in pending:
-                    procs[q].send_signal(signal.SIGTERM)
-                kill_at = time.monotonic() + grace
-        if kill_at is not None and pending and time.monotonic() > kill_at:
-            # a rank stuck in a collective does not act on SIGTERM: end it by its exact PID
-            for q in sorted(pending):
-                print(f"[bench] rank {q} (pid {procs[q].pid}) still running {grace:.0f} s after SIGTERM: SIGKILL", file=sys.stderr)
-                procs[q].kill()
-            for q in sorted(pending):
-                procs[q].wait()
-            pending.clear()
-        time.sleep(0.05)
-    return rc
-
-
-def masked_streams(dev, spec: str):
-    """HIP streams restricted to sets of compute units (hipExtStreamCreateWithCUMask), wrapped for torch."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    out = []
-    with torch.cuda.device(dev):
-        torch.cuda.current_stream(dev).synchronize()       # the runtime is initialised
-        for m in spec.split(";"):
-            words = [int(w, 16) for w in m.split(",") if w.strip()]
-            arr = (ctypes.c_uint32 * len(words))(*words)
-            h = ctypes.c_void_p(None)
-            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(len(words)), arr)
-            if rc != 0 or not h.value:
-                raise SystemExit(f"hipExtStreamCreateWithCUMask failed ({rc}) for mask {m}")
-            out.append(torch.cuda.ExternalStream(h.value, device=dev))
-    return out
 
 
 def main():
@@ -794,211 +609,6 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
-    """Untimed extras of the N = 1 line (SURVEY.md section 8d "also report"): forward-only and SH-only rates, and whole
-    PGD iterations split into phases."""
-    from gsplat_attack.attack import PhaseTimer, SurrogateDetector, pgd_attack
-    from gsplat_attack.renderer import PipelineParams, render
-    cam = cams[0]
-    log("extras: forward-only views, SH-only gradients ...")
-    with torch.no_grad():
-        run_fwd = min(args.steps, 100)
-        for s_ in (streams or []):
-            s_.wait_stream(torch.cuda.current_stream(dev))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(run_fwd):
-            if streams is None:
-                render(cam, model, pipe, bg)
-            else:
-                with torch.cuda.stream(streams[i % len(streams)]):
-                    render(cam, model, pipe, bg)
-        torch.cuda.synchronize()
-        fwd_rate = run_fwd / (time.perf_counter() - t0)
-    col_rate = None
-    if not args.color_only:
-        # gradients on the SH coefficients only (BASELINE configs 2/3): geometry frozen, lighter K7 / K8+K9
-        frozen = [getattr(model, n_) for n_ in ("_xyz", "_scaling", "_rotation", "_opacity")]
-        for p_ in frozen:
-            p_.requires_grad_(False)
-        pipe_c = PipelineParams(skip_objects=not args.objects, viewspace_grad=False)
-        n_col = min(args.steps, 150)
-
-        def col_steps(n):
-            for i in range(n):
-                ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
-                with ctx_:
-                    model.zero_grad()
-                    render(cam, model, pipe_c, bg)["render"].backward(gc)
-        for s_ in (streams or []):
-            s_.wait_stream(torch.cuda.current_stream(dev))
-        col_steps(6)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        col_steps(n_col)
-        torch.cuda.synchronize()
-        col_rate = n_col / (time.perf_counter() - t0)
-        # the same over the ring of cameras (what a batch of attack views is), without and with each camera's binning
-        # kept across renders (RenderCache -> gsr_ctx_rerender: the geometry is frozen, so only the colour kernel and the
-        # compositor run from a camera's second render on); bit-equal results (tests/test_gpu_rerender.py)
-        from diff_gaussian_rasterization import RenderCache
-        ring_rates = []
-        for cache_ in (None, RenderCache()):
-            pipe_r = PipelineParams(skip_objects=not args.objects, viewspace_grad=False, render_cache=cache_)
-
-            def ring_steps(n):
-                for i in range(n):
-                    ctx_ = torch.cuda.stream(streams[i % len(streams)]) if streams is not None else contextlib.nullcontext()
-                    with ctx_:
-                        model.zero_grad()
-                        render(cams[i % len(cams)], model, pipe_r, bg)["render"].backward(gc)
-            ring_steps(2 * len(cams))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ring_steps(n_col)
-            torch.cuda.synchronize()
-            ring_rates.append(n_col / (time.perf_counter() - t0))
-            del pipe_r, cache_
-        for p_ in frozen:
-            p_.requires_grad_(True)
-    extras = {"fwd_only_views_per_s": round(fwd_rate, 1),
-              "sh_grads_only_views_per_s": None if col_rate is None else round(col_rate, 1)}
-    if not args.color_only:
-        # The drop-in regime: what the reference's UNCHANGED render() reaches (gaussian_renderer/__init__.py:53-95) when a
-        # user installs this package without gsplat_attack.patch_reference() -- activated tensors (exp / sigmoid /
-        # normalize / cat and their backward as PyTorch kernels) through GaussianRasterizer.forward, and ALWAYS the 16
-        # object channels (`sh_objs = pc.get_objects`).  Same views, same dL/dC, gradients to all raw parameters.
-        log("extras: the drop-in regime (classic activated-tensor surface + 16 object channels) ...")
-        pipe_d = PipelineParams(skip_objects=False, fused_activations=False)
-        n_d = min(args.steps, 60)
-
-        dmodel = [model]
-
-        def dropin_steps(n, sts):
-            m_ = dmodel[0]
-            for s_ in (sts or []):
-                s_.wait_stream(torch.cuda.current_stream(dev))
-            for i in range(n):
-                ctx_ = torch.cuda.stream(sts[i % len(sts)]) if sts else contextlib.nullcontext()
-                with ctx_:
-                    m_.zero_grad()
-                    render(cams[i % len(cams)], m_, pipe_d, bg)["render"].backward(gc)
-            for s_ in (sts or []):
-                torch.cuda.current_stream(dev).wait_stream(s_)
-
-        def dropin_rates():
-            rates_ = []
-            for sts in (streams, None):
-                dropin_steps(8, sts)
-                torch.cuda.synchronize()
-                ts = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    dropin_steps(n_d, sts)
-                    torch.cuda.synchronize()
-                    ts.append(time.perf_counter() - t0)
-                rates_.append(n_d / sorted(ts)[1])
-            D.profile(True)
-            dropin_steps(6, None)
-            torch.cuda.synchronize()
-            st_ = {k: round(ms / 6, 4) for k, (ms, _) in D.profile_read().items()}
-            D.profile(False)
-            return rates_, st_
-        rates, st_d = dropin_rates()
-        # the attack's case: every object feature zero (reference scene/gaussian_model.py:528, combine_splats) -- the classic
-        # binding then composites without the object channels (GSR_FLAG_OBJECTS_FOR_BACKWARD_ONLY), same image and gradients
-        dmodel[0] = model.clone()
-        with torch.no_grad():
-            dmodel[0]._objects_dc.zero_()
-        rates_z, st_z = dropin_rates()
-        dmodel[0] = model
-        extras["dropin"] = {"value": round(rates[0], 1), "sequential_views_per_s": round(rates[1], 1), "unit": "views/s",
-                            "steps": n_d, "streams": len(streams) if streams else 1, "stages_ms": st_d,
-                            "what": "render() on the classic surface with object channels on (--classic --objects): the "
-                                    "configuration the reference's unchanged gaussian_renderer.render() reaches; median "
-                                    "of 3 regions; `value` pipelined over the streams, `sequential` on one",
-                            "zero_object_features": {
-                                "value": round(rates_z[0], 1), "sequential_views_per_s": round(rates_z[1], 1), "stages_ms": st_z,
-                                "what": "the same with every object feature zero, as in the attack's combined scenes "
-                                        "(reference scene/gaussian_model.py:528): the binding finds that out once per tensor "
-                                        "version and composites without the 16 object channels; image, object map (zeros) "
-                                        "and gradients equal the object variant's (tests/test_gpu_zero_objects.py)"}}
-    if col_rate is not None:
-        extras["sh_grads_only_ring_views_per_s"] = round(ring_rates[0], 1)
-        extras["sh_grads_only_ring_binning_kept_views_per_s"] = round(ring_rates[1], 1)
-
-    log("pgd: config 3 (colour L2, PGD-20, B = 1) and config 4 on one GPU (8 views, five groups) ...")
-    det = SurrogateDetector().to(dev)
-    never = lambda im, i: False                            # noqa: E731 -- the success check runs, the loop never stops on it
-
-    def measure(name, views, groups, iters, n_streams, rerender, cache_binning=True, batched=True):
-        m = model.clone()
-        kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0, cache_binning=cache_binning,
-                  batched=batched)
-        if rerender:
-            kw.update(success_fn=never, background=None)
-        pgd_attack(m, views, iters=3, **kw)                # warm-up
-        torch.cuda.synchronize()
-        recs = []
-        pgd_attack(m, views, iters=iters, log=recs.append, **kw)
-        torch.cuda.synchronize()
-        per_it = sorted(r["seconds"] for r in recs)
-        wall = per_it[len(per_it) // 2] * 1e3              # median iteration (each one ends with a synchronise)
-        out = {"iteration_ms": round(wall, 3), "iteration_ms_all": [round(x * 1e3, 3) for x in per_it],
-               "views": len(views), "groups": list(groups), "streams": n_streams, "what": name,
-               # colour-only attacks: each camera's rasteriser context (projection, sorts, tile lists) kept in HBM after its
-               # first render and re-used while the geometry tensors are untouched (gsr_ctx_rerender); same bits
-               "binning_kept": bool(cache_binning and tuple(groups) == ("color",)),
-               # all-attribute attacks on two or more views: the views of an iteration go through one launch chain
-               "views_batched": bool(batched and len(views) >= 2 and not (cache_binning and tuple(groups) == ("color",)))}
-        if n_streams == 1:
-            # phase split on one stream: HIP events at the phase boundaries + the library's own stage events
-            tm = PhaseTimer()
-            D.profile(True)
-            pgd_attack(m, views, iters=iters, timer=tm, **kw)
-            ph = {k: v / iters for k, v in tm.totals_ms().items()}
-            st = {k: ms / iters for k, (ms, _) in D.profile_read().items()}
-            D.profile(False)
-            r_bwd = st["render_bwd"] + st["preprocess_bwd"]
-            out["phases_ms"] = {
-                "raster_forward": round(ph["render"], 3),
-                "raster_backward": round(r_bwd, 3),
-                "detector": round(ph["loss"] + max(ph["backward"] - r_bwd, 0.0), 3),
-                "gradient_accumulation": round(ph["reduce"], 3),
-                "step": round(ph["step"], 3),
-                "rerender": round(ph["rerender"], 3),
-            }
-            tot = sum(out["phases_ms"].values())
-            in_scope_overhead = out["phases_ms"]["gradient_accumulation"] + out["phases_ms"]["step"]
-            out["overhead_frac"] = round(in_scope_overhead / max(tot, 1e-9), 4)
-            out["phases_note"] = ("HIP events on the one stream (with the library's per-stage events on, which add a few "
-                                  "microseconds per stage); detector = surrogate forward + its share of backward; "
-                                  "overhead_frac = (gradient_accumulation + step) / sum of phases")
-        del m
-        return out
-    pgd = {
-        "cfg3": measure("BASELINE config 3: DAGGER PGD-20, L2 on the SH colour only, ONE view per iteration, forward-only "
-                        "re-render after every step (attack.py:522-530), surrogate detector; the camera's binning is kept "
-                        "across iterations (the geometry is frozen)", cams[:1], ("color",), 20, 1, True),
-        "cfg3_rebinned_every_render": measure("config 3 with every render running the whole forward (cache_binning=False): "
-                                              "what a rasteriser without kept contexts does", cams[:1], ("color",), 20, 1, True,
-                                              cache_binning=False),
-        "cfg3_8views": measure("config 3's colour attack on a batch of 8 views over 4 streams, binning kept", cams[:8],
-                               ("color",), 6, max(args.streams, 1), True),
-        "cfg3_8views_rebinned_every_render": measure("the same, every render the whole forward", cams[:8], ("color",), 6,
-                                                     max(args.streams, 1), True, cache_binning=False),
-        "cfg4_one_gpu": measure("BASELINE config 4 on one GPU: 8 views per iteration, L2 on {colour, position, scaling, "
-                                "rotation, opacity}, one stream, the 8 views as ONE batch (gsr_forward_raw_batch)", cams[:8],
-                                ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False),
-        "cfg4_one_gpu_pipelined": measure("the same with the 8 views dealt over 4 streams, one render() per view", cams[:8],
-                                          ("color", "position", "scaling", "rotation", "opacity"), 6, max(args.streams, 1), False,
-                                          batched=False),
-        "cfg4_one_gpu_per_view": measure("the same on one stream with one render() + backward per view (round 5's loop)", cams[:8],
-                                         ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False, batched=False),
-    }
-    return extras, pgd
 
 
 if __name__ == "__main__":

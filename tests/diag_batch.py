@@ -40,7 +40,21 @@ def main():
         bucket.reset()
         render_batch(cams, model, pipe, bg)["render"].backward(gcb)
 
-    for name, fn in (("sequential", seq), ("batched", bat)):
+    # two batches in flight on two streams (each with its own bucket): the front end of one beside the compositors of the other
+    streams2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    buckets2 = [D.GradBucket(P, dev) for _ in range(2)]
+    pipes2 = [PipelineParams(skip_objects=True, grad_bucket=b) for b in buckets2]
+    flip = [0]
+
+    def bat2():
+        i = flip[0] = flip[0] ^ 1
+        with torch.cuda.stream(streams2[i]):
+            buckets2[i].reset()
+            render_batch(cams, model, pipes2[i], bg)["render"].backward(gcb)
+
+    for s_ in streams2:
+        s_.wait_stream(torch.cuda.current_stream(dev))
+    for name, fn in (("sequential", seq), ("batched", bat), ("batched-2streams", bat2)):
         if only and name != only:
             continue
         for _ in range(3):
