@@ -726,6 +726,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   sp.add<uint32_t>((size_t)RS_BINS_DEV * nbP); sp.add<uint32_t>(RS_BINS_DEV);
   sp.add<uint4>(nk1); sp.add<uint32_t>(nbP + 2);
   if (group_sums) sp.add<uint4>(ngroups);
+  sp.add<uint8_t>(Pp);
   void* scratch_blk = pool_alloc(dev, sp.bytes + 256, st);
   if (!c->keep_blk || !scratch_blk) {
     pool_free(dev, scratch_blk);
@@ -749,6 +750,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
   uint4* bout = ss.take<uint4>(nk1);
   uint32_t* psums = ss.take<uint32_t>(nbP + 2);
   uint4* gsum = group_sums ? ss.take<uint4>(ngroups) : nullptr;
+  uint8_t* tcnt8 = ss.take<uint8_t>(Pp);
 
   void* pairs_blk[4] = {nullptr, nullptr, nullptr, nullptr};
   void* tbl_blk = nullptr;
@@ -844,6 +846,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
         pa.means = means3D; pa.scales = scales; pa.rots = rotations; pa.cov3d = cov3D_precomp;
         pa.opac = opacities; pa.sh = shs; pa.sh_dc = sh_dc; pa.colors = colors_precomp; pa.radii = radii;
         pa.G0 = G0; pa.G1 = G1; pa.G2 = G2; pa.D = c->D; pa.dkey = dkey; pa.tcnt = tcnt; pa.offg = nullptr;
+        pa.tcnt8 = tcnt8;
         pa.abc = c->abc;
         pa.Pa = segb ? P - segb->Pb : P;
         pa.means_b = segb ? segb->xyz : nullptr; pa.scales_b = segb ? segb->scaling : nullptr;
@@ -903,14 +906,15 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
                             c->dv + DV_V, nullptr, nullptr, st);
         radix_pass<RS_BINS>(k1, vtmp, dkey, v2, (uint32_t)Pv, nV, d1, rn, table, tsums, true, 0, 0, nullptr, nullptr, nullptr, st);
         radix_pass<RS_BINS>(dkey, v2, k1, vtmp, (uint32_t)Pv, nV, d2, rn, table, tsums, true, 0, 0, nullptr, nullptr, nullptr, st);
-        radix_pass<RS_BINS>(k1, vtmp, nullptr, c->order, (uint32_t)Pv, nV, d3, rn, table, tsums, true, 0, 0, nullptr, tcnt, v2, st);
+        radix_pass<RS_BINS>(k1, vtmp, nullptr, c->order, (uint32_t)Pv, nV, d3, rn, table, tsums, true, 0, 0, nullptr, tcnt, v2, st,
+                            nullptr, 0, c->lanegroup ? tcnt8 : nullptr);
       } else {
       radix_pass<RS_BINS_DEV>(dkey, nullptr, k1, vtmp, (uint32_t)Pv, nullptr, d0, DROUNDS, table, tsums, false, 1, 1,
                               c->dv + DV_V, nullptr, nullptr, st);
       radix_pass<RS_BINS_DEV>(k1, vtmp, dkey, v2, (uint32_t)Pv, nV, d1, DROUNDS, table, tsums, true, 0, 0, nullptr, nullptr,
                               nullptr, st);
       radix_pass<RS_BINS_DEV>(dkey, v2, nullptr, c->order, (uint32_t)Pv, nV, d2, DROUNDS, table, tsums, true, 0, 0, nullptr,
-                              tcnt, vtmp, st);
+                              tcnt, vtmp, st, nullptr, 0, c->lanegroup ? tcnt8 : nullptr);
       }
       F_LAUNCH("depth sort");
     }
@@ -1332,7 +1336,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     // (GSR_BATCH_K9=0: one k_pre_bwd launch per view instead, the others in accumulate mode -- the A/B and the bit-exact form)
     const bool batch_fused = c->B > 1 && c->raw && c->lanegroup && batch_k9_fused();
     void* ss_blk = nullptr;
-    const int ss_blocks = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    const int ss_blocks = batch_fused ? ((P + 63) / 64) * BATCH_K9_WAVES : (P + PRE_BLOCK - 1) / PRE_BLOCK;
     pa.sumsq = nullptr;
     if (ss_out) {
       if (!(c->lanegroup && c->raw) || accumulate || nchunks != 1 || (c->B > 1 && !batch_fused))
@@ -1354,14 +1358,14 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
         ba.means = c->means3D; ba.scales = c->scales; ba.rots = c->rots; ba.D = c->D;
         ba.dmeans3D = dmeans3D; ba.dmeans2D = dmeans2D; ba.dsh = dshs; ba.dsh_dc = dsh_dc; ba.dopac = dopacities;
         ba.dscales = dscales; ba.drots = drotations; ba.sumsq = pa.sumsq;
-        const dim3 gridB((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK));
+        const dim3 gridB((unsigned)((ge - gb + 63) / 64)), blkB(64 * BATCH_K9_WAVES);
         const size_t lds = sizeof(float) * 3 * 64 * (size_t)c->B;
         if (geom) {
-          if (accumulate) hipLaunchKernelGGL((k_pre_bwd_batch<true, true>), gridB, dim3(PRE_BLOCK), lds, st, ba);
-          else hipLaunchKernelGGL((k_pre_bwd_batch<true, false>), gridB, dim3(PRE_BLOCK), lds, st, ba);
+          if (accumulate) hipLaunchKernelGGL((k_pre_bwd_batch<true, true>), gridB, blkB, lds, st, ba);
+          else hipLaunchKernelGGL((k_pre_bwd_batch<true, false>), gridB, blkB, lds, st, ba);
         } else {
-          if (accumulate) hipLaunchKernelGGL((k_pre_bwd_batch<false, true>), gridB, dim3(PRE_BLOCK), lds, st, ba);
-          else hipLaunchKernelGGL((k_pre_bwd_batch<false, false>), gridB, dim3(PRE_BLOCK), lds, st, ba);
+          if (accumulate) hipLaunchKernelGGL((k_pre_bwd_batch<false, true>), gridB, blkB, lds, st, ba);
+          else hipLaunchKernelGGL((k_pre_bwd_batch<false, false>), gridB, blkB, lds, st, ba);
         }
       }
       for (int v = 0; !batch_fused && ge > gb && v < c->B; ++v) {

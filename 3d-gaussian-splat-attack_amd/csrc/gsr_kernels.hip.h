@@ -1735,6 +1735,7 @@ struct PreArgs {
   double* abc;            // [P] k_pre_geom<., NDL>: needle marks for K9 (the needle's 2D covariance entry a, or NaN: not a needle), or null
   uint32_t* dkey;         // float bits of the view depth; 0xFFFFFFFF for a Gaussian that emits no pair
   uint32_t* tcnt;         // tiles of the (tightened) rect
+  uint8_t* tcnt8;         // k_pre_geom: the same saturated at 255 (the depth sort's last pass gathers tiles-per-rank from it), or null
   const uint32_t* offg;   // colour kernel with tcnt == null (re-render of a kept context): a Gaussian emits pairs iff
                           // offg[g + 1] != offg[g] (the storage-order scan of tcnt, which the context keeps)
   int cull;               // != 0: shrink the rect to the alpha >= 1/255 footprint (tighten_rect)
@@ -1829,9 +1830,11 @@ __global__ void __launch_bounds__(PREG_BLOCK) k_pre_geom(PreArgs a) {
     }
     a.dkey[vo + g] = key;
     a.tcnt[vo + g] = cnt;
+    if (a.tcnt8) a.tcnt8[vo + g] = (uint8_t)min(cnt, 255u);
   } else if (g < a.Pfill) {
     a.dkey[vo + g] = 0xFFFFFFFFu;
     a.tcnt[vo + g] = 0u;
+    if (a.tcnt8) a.tcnt8[vo + g] = 0;
   }
   PreBlockOut bo = a.bo;
   if (bo.ranges != nullptr) bo.ranges += (size_t)view * (size_t)bo.ntiles;     // this view's tiles
@@ -2362,22 +2365,27 @@ struct PreBwdBatchArgs {
   float* sumsq;           // ACC = false only, or null: [workgroups][SUMSQ_W] sums of squares of what is written
 };
 
+// A workgroup is BATCH_K9_WAVES waves that share 64 Gaussians: wave w walks the views v = w, w + W, ... (the walk is a chain of
+// dependent memory phases per view; W chains of B / W views finish sooner than one of B), the waves' sums meet in LDS, wave 0
+// finishes and stores the geometry gradients, and the dL/dSH phase is dealt over the waves by groups of 16 Gaussians.
+constexpr int BATCH_K9_WAVES = 2;
 template <bool GEOM, bool ACC>
-__global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd_batch(PreBwdBatchArgs a) {
-  static_assert(PRE_WAVES == 1, "one wave per workgroup: the LDS arrays below are the wave's own");
-  __shared__ float4 srow[ROW_CHUNK * PART_F4];
+__global__ void __launch_bounds__(64 * BATCH_K9_WAVES) k_pre_bwd_batch(PreBwdBatchArgs a) {
+  __shared__ float4 srow_all[BATCH_K9_WAVES][ROW_CHUNK * PART_F4];
   __shared__ float spos[64 * 3];
-  __shared__ uint32_t sany[64];
+  __shared__ uint32_t sany[BATCH_K9_WAVES][64];
+  __shared__ float sacc[BATCH_K9_WAVES > 1 ? BATCH_K9_WAVES - 1 : 1][12][64];     // the other waves' sums: [value][lane]
   extern __shared__ float shrgb[];                       // [B][64][3]
   const int lane = threadIdx.x & 63;
-  const int gw0 = a.g0 + blockIdx.x * PRE_BLOCK;         // first Gaussian of this wave
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float4* const srow = srow_all[wave];
+  const int gw0 = a.g0 + blockIdx.x * 64;                // first Gaussian of this workgroup
   const int g = gw0 + lane;
-  const int nw = min(64, a.P - gw0);
-  if (nw <= 0) return;
+  const int nw = min(64, a.P - gw0);                     // (the grid covers [g0, P): nw >= 1)
   const bool mine = g < a.P;
   float p[3] = {0.f, 0.f, 0.f};
   if (mine) { p[0] = a.means[3 * g]; p[1] = a.means[3 * g + 1]; p[2] = a.means[3 * g + 2]; }
-  spos[3 * lane] = p[0]; spos[3 * lane + 1] = p[1]; spos[3 * lane + 2] = p[2];
+  if (wave == 0) { spos[3 * lane] = p[0]; spos[3 * lane + 1] = p[1]; spos[3 * lane + 2] = p[2]; }
   // view-independent: activated scale / rotation and the 3D covariance
   // (the activated scale and rotation themselves are formed again behind the view loop, where dL/dSigma3D is pushed through
   // them: eight registers less across the loop)
@@ -2396,7 +2404,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd_batch(PreBwdBatchArgs a) 
   float dp[3] = {0.f, 0.f, 0.f}, dc6s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dops = 0.f, opv = 0.f;
   bool any = false;
 #pragma unroll 1
-  for (int v = 0; v < a.B; ++v) {
+  for (int v = wave; v < a.B; v += BATCH_K9_WAVES) {
     const size_t o = (size_t)v * (size_t)a.Ppad;
     const uint32_t* offg = a.offg + o;
     uint32_t o0 = 0, o1 = 0;
@@ -2500,12 +2508,36 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd_batch(PreBwdBatchArgs a) 
     float* hs = shrgb + ((size_t)v * 64 + lane) * 3;
     hs[0] = hr[0]; hs[1] = hr[1]; hs[2] = hr[2];
   }
-  sany[lane] = any ? 1u : 0u;
-  // ---- the sums over the views: scale / rotation / opacity through the activations, then the stores ----------------------
+  sany[wave][lane] = any ? 1u : 0u;
+  // ---- the waves' sums meet: waves 1.. park theirs, wave 0 adds them up --------------------------------------------------
+  if (BATCH_K9_WAVES > 1) {
+    if (GEOM && wave > 0) {
+      float (*dst)[64] = sacc[wave - 1];
+      dst[0][lane] = dp[0]; dst[1][lane] = dp[1]; dst[2][lane] = dp[2];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dst[3 + i][lane] = dc6s[i];
+      dst[9][lane] = dops; dst[10][lane] = opv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BATCH_K9_WAVES; ++w) any = any || sany[w][lane] != 0u;
+    if (GEOM && wave == 0) {
+#pragma unroll
+      for (int w = 1; w < BATCH_K9_WAVES; ++w) {
+        float (*src)[64] = sacc[w - 1];
+        dp[0] += src[0][lane]; dp[1] += src[1][lane]; dp[2] += src[2][lane];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dc6s[i] += src[3 + i][lane];
+        dops += src[9][lane];
+        if (sany[w][lane] != 0u) opv = src[10][lane];
+      }
+    }
+  }
+  // ---- the sums over the views: scale / rotation / opacity through the activations, then the stores (wave 0) --------------
   float ssq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool want_ss = !ACC && a.sumsq != nullptr;
   auto put = [](float* ptr, float val) { if (ACC) *ptr += val; else *ptr = val; };
-  if (GEOM && mine && (any || !ACC)) {
+  if (GEOM && wave == 0 && mine && (any || !ACC)) {
     float ds[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     if (any && (a.dscales || a.drots)) {
       float sc[3], q[4], inv_qn;
@@ -2537,22 +2569,27 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd_batch(PreBwdBatchArgs a) 
 #pragma unroll
     for (int k = 0; k < 6; ++k) ssq[k] = wave_sum_to_hi(ssq[k]);
     if (lane == 63) {
-      float* dst = a.sumsq + (size_t)blockIdx.x * SUMSQ_W;
+      float* dst = a.sumsq + ((size_t)blockIdx.x * BATCH_K9_WAVES + wave) * SUMSQ_W;      // every wave of the grid writes its slot
 #pragma unroll
       for (int k = 0; k < 6; ++k) dst[k] = ssq[k];
     }
   };
   if (a.dsh == nullptr) { flush_sumsq(); return; }
-  // ---- dL/dSH = sum over the views of basis(direction of the view) x dL/drgb of the view: four lanes per Gaussian ---------
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- dL/dSH = sum over the views of basis(direction of the view) x dL/drgb of the view: four lanes per Gaussian, the
+  // groups of 16 Gaussians dealt over the waves (the views' dL/drgb of all 64 are in LDS behind the barrier above) -----------
+  if (BATCH_K9_WAVES == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   const int qd = lane & 3, grp = lane >> 2;
 #pragma unroll 1
-  for (int r0 = 0; r0 < nw; r0 += 16) {
+  for (int r0 = 16 * wave; r0 < nw; r0 += 16 * BATCH_K9_WAVES) {
     const int si = r0 + grp;
     if (si < nw) {
-      const bool seen = sany[si] != 0u;
+      bool seen = false;
+#pragma unroll
+      for (int w = 0; w < BATCH_K9_WAVES; ++w) seen = seen || sany[w][si] != 0u;
       float out[12];
 #pragma unroll
       for (int j = 0; j < 12; ++j) out[j] = 0.f;

@@ -322,7 +322,8 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
                                                               int iota, int drop, uint32_t* __restrict__ count_out,
                                                               const uint32_t* __restrict__ aux_src,
                                                               uint32_t* __restrict__ aux_out,
-                                                              uint32_t* __restrict__ key_ranges, uint32_t key_limit) {
+                                                              uint32_t* __restrict__ key_ranges, uint32_t key_limit,
+                                                              const uint8_t* __restrict__ aux_src8 = nullptr) {
   constexpr int RS_CHUNK = rs_chunk(RS_ROUNDS);
   constexpr int MAXW = BINS == 256 ? 8 : (BINS == 512 ? 9 : (BINS == 1024 ? 10 : 11));
   static_assert(BINS == (1 << MAXW), "BINS is a power of two between 256 and 2048");
@@ -444,7 +445,15 @@ __global__ void __launch_bounds__(RS_THREADS) k_radix_scatter(const uint32_t* __
     const uint32_t v = sval[p];
     if (keys_out) keys_out[g] = k;
     vals_out[g] = v;
-    if (aux_out) aux_out[g] = aux_src[v];
+    if (aux_out) {
+      // aux_src8 (optional): the same numbers saturated at 255 in a byte array -- a random gather over millions of elements
+      // then touches an eighth of the sectors (8 MB instead of 32 MB for a batch of eight 1 M-Gaussian views: most of it
+      // stays in the XCDs' L2s); 255 = look the number up in the 32-bit array
+      uint32_t ax;
+      if (aux_src8) { ax = aux_src8[v]; if (ax == 255u) ax = aux_src[v]; }
+      else ax = aux_src[v];
+      aux_out[g] = ax;
+    }
     if (key_ranges && k < key_limit) {
       // LAST pass of a sort on the whole key: equal keys end up contiguous, [key_ranges[2k], key_ranges[2k+1]) is key
       // k's span of the output.  A run of equal keys inside this block's sorted chunk is a piece of that span (pieces of
@@ -474,7 +483,7 @@ template <int BINS>
 inline void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n,
                        const uint32_t* n_dev, const DigitSpec& ds, int rounds, uint32_t* table, uint32_t* sums, bool hist,
                        int iota, int drop, uint32_t* count_out, const uint32_t* aux_src, uint32_t* aux_out,
-                       hipStream_t st, uint32_t* key_ranges = nullptr, uint32_t key_limit = 0) {
+                       hipStream_t st, uint32_t* key_ranges = nullptr, uint32_t key_limit = 0, const uint8_t* aux_src8 = nullptr) {
   const uint32_t chunk = (uint32_t)rs_chunk(rounds);
   const uint32_t nb = (n + chunk - 1) / chunk;
   if (rounds == RS_ROUNDS_MIN) {
@@ -482,13 +491,13 @@ inline void radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uin
     hipLaunchKernelGGL(k_radix_rowscan, dim3(BINS / RS_WAVES), dim3(RS_THREADS), 0, st, table, nb, n, n_dev, chunk, ds, sums);
     hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MIN, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, n_dev, ds,
                        (const uint32_t*)table, (const uint32_t*)sums, nb, iota, drop, count_out, aux_src, aux_out,
-                       key_ranges, key_limit);
+                       key_ranges, key_limit, aux_src8);
   } else {
     if (hist) hipLaunchKernelGGL((k_radix_hist<RS_ROUNDS_MAX, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, n, n_dev, ds, table, nb);
     hipLaunchKernelGGL(k_radix_rowscan, dim3(BINS / RS_WAVES), dim3(RS_THREADS), 0, st, table, nb, n, n_dev, chunk, ds, sums);
     hipLaunchKernelGGL((k_radix_scatter<RS_ROUNDS_MAX, BINS>), dim3(nb), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, n_dev, ds,
                        (const uint32_t*)table, (const uint32_t*)sums, nb, iota, drop, count_out, aux_src, aux_out,
-                       key_ranges, key_limit);
+                       key_ranges, key_limit, aux_src8);
   }
 }
 
