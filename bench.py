@@ -50,7 +50,7 @@ from benchparts.cpu import cpu_baseline, parity_and_cfg1  # noqa: E402
 from benchparts.extras import extras_and_pgd, masked_streams  # noqa: E402
 from benchparts.fanout import fan_out  # noqa: E402
 
-PMC_FILE = "r05_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r05.sh)
+PMC_FILE = "r06_pmc_traffic.json"   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/collect_r06.sh)
 
 
 def main():
@@ -456,7 +456,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             if pmc.get("sources_sha256") != sources_digest():
                 traffic_note = (f"profiles/{PMC_FILE} was collected from other kernel sources than this build's (digest "
-                                "mismatch): not quoted; run profiles/collect_r05.sh again")
+                                "mismatch): not quoted; run profiles/collect_r06.sh again")
                 raise LookupError(traffic_note)
             kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2, 1>",
                     "preprocess_bwd": "void gsr::k_pre_bwd<true, true, false>",

@@ -467,6 +467,45 @@ def test_cfg4_views_of_a_batch_accumulate_at_full_size():
         assert norm <= GRAD_TOL and frac <= 3e-3, (n, norm, frac)
 
 
+def test_cfg4_batch_of_four_views_through_one_launch_chain_vs_windowed_oracle():
+    """BASELINE config 4's rasterisation as ONE batch (gsr_forward_raw_batch / gsr_backward_raw_batch_into): four ring views
+    of S-nyc-1M at 1080p rendered by one launch chain -- every view's image against the windowed oracle on its own windows,
+    and the batch's summed gradients (written once per Gaussian by k_pre_bwd_batch) against the SUM of the oracle's per-view
+    gradients, all five attribute groups."""
+    import diff_gaussian_rasterization as Dm
+    from gsplat_attack.renderer import PipelineParams, render_batch
+    D = _hip()
+    dev, model, cams = _scene_on_gpu("nyc-1M", 6)
+    bg = torch.tensor([0.05, 0.0, 0.1])
+    idx = (0, 2, 3, 5)
+    views = [cams[i] for i in idx]
+    per_view = []
+    for vi, cam in zip(idx, views):
+        wins, longest, gx, gy, keys = _windows_for(D, model, cam, bg.to(dev))
+        wins = wins[:3]
+        m = window_mask(wins, 1080, 1920)
+        gc = torch.randn(3, 1080, 1920, generator=torch.Generator().manual_seed(60 + vi)) * m
+        ro, rgrads, gc, _ = oracle_raw("nyc-1M", vi, bg, gc, wins, keys=keys, n_views=6)
+        per_view.append((gc.to(dev), rgrads, ro, m))
+    bucket = Dm.GradBucket(int(model.get_xyz.shape[0]), dev)
+    out = render_batch(views, model, PipelineParams(skip_objects=True, grad_bucket=bucket), bg.to(dev))
+    out["render"].backward(torch.stack([pv[0] for pv in per_view]))
+    torch.cuda.synchronize()
+    for v, (_, _, ro, m) in enumerate(per_view):
+        err = (out["render"][v].detach().cpu().double() - ro.color.detach()).abs().max(dim=0).values
+        solid = m & ~ro.fragile_px
+        assert err[solid].max().item() <= RGB_TOL, (v, err[solid].max().item())
+        _note(f"[cfg4 batch of four, view {idx[v]}] solid RGB err {err[solid].max().item():.2e}")
+    got = bucket.views()
+    names = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "scaling": "_scaling", "rotation": "_rotation",
+             "opacity": "_opacity"}
+    for n in RAW:
+        want = sum(pv[1][n] for pv in per_view)
+        norm, frac = grad_error(got[names[n]].detach().cpu().reshape(want.shape), want, elem_tol=5 * GRAD_TOL)
+        _note(f"[cfg4 batch of four] {n}: normwise {norm:.2e}, elements off {frac:.1e}")
+        assert norm <= GRAD_TOL and frac <= 3e-3, (n, norm, frac)
+
+
 def getattr_grad(model, name):
     return model.named_parameters()[name].grad.detach().cpu()
 
