@@ -11,8 +11,8 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/r06
 mkdir -p $OUT
-PMCB="python3 $R/bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras"
-STATS="python3 $R/bench.py --steps 100 --warmup 10 --regions 3 --no-cpu-baseline --no-extras"
+PMCB="python3 $R/bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras --batch 0"
+STATS="python3 $R/bench.py --steps 100 --warmup 10 --regions 3 --no-cpu-baseline --no-extras --batch 0"
 if [ "${PART:-A}" = "A" ]; then
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $STATS > $OUT/bench_stats.json 2> $OUT/bench_stats.err || exit 1
@@ -55,7 +55,7 @@ def digest():
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()
-json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras",
+json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras --batch 0 (single-view launches only: the batched block launches the same kernels over eight views at once)",
            "sources_sha256": digest(), "per_kernel": res},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_fetch_x2"] / 1e6, 1) for k, v in res.items()}, indent=1))

@@ -19,12 +19,16 @@ from gsplat_attack.renderer import PipelineParams, render  # noqa: E402
 from gsplat_attack.scenes import make_scene  # noqa: E402
 
 NV = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+MODE = sys.argv[2] if len(sys.argv) > 2 else "fused"          # "dropin": the classic surface + object channels, one stream
 dev = torch.device("cuda:0")
 model, cams, _ = make_scene("nyc-1M", device=dev, n_views=8)
 bg = torch.zeros(3, device=dev)
 gc = torch.randn(3, cams[0].image_height, cams[0].image_width, device=dev)
-pipe = PipelineParams(skip_objects=True)
-streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+pipe = PipelineParams(skip_objects=True) if MODE == "fused" else PipelineParams(skip_objects=False, fused_activations=False)
+if MODE == "dropin0":
+    with torch.no_grad():
+        model._objects_dc.zero_()
+streams = [torch.cuda.Stream(device=dev) for _ in range(4 if MODE == "fused" else 1)]
 lib = D._load()
 acc = {}
 
@@ -48,7 +52,7 @@ def run(n):
     for s_ in streams:
         s_.wait_stream(torch.cuda.current_stream(dev))
     for i in range(n):
-        with torch.cuda.stream(streams[i % 4]):
+        with torch.cuda.stream(streams[i % len(streams)]):
             model.zero_grad()
             render(cams[i % 8], model, pipe, bg)["render"].backward(gc)
     for s_ in streams:
@@ -57,7 +61,7 @@ def run(n):
 
 run(16)
 torch.cuda.synchronize()
-for name in ("gsr_forward_raw", "gsr_backward_raw", "gsr_backward_raw_into"):
+for name in ("gsr_forward_raw", "gsr_backward_raw", "gsr_backward_raw_into", "gsr_forward", "gsr_backward"):
     setattr(lib, name, Timed(getattr(lib, name), name))
 pr = cProfile.Profile()
 t0 = time.perf_counter()
@@ -67,7 +71,7 @@ pr.disable()
 host = time.perf_counter() - t0
 torch.cuda.synchronize()
 wall = time.perf_counter() - t0
-print(f"{NV} views over 4 streams: {NV / wall:.0f} views/s, host {host / NV * 1e3:.3f} ms per view to enqueue (profiler on)")
+print(f"{MODE}: {NV} views over {len(streams)} stream(s): {NV / wall:.0f} views/s, host {host / NV * 1e3:.3f} ms per view to enqueue (profiler on)")
 for k, (t, c) in acc.items():
     print(f"  inside {k}: {t / NV * 1e3:.3f} ms per view ({c} calls)")
 st = pstats.Stats(pr)
