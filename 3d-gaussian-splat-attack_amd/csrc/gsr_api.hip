@@ -588,7 +588,10 @@ static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hi
   const dim3 blkT(64);
   // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
   // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
-  const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : 2);
+  // From 16 384 tiles on (a 4K image, a batch of two or more 1080p views) one wave per tile: the chip is full of waves either
+  // way, and a tile's list is then staged once instead of once per half tile (S-airport-4K K6 0.215 -> 0.207 ms, an 8-view batch
+  // of S-nyc-1M 0.140 -> 0.129 ms per view; at 8160 tiles the longer items cost more in the kernel's tail than they save).
+  const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : (ntiles < 16384 ? 2 : 4));
   const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
   // the tile's waves as one workgroup that stages every batch once (k_render_fwd's WPB): S-nyc-1M gathers 596 -> 367 MB
   // but runs 0.197 -> 0.224 ms (two workgroup barriers per batch, and the waves of a tile wait for each other), so
@@ -1201,7 +1204,10 @@ static bool batch_k9_fused() {
 static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_objects, float* dmeans3D, float* dmeans2D,
                          float* dshs, float* dsh_dc, float* dsh_objs, float* dcolors_precomp, float* dopacities,
                          float* dscales, float* drotations, float* dcov3D, void* stream, bool accumulate = false,
-                         int nchunks = 1, gsr_chunk_fn chunk_done = nullptr, void* chunk_user = nullptr) {
+                         int nchunks = 1, gsr_chunk_fn chunk_done = nullptr, void* chunk_user = nullptr,
+                         int64_t view_stride = 0) {
+  // view_stride != 0 (gsr_backward_raw_batch_views): a batch context's PER-VIEW gradients -- the attribute-gradient pointers
+  // are view 0's buffers, view v's lie v * view_stride floats further; every view's buffers are overwritten
   if (!c) return set_err(GSR_ERR_STATE, "gsr_backward: null context");
   // gsr_ctx_request_sumsq is one-shot: the request is taken (and the context disarmed) here, whatever this call's fate --
   // a backward that fails early must not leave the next one writing six doubles to a buffer that may be gone by then
@@ -1334,7 +1340,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     // what it writes; one small launch behind it adds them up per tensor (fixed order) into the caller's six doubles
     // a batch of views: ONE launch of k_pre_bwd_batch per range walks the B views and writes the gradients once
     // (GSR_BATCH_K9=0: one k_pre_bwd launch per view instead, the others in accumulate mode -- the A/B and the bit-exact form)
-    const bool batch_fused = c->B > 1 && c->raw && c->lanegroup && batch_k9_fused();
+    const bool batch_fused = c->B > 1 && c->raw && c->lanegroup && batch_k9_fused() && view_stride == 0;
     void* ss_blk = nullptr;
     const int ss_blocks = batch_fused ? ((P + 63) / 64) * BATCH_K9_WAVES : (P + PRE_BLOCK - 1) / PRE_BLOCK;
     pa.sumsq = nullptr;
@@ -1370,8 +1376,14 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
       }
       for (int v = 0; !batch_fused && ge > gb && v < c->B; ++v) {
         const size_t o = (size_t)v * (size_t)c->Ppad;
-        const bool acc_v = accumulate || v > 0;
+        const bool acc_v = view_stride == 0 && (accumulate || v > 0);
         if (c->B > 1) {
+          if (view_stride != 0) {               // this view's own gradient buffers
+            const size_t vs = (size_t)v * (size_t)view_stride;
+            pa.dmeans3D = dmeans3D ? dmeans3D + vs : nullptr; pa.dsh = dshs ? dshs + vs : nullptr;
+            pa.dsh_dc = dsh_dc ? dsh_dc + vs : nullptr; pa.dopac = dopacities ? dopacities + vs : nullptr;
+            pa.dscales = dscales ? dscales + vs : nullptr; pa.drots = drotations ? drotations + vs : nullptr;
+          }
           pa.va = view_args(c->views[v]);
           pa.offg = c->offg + o; pa.G0 = c->G0 + REC * o; pa.G1 = c->G1 + REC * o; pa.G2 = c->G2 + REC * o;
           pa.D = c->D ? c->D + 9 * o : nullptr; pa.abc = c->abc ? c->abc + o : nullptr;
@@ -1454,6 +1466,15 @@ int gsr_backward_raw_batch_into(GsrCtx* c, const float* grad_color, float* dxyz,
   if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw_batch_into: context came from gsr_forward; use gsr_backward");
   return backward_impl(c, grad_color, nullptr, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, nullptr, nullptr, dopacity_logit,
                        dlog_scaling, drotation_raw, nullptr, stream, accumulate != 0);
+}
+
+int gsr_backward_raw_batch_views(GsrCtx* c, const float* grad_color, float* dxyz, float* dmeans2D, float* dfeatures_dc,
+                                 float* dfeatures_rest, float* dopacity_logit, float* dlog_scaling, float* drotation_raw,
+                                 int64_t view_stride, void* stream) {
+  if (c && !c->raw) return set_err(GSR_ERR_STATE, "gsr_backward_raw_batch_views: context came from gsr_forward; use gsr_backward");
+  if (view_stride <= 0) return set_err(GSR_ERR_INVALID, "gsr_backward_raw_batch_views: view_stride must be positive (floats between two views' buffers)");
+  return backward_impl(c, grad_color, nullptr, dxyz, dmeans2D, dfeatures_rest, dfeatures_dc, nullptr, nullptr, dopacity_logit,
+                       dlog_scaling, drotation_raw, nullptr, stream, false, 1, nullptr, nullptr, view_stride);
 }
 
 int gsr_mark_visible(const GsrSettings* s, int32_t P, const float* means3D, uint8_t* present, void* stream) {

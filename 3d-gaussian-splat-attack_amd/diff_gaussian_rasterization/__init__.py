@@ -135,6 +135,8 @@ def _load():
         lib.gsr_forward_raw_batch.argtypes = ([ctypes.POINTER(_CSettings), i32, i32] + [vp] * 6 + [vp, vp, ctypes.POINTER(vp), i64p, vp])
         lib.gsr_backward_raw_batch_into.restype = ctypes.c_int
         lib.gsr_backward_raw_batch_into.argtypes = [vp] * 9 + [i32, vp]
+        lib.gsr_backward_raw_batch_views.restype = ctypes.c_int
+        lib.gsr_backward_raw_batch_views.argtypes = [vp] * 9 + [ctypes.c_int64, vp]
     lib.gsr_ctx_rerender.restype = ctypes.c_int
     lib.gsr_ctx_rerender.argtypes = [vp] * 8 + [ctypes.c_uint32, vp]
     lib.gsr_ctx_free.restype = None
@@ -662,6 +664,28 @@ class GradBucket:
             p.grad = v.view(p.shape)
 
 
+class GradBucketSet:
+    """B gradient buckets of one model, one per view of a batch, in ONE flat buffer [B, 59 P] (each bucket laid out like a
+    GradBucket: xyz | f_dc | f_rest | opacity | scaling | rotation).  Handed to rasterize_gaussians_raw_batch / render_batch
+    (PipelineParams.grad_bucket) in place of a GradBucket, it receives every view's OWN attribute gradients
+    (gsr_backward_raw_batch_views): the views share one launch chain and one backward composite, and view v's bucket holds
+    bit for bit what the single-view backward of that view writes.  For callers that need per-view gradients -- independent
+    views, per-view clipping or statistics; the attack's batch wants their sum and takes a GradBucket."""
+
+    def __init__(self, B: int, P: int, device):
+        self.B, self.P = int(B), int(P)
+        self.flat = torch.empty(self.B * 59 * self.P, dtype=torch.float32, device=device)
+        self.used = 0              # views written by the last backward
+
+    def bucket(self, v: int) -> "GradBucket":
+        """View v's gradients as a GradBucket over this set's memory (no copy)."""
+        b = GradBucket.__new__(GradBucket)
+        b.P = self.P
+        b.flat = self.flat[v * 59 * self.P:(v + 1) * 59 * self.P]
+        b.fresh, b.used, b.chunks, b.on_chunk = False, v < self.used, 1, None
+        return b
+
+
 class _RasterizeGaussiansRaw(torch.autograd.Function):
     """Same path with the activation getters fused into the kernels (gsr_forward_raw / gsr_backward_raw): takes the
     RAW parameter tensors of a reference-style GaussianModel."""
@@ -949,7 +973,13 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
         want_sh = need[2] or need[3]
         all59 = need[0] and want_sh and need[4] and need[5] and need[6]
         bucket = ctx.bucket if all59 else None
-        if bucket is not None:
+        bset = bucket if isinstance(bucket, GradBucketSet) else None
+        if bset is not None:
+            # per-view gradients: the pointers are view 0's bucket, view v's lie 59 P floats further
+            if bset.P != P or bset.B < B or bset.flat.device != device:
+                raise ValueError("grad bucket set does not match the batch (views, P or device)")
+            d_x, d_dc, d_rest, d_op, d_sc, d_ro = bset.bucket(0).slices()
+        elif bucket is not None:
             if bucket.P != P or bucket.flat.device != device:
                 raise ValueError("grad bucket does not match the model (P or device)")
             d_x, d_dc, d_rest, d_op, d_sc, d_ro = bucket.slices()
@@ -969,7 +999,7 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
         if norms is not None:
             # the batch's ONE backward writes the summed gradient: its sums of squares are the L2 steps' norms (GradNorms)
             norms.writes += 1
-            overwrites = (bucket is None or bucket.fresh) and not (bucket is not None and bucket.chunks > 1)
+            overwrites = bset is None and (bucket is None or bucket.fresh) and not (bucket is not None and bucket.chunks > 1)
             if norms.writes == 1 and overwrites and P > 0:
                 if lib.gsr_ctx_request_sumsq(ctx.holder.handle, ctypes.c_void_p(norms.sumsq.data_ptr())) != 0:
                     norms.invalidate()              # (a build or a mode that cannot serve it: the step sums the gradient itself)
@@ -980,8 +1010,12 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
         if P > 0:
             with torch.cuda.device(device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-                acc = 1 if (bucket is not None and not bucket.fresh) else 0
-                if bucket is not None and bucket.chunks > 1:
+                acc = 1 if (bucket is not None and bset is None and not bucket.fresh) else 0
+                if bset is not None:
+                    rc = lib.gsr_backward_raw_batch_views(ctx.holder.handle, _ptr(gcol), _ptr(d_x), _ptr(d_m2), _ptr(d_dc),
+                                                          _ptr(d_rest), _ptr(d_op), _ptr(d_sc), _ptr(d_ro), 59 * P, stream)
+                    bset.used = B
+                elif bucket is not None and bucket.chunks > 1:
                     # the per-Gaussian stage in ranges, each announced as soon as its launch is enqueued (all-reduce overlap)
                     hook, bucket.on_chunk = bucket.on_chunk, None
                     errs = []
@@ -1009,6 +1043,8 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
                 if t is not None and bucket is None:
                     t.zero_()
         s = ctx.shapes
+        if bset is not None:
+            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None)
         if bucket is not None:
             bucket.fresh, bucket.used = False, True
             return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None)
@@ -1257,6 +1293,6 @@ def trim_pool() -> None:
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "rasterize_gaussians_raw2", "rasterize_gaussians_raw_batch", "MAX_BATCH", "PairCapacityExceeded", "GradBucket", "GradNorms",
+           "rasterize_gaussians_raw2", "rasterize_gaussians_raw_batch", "MAX_BATCH", "GradBucketSet", "PairCapacityExceeded", "GradBucket", "GradNorms",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]

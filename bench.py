@@ -8,10 +8,16 @@ hand-written HIP) + one backward from a fixed dL/dC[3,H,W] down to .grad on all 
 starts.  A timed region is EXACTLY --steps steps between barrier + synchronise on both sides; --regions of them are
 run back to back and the MEDIAN region is reported (every region's time is listed).
 
-N = 1 (the BASELINE metric): `value` = independent views dealt round-robin over --streams HIP streams (default 4; what a
-batch of views allows: reference attack.py:476-485), `sequential` = the same views strictly one after another on
-one stream (what the reference's default loop, batch_mode false, and config 4's one view per rank see), `pgd` = whole PGD
-iterations (config 3 and config 4 on one GPU) split into their phases.
+N = 1 (the BASELINE metric): `value` = independent views -- each with its own forward, its own dL/dC and its own 59
+attribute-gradient floats per Gaussian -- rendered several at a time through ONE launch chain on one HIP stream
+(gsr_forward_raw_batch + gsr_backward_raw_batch_views: the views of a group share the storage scan, both sorts, the
+emission, the schedule and the two compositor launches; view v's gradients are bit for bit the single-view backward's;
+views per group = the largest divisor of --steps up to 8, so a region is exactly --steps views in whole groups);
+`pipelined_streams` = the same views as one render() + backward per view dealt over --streams HIP streams (the headline
+regime of rounds 2-5), `sequential` = strictly one view after another on one stream (what the reference's default loop,
+batch_mode false, and config 4's one view per rank see), `batched` = the eight ring cameras as one batch whose gradients are
+SUMMED into one bucket (what reference attack.py:476-494 accumulates in .grad), `pgd` = whole PGD iterations (config 3 and
+config 4 on one GPU) split into their phases.
 N > 1 (config 4): a step is one PGD iteration's worth of rasterisation per rank -- --views-per-rank forward+backward
 passes into the rank's gradient bucket, ONE sum all-reduce of the bucket (59 floats per Gaussian) over RCCL, the fused
 projected-gradient step on all six attribute tensors -- strictly in that order, as a PGD loop needs it; `allreduce_ms`
@@ -82,6 +88,15 @@ def main():
                     help="N = 1: views per batch of the `batched` block (one launch chain per batch, gsr_forward_raw_batch); "
                          "0 = skip.  N > 1: the rank's --views-per-rank views go through one launch chain unless --no-batch")
     ap.add_argument("--no-batch", action="store_true", help="N > 1: one render() + backward per view, as in round 5")
+    ap.add_argument("--headline", choices=("auto", "batched-views", "streams"), default="auto",
+                    help="N = 1: how the independent views of the headline `value` are run -- batched-views: several views "
+                         "at a time through ONE launch chain, every view's 59 gradient floats per Gaussian written to its "
+                         "own buffer (gsr_backward_raw_batch_views); streams: one render() + backward per view dealt over "
+                         "--streams HIP streams (rounds 2-5's headline, reported as `pipelined_streams` otherwise); auto: "
+                         "batched-views when the configuration allows it")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling runs: only the headline regime (warm-up included) launches kernels, so that per-kernel "
+                         "averages of a profiler describe one kind of launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (dense point, forward-only, PGD blocks)")
     ap.add_argument("--scale-modifier", type=float, default=1.0,
@@ -189,6 +204,30 @@ def main():
         for s_ in sts:
             torch.cuda.current_stream(dev).wait_stream(s_)
 
+    # ---- N = 1 headline: independent views, several at a time through ONE launch chain --------------------------------
+    # Every view keeps its own gradient: view v's 59 floats per Gaussian land in bucket v of a GradBucketSet, bit for bit
+    # what the single-view backward writes (tests/test_gpu_batch.py).  The views of a step group share the storage scan,
+    # both sorts, the emission, the tile schedule and the two compositor launches; the per-Gaussian backward runs once per
+    # view.  Views per group: the largest divisor of --steps up to 8, so that a region is EXACTLY --steps views in whole
+    # groups and every launch of a kernel covers the same number of views.
+    Bh = 0
+    if world == 1 and args.headline != "streams" and not (args.classic or args.objects or args.color_only or args.cu_masks):
+        Bh = max([d for d in range(2, min(8, D.MAX_BATCH) + 1) if args.steps % d == 0], default=0)
+    if args.headline == "batched-views" and Bh == 0:
+        raise SystemExit("[bench] --headline batched-views needs N = 1, the fused path without object channels and a "
+                         "--steps with a divisor in 2..8")
+    if Bh:
+        bset_h = D.GradBucketSet(Bh, P, dev)
+        pipe_h = PipelineParams(skip_objects=True, grad_bucket=bset_h)
+        gcb_h = gc.unsqueeze(0).expand(Bh, 3, H, W).contiguous()
+
+        def run_headline(n):
+            assert n % Bh == 0
+            for _ in range(n // Bh):
+                out_h = render_batch([next_cam() for _ in range(Bh)], model, pipe_h, bg, scale_mod[0])
+                out_h["render"].backward(gcb_h)
+            return out_h
+
     # ---- N > 1: one PGD iteration per step (config 4) ---------------------------------------------------------------
     ar_events = []
     bytes_reduced = [0]
@@ -263,7 +302,7 @@ def main():
 
     if rank == 0:
         log(f"scene ready: P={P}, {W}x{H}; warmup x{args.warmup}")
-    for i in range(args.warmup):
+    for i in range(0 if (Bh and args.headline_only) else args.warmup):
         if pgd_loop:
             pgd_step()
         else:
@@ -271,12 +310,30 @@ def main():
         torch.cuda.synchronize()
         if rank == 0 and not pgd_loop:
             log(f"warmup step {i} done, N={D.last_num_rendered(out['render'])}")
+    if Bh:
+        # the headline regime's own warm-up: at least --warmup views, in whole groups
+        oh = run_headline(max(-(-args.warmup // Bh), 2) * Bh)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"headline warm-up done ({Bh} views per launch chain), pairs per group N={D.last_num_rendered(oh['render'])}")
+        del oh
     out = None
     ar_events.clear()
     info = {}
     # pair / visible counts of every camera of the ring (the roofline figures use their means)
     Ns, Vs, Es = [], [], []
-    for c_ in (cams[:n_views] if not args.one_camera else [cam]):
+    if Bh and args.headline_only:
+        # (profiling runs: counted from forward-only GROUPS, so that every K6 launch of the process is a group launch)
+        with torch.no_grad():
+            pass
+        for g0 in range(0, n_views, Bh):
+            grp = [cams[(g0 + k) % n_views] for k in range(Bh)]
+            o_ = render_batch(grp, model, PipelineParams(skip_objects=True), bg, scale_mod[0])
+            Ns.extend([D.last_num_rendered(o_["render"]) // Bh] * Bh)
+            Vs.extend([int(D.export_state(o_["render"], "dv")[1].item()) // Bh] * Bh)
+            Es.extend([int(D.export_state(o_["render"], "n_contrib").to(torch.int64).sum().item()) // Bh] * Bh)
+            del o_
+    for c_ in ([] if (Bh and args.headline_only) else (cams[:n_views] if not args.one_camera else [cam])):
         o_ = render(c_, model, pipe, bg, scale_mod[0])
         Ns.append(D.last_num_rendered(o_["render"]))
         Vs.append(int(D.export_state(o_["render"], "dv")[1].item()))
@@ -289,7 +346,7 @@ def main():
     info["E"] = int(round(sum(Es) / len(Es)))
     step_no[0] = 0
 
-    def timed_regions(n_regions, use_streams=True, profile_stage=None):
+    def timed_regions(n_regions, use_streams=True, profile_stage=None, runner=None):
         """n_regions x exactly --steps steps, each between barrier + synchronise; per-region seconds (max over ranks)."""
         secs = []
         for _ in range(n_regions):
@@ -297,7 +354,10 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run_steps(args.steps, use_streams)
+            if runner is not None:
+                runner(args.steps)
+            else:
+                run_steps(args.steps, use_streams)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -314,12 +374,31 @@ def main():
     # Timed regions: only the dominant kernel (K7, the backward composite) is timed inside them, by two HIP events that
     # hipExtLaunchKernelGGL stamps with the dispatch's own start and end on its launch stream.
     DOMINANT = "render_bwd"
-    run_steps(2 * max(args.streams, 1))                    # untimed: lets every stream build its own workspace blocks
-    torch.cuda.synchronize()
-    D.profile(True, stages=[DOMINANT])
-    secs = timed_regions(args.regions)
-    dom_calls = D.profile_read()[DOMINANT]
+    pipelined = None
+    if Bh:
+        D.profile(True, stages=[DOMINANT])
+        secs = timed_regions(args.regions, runner=run_headline)
+        dom_calls = D.profile_read()[DOMINANT]
+        D.profile(False)
+        if not args.headline_only and streams is not None:
+            # rounds 2-5's headline regime beside it: one render() + backward per view, dealt over the streams
+            run_steps(2 * max(args.streams, 1))
+            torch.cuda.synchronize()
+            secs_p = timed_regions(args.regions)
+            mp_ = sorted(secs_p)[len(secs_p) // 2]
+            pipelined = {"value": round(args.steps / mp_, 2), "unit": "views/s", "ms_per_step": round(mp_ / args.steps * 1e3, 4),
+                         "regions_ms": [round(x * 1e3, 2) for x in secs_p], "streams": args.streams,
+                         "what": "the same independent views as one render() + backward per view dealt round-robin over "
+                                 "--streams HIP streams: the headline regime of rounds 2-5"}
+    else:
+        run_steps(2 * max(args.streams, 1))                # untimed: lets every stream build its own workspace blocks
+        torch.cuda.synchronize()
+        D.profile(True, stages=[DOMINANT])
+        secs = timed_regions(args.regions)
+        dom_calls = D.profile_read()[DOMINANT]
     dom_ms_timed = dom_calls[0] / max(dom_calls[1], 1)
+    # views one launch of the dominant kernel covers in the timed regions
+    views_per_launch = Bh if Bh else (B if (pgd_loop and batch_views) else 1)
     med = sorted(secs)[len(secs) // 2]
     if rank == 0:
         log(f"timed regions ({args.steps} steps each): " + ", ".join(f"{x * 1e3:.1f} ms" for x in secs))
@@ -352,7 +431,7 @@ def main():
                          "streams: N x what the N = 1 line's `value` measures; one region, max over ranks"}
     # the same views strictly one after another on one stream
     seq = None
-    if world == 1 and streams is not None:
+    if world == 1 and streams is not None and not args.headline_only:
         D.profile(False)
         secs1 = timed_regions(args.regions, use_streams=False)
         m1 = sorted(secs1)[len(secs1) // 2]
@@ -366,7 +445,7 @@ def main():
     # virtual scene -- one scan, one depth sort, one emission, one tile sort, one schedule, one forward and one backward
     # composite for all of them, every SH row read once, the 59 gradient floats per Gaussian written once.  ONE stream.
     batched = None
-    if world == 1 and args.batch >= 2 and not args.classic and not args.objects and not args.color_only:
+    if world == 1 and args.batch >= 2 and not args.classic and not args.objects and not args.color_only and not args.headline_only:
         Bb = min(args.batch, len(cams), D.MAX_BATCH)
         bcams = cams[:Bb]
         bucket_b = D.GradBucket(P, dev)
@@ -417,6 +496,9 @@ def main():
         for _ in range(nb):
             pgd_step()
         nb_views = nb * B
+    elif Bh:
+        run_headline(3 * Bh)                               # the headline regime's stages (per view: / views)
+        nb_views = 3 * Bh
     else:
         for _ in range(nb):
             step()
@@ -442,10 +524,12 @@ def main():
                          "GBps": round(sb[name] / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 and sb[name] else None}
         dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd", "tile_sort", "bin"),
                   key=lambda n: per[n]["avg_ms"])
-        dom_ms = per[dom]["avg_ms"]
+        # (stage times are per VIEW; a launch of the dominant kernel covers views_per_launch views in the headline regime)
+        vpl = views_per_launch
+        dom_ms = round(per[dom]["avg_ms"] * vpl, 4)
         if dom == DOMINANT:
             dom_ms = round(dom_ms_timed, 4)      # the duration measured inside the timed regions themselves
-        achieved = sb[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        achieved = sb[dom] * vpl / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes of the dominant kernel from the committed PMC passes (profiles/collect_r03.sh: FETCH_SIZE and
         # WRITE_SIZE in separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only when they
         # were taken on this very workload
@@ -461,15 +545,19 @@ def main():
             kern = {"render_bwd": "void gsr::k_render_bwd<false, 4, true>", "render_fwd": "void gsr::k_render_fwd<false, 2, 1>",
                     "preprocess_bwd": "void gsr::k_pre_bwd<true, true, false>",
                     "preprocess": "void gsr::k_pre_color<true>"}.get(dom)
+            if int(pmc.get("views_per_launch", 1)) != vpl:
+                traffic_note = (f"profiles/{PMC_FILE} counts launches of {pmc.get('views_per_launch', 1)} view(s), this run's "
+                                f"cover {vpl}: not quoted")
+                raise LookupError(traffic_note)
             if (args.scene, args.P, args.width, args.height, args.objects) == ("nyc-1M", None, None, None, False):
                 traffic = round(pmc["per_kernel"][kern]["hbm_bytes_fetch_x2"])
                 n_valu = pmc["per_kernel"][kern].get("SQ_INSTS_VALU")
                 if n_valu:
                     peak = 1024 * 2.4e9 / 2 / 1e9
-                    ach = n_valu / (per[dom]["avg_ms"] * 1e-3) / 1e9
+                    ach = n_valu / (per[dom]["avg_ms"] * vpl * 1e-3) / 1e9
                     valu = {"bound": "fp32 VALU issue", "wave_instr_per_launch": round(n_valu),
                             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-                            "frac": round(ach / peak, 4), "launch_ms": per[dom]["avg_ms"]}
+                            "frac": round(ach / peak, 4), "launch_ms": round(per[dom]["avg_ms"] * vpl, 4)}
         except Exception as e:                             # noqa: BLE001
             traffic = None
             valu = None
@@ -480,7 +568,10 @@ def main():
         workload = (f"{spec.name}: {P} Gaussians (SH degree 3), {W}x{H}, "
                     + (f"one PGD iteration per step: {B} view(s) per GPU fwd+bwd into a gradient bucket, one all-reduce of "
                        "59 floats/Gaussian, fused L2 step on all six attribute tensors" if pgd_loop else
-                       "one view per step per GPU, render() fwd + bwd to all attribute grads")
+                       (f"one view per step: independent views, {Bh} at a time through ONE launch chain (gsr_forward_raw_batch "
+                        "+ gsr_backward_raw_batch_views), fwd + bwd, every view's 59 attribute-gradient floats per Gaussian "
+                        "written to its own buffer" if Bh else
+                        "one view per step per GPU, render() fwd + bwd to all attribute grads"))
                     + (", 16 object channels on" if args.objects else ", object channels off")
                     + (", gradients on SH coefficients only" if args.color_only else "")
                     + (", classic activated-tensor surface" if args.classic else ""))
@@ -503,23 +594,24 @@ def main():
                        "P": P, "V_visible": V, "N_pairs": N, "width": W, "height": H,
                        "loop": "pgd" if pgd_loop else "independent views",
                        "views_per_rank": B,
+                       "views_per_launch_chain": views_per_launch,
                        "cameras": "one fixed camera" if args.one_camera else
                                   f"the {n_views} ring cameras in turn (V and N are means over them)",
                        "N_pairs_per_camera": info["N_per_camera"], "V_visible_per_camera": info["V_per_camera"],
                        "streams": args.streams,
                        "parallelism": f"views sharded {B}/GPU, dp{world}"
-                                      + (f", independent views pipelined over {args.streams} HIP streams per GPU"
-                                         if args.streams > 1 and not pgd_loop else "")
+                                      + (f", independent views {Bh} per launch chain on one HIP stream" if Bh else
+                                         (f", independent views pipelined over {args.streams} HIP streams per GPU"
+                                          if args.streams > 1 and not pgd_loop else ""))
                                       + (", RCCL all-reduce of 59 floats/Gaussian per step" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_note if traffic is None else
                          f"profiles/{PMC_FILE}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
                          "this workload (not measured inside this run; FETCH_SIZE doubled per MI355X_MICROARCH.md)",
-                         "algorithmic_bytes_per_launch": sb[dom], "avg_launch_ms": dom_ms,
-                         # the same kernel with nothing beside it (untimed one-stream pass): in the timed regions its
-                         # launches share the chip with the other streams' kernels
-                         "avg_launch_ms_alone": per[dom]["avg_ms"],
+                         "algorithmic_bytes_per_launch": sb[dom] * vpl, "views_per_launch": vpl, "avg_launch_ms": dom_ms,
+                         # the same kernel in the untimed per-stage pass (stage events around it)
+                         "avg_launch_ms_alone": round(per[dom]["avg_ms"] * vpl, 4),
                          "note": "K6/K7 are bound by VALU instruction issue (256*N alpha evaluations), not by HBM; "
                                  "HBM is the reporting roofline BASELINE.md section 3 prescribes"},
             "pipeline": {"bytes_per_view": B_total, "achieved": round(B_total / t_view / 1e9, 1), "unit": "GB/s",
@@ -541,6 +633,8 @@ def main():
                 "fwd_TFLOPs_equiv": round(29 * E / (k6 * 1e-3) / 1e12, 1), "bwd_TFLOPs_equiv": round(91 * E / (k7 * 1e-3) / 1e12, 1),
                 "fp32_vector_peak_TFLOPs": 157.3,
                 "note": "render_fwd includes the tile-schedule kernel; one-stream stage durations of the untimed pass"}
+        if pipelined is not None:
+            result["pipelined_streams"] = pipelined
         if seq is not None:
             result["sequential"] = seq
         if batched is not None:

@@ -231,6 +231,14 @@ int gsr_forward_raw_batch(const GsrSettings* settings, int32_t B, int32_t P, con
 int gsr_backward_raw_batch_into(GsrCtx* ctx, const float* grad_color, float* dxyz, float* dmeans2D, float* dfeatures_dc,
                                 float* dfeatures_rest, float* dopacity_logit, float* dlog_scaling, float* drotation_raw,
                                 int32_t accumulate, void* stream);
+/* The same backward with PER-VIEW attribute gradients, for callers that need every view's own gradient (independent views
+ * that merely share a launch chain): the six attribute-gradient pointers are VIEW 0's buffers, view v's lie v * view_stride
+ * floats further (e.g. B gradient buckets of 59 * P floats one after another: view_stride = 59 * P); dmeans2D is [B,P,3] as
+ * above.  One forward-batch chain and one backward composite for all views, then one per-Gaussian launch per view: view v's
+ * buffers receive bit for bit what gsr_backward_raw on that view alone writes (zeros for Gaussians the view does not see). */
+int gsr_backward_raw_batch_views(GsrCtx* ctx, const float* grad_color, float* dxyz, float* dmeans2D, float* dfeatures_dc,
+                                 float* dfeatures_rest, float* dopacity_logit, float* dlog_scaling, float* drotation_raw,
+                                 int64_t view_stride, void* stream);
 
 /* Forward-only render of TWO parameter sets as one scene: the attacked target (a) followed by the frozen background (b),
  * Gaussians numbered a then b (radii [Pa+Pb]).  Replaces what the reference does after every PGD step to check the

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the round-5 evidence on a GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats of the benchmark, four streams and one   -> profiles/r06_kernel_stats*.csv
+#   1. rocprofv3 --kernel-trace --stats of the benchmark: the headline regime (views five at a time through one launch
+#      chain, --headline-only) and the per-view loop on one stream                -> profiles/r06_kernel_stats*.csv
 #   2. separate PMC passes FETCH_SIZE / WRITE_SIZE / SQ counters (MI355X_MICROARCH.md "HBM": never in one pass, never
 #      with traces other than --kernel-trace)                                    -> profiles/r06_pmc_traffic.json
 #   3. bench lines: default, one stream only, config 2 and config 5 scenes       -> profiles/r06_bench*.json
@@ -11,12 +12,12 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/r06
 mkdir -p $OUT
-PMCB="python3 $R/bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras --batch 0"
-STATS="python3 $R/bench.py --steps 100 --warmup 10 --regions 3 --no-cpu-baseline --no-extras --batch 0"
+PMCB="python3 $R/bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras --headline-only"
+STATS="python3 $R/bench.py --steps 100 --warmup 10 --regions 3 --no-cpu-baseline --no-extras --headline-only"
 if [ "${PART:-A}" = "A" ]; then
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $STATS > $OUT/bench_stats.json 2> $OUT/bench_stats.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- $STATS --streams 1 > $OUT/bench_stats1.json 2> $OUT/bench_stats1.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1 -o s -- python3 $R/bench.py --steps 100 --warmup 10 --regions 3 --no-cpu-baseline --no-extras --headline streams --streams 1 --batch 0 > $OUT/bench_stats1.json 2> $OUT/bench_stats1.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- $PMCB > /dev/null 2> $OUT/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- $PMCB > /dev/null 2> $OUT/write.err || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT/sq -o q -- $PMCB > /dev/null 2> $OUT/sq.err || exit 1
@@ -55,7 +56,8 @@ def digest():
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()
-json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras --batch 0 (single-view launches only: the batched block launches the same kernels over eight views at once)",
+json.dump({"command": "python3 bench.py --steps 10 --warmup 2 --regions 1 --no-cpu-baseline --no-extras --headline-only (every launch of the compositors covers the headline regime's 5 views: --steps 10, 20 and 100 all group views by 5)",
+           "views_per_launch": 5,
            "sources_sha256": digest(), "per_kernel": res},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_fetch_x2"] / 1e6, 1) for k, v in res.items()}, indent=1))
@@ -75,7 +77,7 @@ python3 tests/diag_coresidency.py 4 64 2>/dev/null | grep -v amdgpu.ids >> $R/gp
 python3 tests/diag_coresidency.py 1 32 2>/dev/null | grep -v amdgpu.ids >> $R/gpurun_out/r06_coresidency.txt
 fi
 if [ "${PART:-A}" = "B" ]; then
-python3 bench.py --steps 100 --warmup 10 --streams 1 --no-cpu-baseline --no-extras > $R/gpurun_out/r06_bench_1stream.json 2> $OUT/bench1.err || exit 1
+python3 bench.py --steps 100 --warmup 10 --headline streams --streams 1 --batch 0 --no-cpu-baseline --no-extras > $R/gpurun_out/r06_bench_1stream.json 2> $OUT/bench1.err || exit 1
 python3 bench.py --steps 100 --warmup 10 --scene hydrant-full --no-cpu-baseline --no-extras > $R/gpurun_out/r06_bench_hydrantfull.json 2> $OUT/bench_c2.err || exit 1
 python3 bench.py --steps 50 --warmup 5 --scene airport-4K --no-cpu-baseline --no-extras > $R/gpurun_out/r06_bench_airport4k.json 2> $OUT/bench_c5.err || exit 1
 python3 bench.py --steps 50 --warmup 5 --objects --no-cpu-baseline --no-extras > $R/gpurun_out/r06_bench_objects.json 2> $OUT/bench_obj.err || exit 1

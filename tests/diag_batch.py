@@ -20,6 +20,8 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     only = sys.argv[4] if len(sys.argv) > 4 else ""
+    if len(sys.argv) > 5:
+        D.set_flags(int(sys.argv[5], 0))               # launch overrides (diff_gaussian_rasterization.flag_*), e.g. 0x30 = FWD_SPLIT(4)
     dev = torch.device("cuda:0")
     model, cams, spec = make_scene(scene, device=dev, n_views=max(B, 8))
     cams = cams[:B]

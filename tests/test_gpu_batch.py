@@ -257,3 +257,32 @@ def test_pgd_attack_batched_matches_per_view_loop():
         assert d <= 2e-4, (n, d)
     # and the batch really ran: the first iteration's loss equals the per-view one exactly (same images, same detector)
     assert h1[0] == pytest.approx(h2[0], rel=1e-6)
+
+
+@pytest.mark.parametrize("P,W,H,B", [(60_000, 640, 360, 5), (1000, 128, 128, 3)])
+def test_per_view_gradients_of_a_batch_equal_the_single_view_backward(P, W, H, B):
+    """gsr_backward_raw_batch_views / GradBucketSet: the views share one launch chain and one backward composite, and every
+    view's OWN 59 gradient floats per Gaussian are bit for bit those of the single-view call."""
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.scenes import make_scene
+    from gsplat_attack.renderer import PipelineParams, render, render_batch
+    dev = _dev()
+    model, cams, _ = make_scene("nyc-1M", device=dev, P=P, width=W, height=H, n_views=B)
+    g = torch.Generator().manual_seed(B)
+    gcs = [torch.randn(3, H, W, generator=g).to(dev) for _ in cams]
+    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    bset = D.GradBucketSet(B, P, dev)
+    bset.flat.fill_(float("nan"))                       # every float of every view's bucket must be written
+    out = render_batch(cams, model, PipelineParams(skip_objects=True, grad_bucket=bset), bg)
+    out["render"].backward(torch.stack(gcs))
+    torch.cuda.synchronize()
+    assert bset.used == B and torch.isfinite(bset.flat).all()
+    for v, cam in enumerate(cams):
+        one = D.GradBucket(P, dev)
+        o = render(cam, model, PipelineParams(skip_objects=True, grad_bucket=one), bg)
+        o["render"].backward(gcs[v])
+        assert torch.equal(out["render"][v].detach(), o["render"].detach())
+        assert torch.equal(bset.bucket(v).flat, one.flat), f"view {v}"
+        assert torch.equal(out["viewspace_points"].grad[v], o["viewspace_points"].grad)
+    # the set's buckets are views of its memory, shaped like the model's parameters
+    assert bset.bucket(1).views()["_features_rest"].shape == (P, 15, 3)
