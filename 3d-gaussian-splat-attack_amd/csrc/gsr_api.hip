@@ -588,10 +588,11 @@ static int launch_render_fwd(GsrCtx* c, float* out_color, float* out_objects, hi
   const dim3 blkT(64);
   // pixels per lane of K6: fewer = more, shorter waves per tile (see k_render_fwd); images with fewer tiles than
   // half the chip's wave slots are split down to one 16x4 strip per wave.  GSR_FLAG_FWD_SPLIT(n) overrides.
-  // From 16 384 tiles on (a 4K image, a batch of two or more 1080p views) one wave per tile: the chip is full of waves either
-  // way, and a tile's list is then staged once instead of once per half tile (S-airport-4K K6 0.215 -> 0.207 ms, an 8-view batch
-  // of S-nyc-1M 0.140 -> 0.129 ms per view; at 8160 tiles the longer items cost more in the kernel's tail than they save).
-  const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : (ntiles < 16384 ? 2 : 4));
+  // From 32 000 tiles on (a 4K image, a batch of four or more 1080p views) one wave per tile: four rounds of waves fill the
+  // chip either way, and a tile's list is then staged once instead of once per half tile (S-airport-4K K6 0.215 -> 0.207 ms,
+  // an 8-view batch of S-nyc-1M 0.140 -> 0.129 ms per view).  Below that the longer work items cost more in the kernel's
+  // tail than they save: 8160 tiles 0.196 -> 0.268 ms, an 8-view batch of S-hydrant-full (20 000 tiles) 0.042 -> 0.061.
+  const int fwd_npx = flag_fwd_npx(s->flags) ? flag_fwd_npx(s->flags) : (ntiles < 4096 ? 1 : (ntiles < 32000 ? 2 : 4));
   const dim3 gridT(render_grid(ntiles * (PXL / fwd_npx)));
   // the tile's waves as one workgroup that stages every batch once (k_render_fwd's WPB): S-nyc-1M gathers 596 -> 367 MB
   // but runs 0.197 -> 0.224 ms (two workgroup barriers per batch, and the waves of a tile wait for each other), so
@@ -1029,8 +1030,10 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
       (void)hipGetLastError();
       return e == hipSuccess ? SCHED_LDS_TILES : SCHED_LDS_TILES_DEFAULT;
     }();
+    static const int batch_sched_env = [] { const char* e = getenv("GSR_BATCH_SCHED"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL(k_tile_schedule, dim3((c->segoff ? 2 : 1) * B), dim3(1024), sched_lds_bytes(tpv, sched_lds_cap), st, tpv,
-                       sched_lds_cap, c->ranges, c->sched, c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC, B);
+                       sched_lds_cap, c->ranges, c->sched, c->seg_shift, c->segoff, c->rec_item, c->rec_cap, c->dv + DV_NREC, B,
+                       batch_sched_env);
     F_LAUNCH("tile schedule");
     const int rk6 = launch_render_fwd(c, out_color, out_objects, st);
     if (rk6 != GSR_OK) return fail(rk6);

@@ -612,7 +612,8 @@ inline size_t sched_lds_bytes(int ntiles, int lds_cap) { return 2u * (size_t)((s
 __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ sched, uint32_t seg_shift,
                                                         uint32_t* __restrict__ segoff, uint2* __restrict__ rec_item,
-                                                        uint32_t rec_cap, uint32_t* __restrict__ nrec_out, int B) {
+                                                        uint32_t rec_cap, uint32_t* __restrict__ nrec_out, int B,
+                                                        int view_major) {
   __shared__ uint32_t hist[SCHED_BINS];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t smax;
@@ -700,7 +701,9 @@ __global__ void __launch_bounds__(1024) k_tile_schedule(int ntiles, int lds_cap,
       const int i = i0 + k * 1024;
       if (i < ntiles) {
         const uint32_t prio = min(3u, (uint32_t)((float)len[k] * prio_scale));    // 0..3: length relative to the longest list
-        sched[(size_t)p[k] * (size_t)B + view] = (uint32_t)(tile0 + i) | (prio << 28);
+        // (view_major: view after view, each longest-first -- the waves in flight then gather the records of one or two views)
+        const size_t pos = view_major ? (size_t)tile0 + p[k] : (size_t)p[k] * (size_t)B + view;
+        sched[pos] = (uint32_t)(tile0 + i) | (prio << 28);
       }
     }
   }
