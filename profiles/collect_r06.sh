@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the round-5 evidence on a GPU box (run through gpurun from the repo root):
+# Collects the round-6 evidence on a GPU box (run through gpurun from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of the benchmark: the headline regime (views five at a time through one launch
 #      chain, --headline-only) and the per-view loop on one stream                -> profiles/r06_kernel_stats*.csv
 #   2. separate PMC passes FETCH_SIZE / WRITE_SIZE / SQ counters (MI355X_MICROARCH.md "HBM": never in one pass, never
