@@ -1,7 +1,7 @@
 """Diagnostic: what the published backward's 1 / (det^2 + 1e-7) (gsr_math.h GSR_DET_GUARD, oracle_r.DET_GUARD) changes against
 the exact derivative 1 / det^2 of the 2D covariance inversion, on full-size scenes: the attribute gradients of one view
 from the default library and from a build with -DGSR_DET_GUARD=0.0f (libgsraster_exactdet.so next to the default one:
-`hipcc ... -DGSR_DET_GUARD=0.0f -o .../libgsraster_exactdet.so gsr_api.hip`).
+`make -C 3d-gaussian-splat-attack_amd/csrc exactdet`).
 
     python tests/diag_det_guard.py [scene ...]          (default: nyc-1M airport-4K)
 """
