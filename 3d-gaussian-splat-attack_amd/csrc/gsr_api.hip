@@ -1621,6 +1621,59 @@ int gsr_pgd_step(float* x, const float* grad, const float* x0, int64_t rows, int
   return GSR_OK;
 }
 
+int gsr_pgd_step_multi(int32_t n, float* const* x, const float* const* grad, const float* const* x0, const int64_t* rows,
+                       const int32_t* cols, const float* alpha, const float* epsilon, int32_t l2, const double* const* sumsq,
+                       void* stream) {
+  if (n < 0 || n > PGD_MAX_TENSORS) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_multi: n=%d (0..%d tensors)", n, PGD_MAX_TENSORS);
+  if (n == 0) return GSR_OK;
+  if (!x || !grad || !x0 || !rows || !cols || !alpha || !epsilon) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_multi: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int dev = cur_dev();
+  PgdMulti m;
+  memset(&m, 0, sizeof(m));
+  unsigned long long blocks = 0;
+  size_t need = 0;                                       // doubles of partial sums this call has to make itself
+  for (int t = 0; t < n; ++t) {
+    if (rows[t] < 0 || cols[t] < 1 || cols[t] > PGD_MAX_COLS)
+      return set_err(GSR_ERR_INVALID, "gsr_pgd_step_multi: tensor %d: rows=%lld cols=%d (1..%d columns)", t, (long long)rows[t], cols[t],
+                     PGD_MAX_COLS);
+    if (rows[t] > 0 && (!x[t] || !grad[t] || !x0[t])) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_multi: tensor %d: null pointer", t);
+    m.x[t] = x[t]; m.g[t] = grad[t]; m.x0[t] = x0[t];
+    m.rows[t] = (unsigned long long)rows[t]; m.cols[t] = cols[t]; m.alpha[t] = alpha[t]; m.eps[t] = epsilon[t];
+    m.first[t] = (unsigned)blocks;
+    blocks += (unsigned long long)((rows[t] + 63) / 64);
+    if (blocks > 0x7fffffffull) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_multi: too many rows for one launch");
+    if (l2 && rows[t] > 0) {
+      if (sumsq && sumsq[t]) { m.partial[t] = sumsq[t]; m.nb[t] = 1; }
+      else {
+        m.nb[t] = (int)std::min<size_t>(((size_t)rows[t] * (size_t)cols[t] + 4095) / 4096, 1024);
+        need += (size_t)m.nb[t];
+      }
+    }
+  }
+  for (int t = n; t <= PGD_MAX_TENSORS; ++t) m.first[t] = (unsigned)blocks;
+  m.n = n;
+  if (blocks == 0) return GSR_OK;
+  void* blk = nullptr;
+  if (need) {
+    blk = pool_alloc(dev, sizeof(double) * need, st);
+    if (!blk) return set_err(GSR_ERR_NOMEM, "gsr_pgd_step_multi: allocation failed");
+    double* partial = static_cast<double*>(blk);
+    for (int t = 0; t < n; ++t) {
+      if (!l2 || rows[t] == 0 || m.partial[t]) continue;
+      hipLaunchKernelGGL(k_pgd_sumsq, dim3(m.nb[t]), dim3(256), 0, st, grad[t], (size_t)rows[t] * (size_t)cols[t], partial);
+      m.partial[t] = partial;
+      partial += m.nb[t];
+    }
+  }
+  if (l2) hipLaunchKernelGGL((k_pgd_step_multi<true>), dim3((unsigned)blocks), dim3(64), 0, st, m);
+  else hipLaunchKernelGGL((k_pgd_step_multi<false>), dim3((unsigned)blocks), dim3(64), 0, st, m);
+  if (blk) pool_free(dev, blk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_pgd_step_multi: launch failed: %s", hipGetErrorString(e));
+  return GSR_OK;
+}
+
 int gsr_knn_dist2(const float* points, int32_t P, float* mean_dist2, void* stream) {
   if (P < 0 || (P > 0 && (!points || !mean_dist2))) return set_err(GSR_ERR_INVALID, "gsr_knn_dist2: null argument");
   if (P == 0) return GSR_OK;

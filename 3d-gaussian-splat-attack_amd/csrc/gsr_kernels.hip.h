@@ -1613,7 +1613,7 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_preprocess_bwd(PreBwdArgs a) {
     bool needle = false;
     if (NDL) {
       float tt[3];
-      for (int j = 0; j < 3; ++j) tt[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+      view_transform(v, p, tt);
       ProjLin pl;
       proj_linear(v, tt, pl);
       float fa, fb, fc;

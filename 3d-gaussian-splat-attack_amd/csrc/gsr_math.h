@@ -47,6 +47,21 @@ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH
                 SH_C3_6 = -0.5900435899266435f;
 
 // Per-view constants, filled on the device from the settings' device tensors.
+// The projection chain of a splat -- view transform, J W, Sigma3D from scale and rotation, the 2D covariance -- is
+// evaluated by the forward (k_pre_geom) and AGAIN by every backward kernel (k_pre_bwd, k_pre_bwd_batch, k_preprocess_bwd),
+// which differentiate the inversion of the 2D covariance at the point they recompute.  For an elongated splat that
+// derivative cancels by the eigenvalue ratio (project_splat_bwd), so the recomputed (a, b, c) must be THE SAME BITS in
+// every kernel: left to the compiler, a*b + c is contracted to an fma or not depending on what a function is inlined
+// into, and two kernels that differ in the last bit of (a, b, c) differ by 1e-7 x the eigenvalue ratio in the gradient
+// (round 6: the batch kernel's scale gradient of a 175:1 needle was 0.5 % from the single-view kernel's and 30x
+// further from the float64 oracle).  GSR_FP_STRICT at the top of a function body switches contraction off for that
+// function: every product and sum in it is rounded once, in source order, in every kernel and on the host.
+#if defined(__clang__)
+#define GSR_FP_STRICT _Pragma("clang fp contract(off)")
+#else
+#define GSR_FP_STRICT
+#endif
+
 struct View {
   float V[16];    // viewmatrix, row-major as given: p_view = [p,1] * V (row-vector convention)
   float PV[16];   // full projection, same convention
@@ -71,6 +86,7 @@ GSR_HD void make_view(View& v, const float* vm, const float* pm, const float* ca
 // 3D covariance from scale + quaternion (q = (r,x,y,z) used as given), packed xx,xy,xz,yy,yz,zz
 // ---------------------------------------------------------------------------------------------
 GSR_HD void quat_to_R(const float q[4], float R[9]) {
+  GSR_FP_STRICT
   const float r = q[0], x = q[1], y = q[2], z = q[3];
   R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z);       R[2] = 2.f * (x * z + r * y);
   R[3] = 2.f * (x * y + r * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
@@ -78,6 +94,7 @@ GSR_HD void quat_to_R(const float q[4], float R[9]) {
 }
 
 GSR_HD void cov3d_from_scale_rot(const float s_in[3], float mod, const float q[4], float c6[6]) {
+  GSR_FP_STRICT
   float R[9];
   quat_to_R(q, R);
   const float s0 = mod * s_in[0], s1 = mod * s_in[1], s2 = mod * s_in[2];
@@ -126,7 +143,14 @@ struct ProjLin {
   bool clx, cly;
 };
 
+// p_view = [p, 1] V
+GSR_HD void view_transform(const View& v, const float p[3], float t[3]) {
+  GSR_FP_STRICT
+  for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+}
+
 GSR_HD void proj_linear(const View& v, const float t[3], ProjLin& o) {
+  GSR_FP_STRICT
   const float limx = FOV_CLAMP * v.tanfovx, limy = FOV_CLAMP * v.tanfovy;
   const float tz = t[2];
   const float txtz = t[0] / tz, tytz = t[1] / tz;
@@ -145,6 +169,7 @@ GSR_HD void proj_linear(const View& v, const float t[3], ProjLin& o) {
 }
 
 GSR_HD void cov2d_from_M(const float M[6], const float c6[6], float& a, float& b, float& c) {
+  GSR_FP_STRICT
   // u = Sigma * M0^T, w = Sigma * M1^T
   const float u0 = c6[0] * M[0] + c6[1] * M[1] + c6[2] * M[2];
   const float u1 = c6[1] * M[0] + c6[3] * M[1] + c6[4] * M[2];
@@ -160,7 +185,7 @@ GSR_HD void cov2d_from_M(const float M[6], const float c6[6], float& a, float& b
 GSR_HD bool project_splat(const View& v, const float p[3], const float c6[6], Splat& s) {
   s.radius = 0;
   float t[3];
-  for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+  view_transform(v, p, t);
   if (!(t[2] > NEAR_Z)) return false;
   float h[4];
   for (int j = 0; j < 4; ++j) h[j] = p[0] * v.PV[j] + p[1] * v.PV[4 + j] + p[2] * v.PV[8 + j] + v.PV[12 + j];
@@ -413,7 +438,7 @@ GSR_HD void sh_to_rgb_bwd(int deg, int Kstore, const float* sh, const float p[3]
 GSR_HD void project_splat_bwd(const View& v, const float p[3], const float c6[6], double dA, double dB, double dC,
                               float dndcx, float dndcy, float dp[3], float dc6[6]) {
   float t[3];
-  for (int j = 0; j < 3; ++j) t[j] = p[0] * v.V[j] + p[1] * v.V[4 + j] + p[2] * v.V[8 + j] + v.V[12 + j];
+  view_transform(v, p, t);
   ProjLin pl;
   proj_linear(v, t, pl);
   float a, b, c;
@@ -603,6 +628,7 @@ GSR_HD void needle_bwd_d(const View& v, const float p[3], const float* sc, float
 GSR_HD float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 GSR_HD void act_normalize4(const float r[4], float q[4], float& inv_n) {
+  GSR_FP_STRICT
   const float n = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
   inv_n = 1.0f / fmaxf(n, 1e-12f);
   const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];

@@ -40,14 +40,15 @@ __global__ void __launch_bounds__(256) k_pgd_sumsq(const float* __restrict__ g, 
 // L2 == true: `partial[nb]` holds the block sums of squares of g.
 // A wave's 64 rows are one contiguous, 256-byte aligned span of 64 * cols floats: it is moved with 16-byte accesses
 // (a full wave's span is a whole number of float4; the last, partial wave of a tensor falls back to 4-byte accesses).
+// (the body of both kernels below: `blk` = the wave's index among the tensor's groups of 64 rows)
 template <bool L2>
-__global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const float* __restrict__ g,
-                                                 const float* __restrict__ x0, size_t rows, int cols, float alpha,
-                                                 float eps, const double* __restrict__ partial, int nb) {
+__device__ __forceinline__ void pgd_step_wave(float* __restrict__ x, const float* __restrict__ g,
+                                              const float* __restrict__ x0, size_t rows, int cols, float alpha,
+                                              float eps, const double* __restrict__ partial, int nb, unsigned blk) {
   __shared__ __attribute__((aligned(16))) float sd[64 * PGD_MAX_COLS];     // the wave's deltas x_new - x0
   __shared__ float sf[64];                    // per-row clip factors
   const int lane = threadIdx.x;
-  const size_t r0 = (size_t)blockIdx.x * 64;
+  const size_t r0 = (size_t)blk * 64;
   const int nr = (int)min((size_t)64, rows - r0);
   const size_t base = r0 * (size_t)cols;
   const int n = nr * cols;
@@ -130,6 +131,41 @@ __global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const fl
       x[base + i] = fmaf(sd[i], sf[r], x0[base + i]);
     }
   }
+}
+
+template <bool L2>
+__global__ void __launch_bounds__(64) k_pgd_step(float* __restrict__ x, const float* __restrict__ g,
+                                                 const float* __restrict__ x0, size_t rows, int cols, float alpha,
+                                                 float eps, const double* __restrict__ partial, int nb) {
+  pgd_step_wave<L2>(x, g, x0, rows, cols, alpha, eps, partial, nb, blockIdx.x);
+}
+
+// Several tensors of one model in ONE launch (gsr_pgd_step_multi): the attack steps up to six attribute tensors per
+// iteration, each a bandwidth-bound launch of a few tens of microseconds whose tail and whose successor's ramp-up are
+// not covered by anything on the stream.  Workgroup b belongs to the tensor t with first[t] <= b < first[t + 1]; the
+// arithmetic per tensor is pgd_step_wave's, so the result is bit for bit that of the per-tensor launches.
+constexpr int PGD_MAX_TENSORS = 8;
+struct PgdMulti {
+  float* x[PGD_MAX_TENSORS];
+  const float* g[PGD_MAX_TENSORS];
+  const float* x0[PGD_MAX_TENSORS];
+  const double* partial[PGD_MAX_TENSORS];     // L2: sums of squares of g (nb[t] partial sums)
+  unsigned long long rows[PGD_MAX_TENSORS];
+  unsigned first[PGD_MAX_TENSORS + 1];        // first workgroup of tensor t; first[n] = the grid
+  int cols[PGD_MAX_TENSORS];
+  int nb[PGD_MAX_TENSORS];
+  float alpha[PGD_MAX_TENSORS];
+  float eps[PGD_MAX_TENSORS];
+  int n;
+};
+
+template <bool L2>
+__global__ void __launch_bounds__(64) k_pgd_step_multi(PgdMulti m) {
+  int t = 0;
+#pragma unroll
+  for (int i = 1; i < PGD_MAX_TENSORS; ++i) t += (i < m.n && blockIdx.x >= m.first[i]) ? 1 : 0;
+  pgd_step_wave<L2>(m.x[t], m.g[t], m.x0[t], (size_t)m.rows[t], m.cols[t], m.alpha[t], m.eps[t], m.partial[t], m.nb[t],
+                    blockIdx.x - m.first[t]);
 }
 
 }  // namespace gsr

@@ -160,6 +160,8 @@ def _load():
         lib.gsr_ctx_request_sumsq.argtypes = [vp, vp]
         lib.gsr_pgd_step_normed.restype = ctypes.c_int
         lib.gsr_pgd_step_normed.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float, vp, vp]
+        lib.gsr_pgd_step_multi.restype = ctypes.c_int
+        lib.gsr_pgd_step_multi.argtypes = [ctypes.c_int32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp]
     lib.gsr_pgd_step.restype = ctypes.c_int
     lib.gsr_pgd_step.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_int32, vp]

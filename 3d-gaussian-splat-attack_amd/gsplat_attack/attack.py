@@ -56,17 +56,30 @@ class SurrogateDetector(nn.Module):
         return self.net(renders.clamp(0.0, 1.0))[:, 0].mean()
 
 
+MULTI_STEP = True       # the stepped tensors of an iteration in one launch (gsr_pgd_step_multi); False: tensor by tensor (A/B, tests)
+
+
 def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsilon: float, norms=None) -> None:
     """norms: a diff_gaussian_rasterization.GradNorms whose sums of squares -- when still valid for this iteration's
     gradients -- spare the L2 rules their own pass over the gradient (same rule, attack.py:53-119, 138-173)."""
-    if norm == "l2" and norms is not None:
-        attrs = {"color": ("_features_rest", "_features_dc"), "position": ("_xyz",), "scaling": ("_scaling",),
-                 "rotation": ("_rotation",), "opacity": ("_opacity",)}
-        todo = [a for g in groups for a in attrs[g]]
-        if all(norms.sumsq_of(a) is not None and getattr(model, a).grad is not None for a in todo):
-            for a in todo:
-                t = getattr(model, a)
-                pgd.l2_step_(t, t.grad, alpha, epsilon, originals[a], sumsq=norms.sumsq_of(a))
+    attrs = {"color": ("_features_rest", "_features_dc"), "position": ("_xyz",), "scaling": ("_scaling",),
+             "rotation": ("_rotation",), "opacity": ("_opacity",)}
+    todo = [a for g in groups for a in attrs[g]]
+    have = all(getattr(model, a).grad is not None for a in todo)
+    if norm == "l2" and norms is not None and have and all(norms.sumsq_of(a) is not None for a in todo):
+        # the raster backward left ||grad||^2 of every tensor on the device: one launch for all of them
+        if pgd.multi_step_([(getattr(model, a), getattr(model, a).grad, originals[a], norms.sumsq_of(a)) for a in todo],
+                           alpha, epsilon, True):
+            return
+        for a in todo:
+            t = getattr(model, a)
+            pgd.l2_step_(t, t.grad, alpha, epsilon, originals[a], sumsq=norms.sumsq_of(a))
+        return
+    if have and len(todo) > 1 and MULTI_STEP:
+        # every stepped tensor has a gradient (the reference's own condition for stepping a group, attack.py:496): the
+        # same rules on all of them in one launch (an L2 norm that is not on the device yet is summed in front)
+        if pgd.multi_step_([(getattr(model, a), getattr(model, a).grad, originals[a], None) for a in todo], alpha, epsilon,
+                           norm == "l2"):
             return
     fn = {("color", "l2"): lambda: pgd.gaussian_color_l2_attack(model, alpha, epsilon, originals["_features_rest"],
                                                                   originals["_features_dc"]),

@@ -71,6 +71,46 @@ def _hip_step(x: torch.Tensor, grad, alpha: float, epsilon: float, x0: torch.Ten
     return True
 
 
+def multi_step_(items, alpha: float, epsilon: float, l2: bool) -> bool:
+    """The update of several tensors of one model in ONE launch (libgsraster.so: gsr_pgd_step_multi; bit for bit what
+    l2_step_ / linf_step_ give tensor by tensor).  items: [(x, grad, x0, sumsq or None), ...], at most 8.  True = done;
+    False = some tensor is not one the fused update takes (host tensors, another dtype or layout, no gradient): nothing
+    was touched and the caller steps tensor by tensor."""
+    import ctypes
+    items = list(items)
+    if not items or len(items) > 8:
+        return False
+    dev = items[0][0].device
+    prepared = []
+    for x, grad, x0, ss in items:
+        x = x.detach()
+        if grad is None or not (x.is_cuda and grad.is_cuda and x0.is_cuda) or x.device != dev:
+            return False
+        if x.shape != grad.shape or x.shape != x0.shape or x.dim() < 1 or x.numel() == 0:
+            return False
+        rows = x.shape[0]
+        cols = x.numel() // rows
+        if cols > 48 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in (x, grad, x0)):
+            return False
+        if ss is not None and not (ss.dtype == torch.float64 and ss.is_cuda and ss.numel() == 1):
+            return False
+        prepared.append((x, grad, x0, ss, rows, cols))
+    import diff_gaussian_rasterization as D
+    lib = D._load()
+    n = len(prepared)
+    ptrs = lambda k: (ctypes.c_void_p * n)(*[(None if p[k] is None else p[k].data_ptr()) for p in prepared])   # noqa: E731
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.gsr_pgd_step_multi(ctypes.c_int32(n), ptrs(0), ptrs(1), ptrs(2), (ctypes.c_int64 * n)(*[p[4] for p in prepared]),
+                                    (ctypes.c_int32 * n)(*[p[5] for p in prepared]), (ctypes.c_float * n)(*([alpha] * n)),
+                                    (ctypes.c_float * n)(*([epsilon] * n)), ctypes.c_int32(1 if l2 else 0), ptrs(3), stream)
+    if rc != 0:
+        raise RuntimeError(lib.gsr_last_error().decode())
+    for p in prepared:
+        torch.autograd.graph.increment_version(p[0])
+    return True
+
+
 def linf_step_(x: torch.Tensor, grad: torch.Tensor, alpha: float, epsilon: float, x0: torch.Tensor) -> None:
     if _hip_step(x.detach(), grad, alpha, epsilon, x0, False):
         return

@@ -329,6 +329,18 @@ int gsr_ctx_request_sumsq(GsrCtx* ctx, double* out6);
 int gsr_pgd_step_normed(float* x, const float* grad, const float* x0, int64_t rows, int32_t cols, float alpha, float epsilon,
                         const double* sumsq, void* stream);
 
+/*
+ * gsr_pgd_step_multi (round 6): the update of gsr_pgd_step / gsr_pgd_step_normed on n <= 8 tensors of one model in ONE
+ * launch (the attack steps _xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation in one iteration, reference
+ * attack.py:496-520: six short bandwidth-bound launches whose tails nothing on the stream covers).  Arrays of n host
+ * entries: x / grad / x0 device pointers, rows, cols (<= 48), alpha, epsilon; sumsq[t] = device pointer to ||grad_t||^2
+ * (one double, as gsr_pgd_step_normed takes it) or NULL -- with l2 != 0 a tensor without one has its norm summed by a
+ * launch of its own in front (sumsq == NULL: all of them).  Results are bit for bit those of the per-tensor calls.
+ */
+int gsr_pgd_step_multi(int32_t n, float* const* x, const float* const* grad, const float* const* x0, const int64_t* rows,
+                       const int32_t* cols, const float* alpha, const float* epsilon, int32_t l2, const double* const* sumsq,
+                       void* stream);
+
 /* Mean squared distance of every point to its 3 nearest other points (exact): replaces the reference's second native
  * import, simple_knn._C.distCUDA2 (reference scene/gaussian_model.py:17, called at :144 to seed the initial scales).
  * points [P,3] float32 device, mean_dist2 [P] float32 device.  Synchronises the stream once (scene set-up routine, not

@@ -66,6 +66,13 @@ def test_version_and_argument_validation_without_device(lib):
     assert out.value >= 400
     assert lib.gsr_ctx_rerender(None, None, None, None, None, None, one, None, 0, None) == 4
     assert b"null context" in lib.gsr_last_error()
+    # the multi-tensor step: the tensor count and the column counts are checked before any HIP call
+    assert lib.gsr_pgd_step_multi(0, None, None, None, None, None, None, None, 1, None, None) == 0
+    assert lib.gsr_pgd_step_multi(9, None, None, None, None, None, None, None, 1, None, None) == 1
+    assert b"tensors" in lib.gsr_last_error()
+    ptr, rows, cols, f = (ctypes.c_void_p * 1)(8), (ctypes.c_int64 * 1)(4), (ctypes.c_int32 * 1)(49), (ctypes.c_float * 1)(0.5)
+    assert lib.gsr_pgd_step_multi(1, ptr, ptr, ptr, rows, cols, f, f, 0, None, None) == 1
+    assert b"columns" in lib.gsr_last_error()
 
 
 def test_package_has_no_cpu_path():

@@ -1,5 +1,7 @@
 """The PGD loop counterpart on the HIP path: the surrogate loss goes down, perturbations stay inside the eps-ball,
 and a batch of views gives the same gradient as the sum of the single-view gradients."""
+import math
+
 import pytest
 import torch
 
@@ -122,6 +124,76 @@ def test_fused_pgd_step_matches_the_tensor_formulation(shape, kind):
         assert torch.allclose(got.cpu(), want, atol=2e-6, rtol=1e-5), (shape, kind, (got.cpu() - want).abs().max())
         if kind == "linf":
             assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("kind", ["linf", "l2", "l2_normed"])
+@pytest.mark.parametrize("rows", [5000, 4097, 37])
+def test_all_stepped_tensors_in_one_launch_equal_the_per_tensor_steps(kind, rows):
+    """gsr_pgd_step_multi: the six attribute tensors of a model (45, 3, 3, 1, 3, 4 floats per row; the gradients slices of
+    one flat bucket, so most start off a 16-byte boundary for odd rows) stepped in one launch -- bit for bit the per-tensor
+    gsr_pgd_step / gsr_pgd_step_normed, with norms already on the device for some, all or none of the tensors."""
+    from gsplat_attack import pgd
+    g = torch.Generator().manual_seed(rows)
+    shapes = [(rows, 15, 3), (rows, 1, 3), (rows, 3), (rows, 1), (rows, 3), (rows, 4)]
+    flat = (torch.randn(59 * rows, generator=g) * 2.0).cuda()
+    xs, x0s, grads, o = [], [], [], 0
+    for sh in shapes:
+        n = math.prod(sh)
+        x = torch.randn(*sh, generator=g)
+        xs.append(x.cuda())
+        x0s.append((x + torch.randn(*sh, generator=g) * torch.rand(rows, *([1] * (len(sh) - 1)), generator=g) * 2.0).cuda())
+        grads.append(flat[o:o + n].view(*sh))
+        o += n
+    grads[3] = torch.zeros_like(grads[3])                   # a zero gradient: no step for that tensor, projection only
+    l2 = kind != "linf"
+    ss = [None] * 6
+    if kind == "l2_normed":
+        ss = [(gr.double() ** 2).sum().reshape(1) if i != 4 else None for i, gr in enumerate(grads)]     # one without
+    want = [x.clone() for x in xs]
+    for w, gr, x0, s_ in zip(want, grads, x0s, ss):
+        if l2:
+            pgd.l2_step_(w, gr, 0.5, 0.8, x0, sumsq=s_)
+        else:
+            pgd.linf_step_(w, gr, 0.5, 0.8, x0)
+    got = [x.clone() for x in xs]
+    vers = [t._version for t in got]
+    assert pgd.multi_step_(list(zip(got, grads, x0s, ss)), 0.5, 0.8, l2)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), (kind, rows, i, (a - b).abs().max().item())
+        assert a._version > vers[i]
+    # tensors the fused update does not take: nothing touched, the caller steps tensor by tensor
+    keep = got[0].clone()
+    assert not pgd.multi_step_([(got[0], grads[0], x0s[0], None), (got[1].double(), grads[1].double(), x0s[1].double(), None)],
+                               0.5, 0.8, l2)
+    assert not pgd.multi_step_([(got[0], None, x0s[0], None)], 0.5, 0.8, l2)
+    assert torch.equal(got[0], keep)
+
+
+def test_pgd_attack_steps_all_groups_in_one_launch_with_the_same_result():
+    from gsplat_attack import attack as A
+    from gsplat_attack.attack import pgd_attack, SurrogateDetector
+    from gsplat_attack.scenes import make_scene
+    dev = torch.device("cuda:0")
+    model, cams, _ = make_scene("hydrant-1k", device=dev, n_views=3)
+    det = SurrogateDetector().to(dev)
+    res = []
+    for multi in (True, False):
+        for norm in ("l2", "linf"):
+            m = model.clone()
+            old = A.MULTI_STEP
+            A.MULTI_STEP = multi
+            try:
+                pgd_attack(m, cams, iters=3, groups=("color", "position", "scaling", "rotation", "opacity"), loss_fn=det,
+                           alpha=0.05, epsilon=0.3, norm=norm)
+            finally:
+                A.MULTI_STEP = old
+            res.append({n: getattr(m, n).detach().clone() for n in ("_xyz", "_features_dc", "_features_rest", "_opacity",
+                                                                    "_scaling", "_rotation")})
+    for a, b in ((res[0], res[2]), (res[1], res[3])):       # same arithmetic per tensor: bit-equal
+        for n in a:
+            assert torch.equal(a[n], b[n]), n
+    assert not torch.equal(res[0]["_xyz"], model._xyz.detach()) and not torch.equal(res[1]["_rotation"], model._rotation.detach())
 
 
 @pytest.mark.parametrize("kind", ["linf", "l2"])
