@@ -2372,8 +2372,13 @@ struct PreBwdBatchArgs {
 // dependent memory phases per view; W chains of B / W views finish sooner than one of B), the waves' sums meet in LDS, wave 0
 // finishes and stores the geometry gradients, and the dL/dSH phase is dealt over the waves by groups of 16 Gaussians.
 constexpr int BATCH_K9_WAVES = 2;
+// Waves per SIMD the geometry variant is compiled for: 3 = 164 VGPRs without scratch (left alone the allocator takes 172 and
+// the kernel drops to 2 waves: 0.085 -> 0.115 ms per view at B = 8); 4 = 128 VGPRs and ~100 bytes of scratch per lane.
+#ifndef GSR_BATCH_K9_OCC
+#define GSR_BATCH_K9_OCC 3
+#endif
 template <bool GEOM, bool ACC>
-__global__ void __launch_bounds__(64 * BATCH_K9_WAVES) k_pre_bwd_batch(PreBwdBatchArgs a) {
+__global__ void __launch_bounds__(64 * BATCH_K9_WAVES, GEOM ? GSR_BATCH_K9_OCC : 1) k_pre_bwd_batch(PreBwdBatchArgs a) {
   __shared__ float4 srow_all[BATCH_K9_WAVES][ROW_CHUNK * PART_F4];
   __shared__ float spos[64 * 3];
   __shared__ uint32_t sany[BATCH_K9_WAVES][64];
