@@ -1586,7 +1586,8 @@ int gsr_pgd_step_normed(float* x, const float* grad, const float* x0, int64_t ro
     return set_err(GSR_ERR_INVALID, "gsr_pgd_step_normed: rows=%lld cols=%d (1..%d columns)", (long long)rows, cols, PGD_MAX_COLS);
   if (rows == 0) return GSR_OK;
   if (!x || !grad || !x0 || !sumsq) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_normed: null argument");
-  hipLaunchKernelGGL((k_pgd_step<true>), dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), x, grad,
+  const int64_t rpw = pgd_rows_per_wave(cols);
+  hipLaunchKernelGGL((k_pgd_step<true>), dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(64), 0, static_cast<hipStream_t>(stream), x, grad,
                      x0, (size_t)rows, cols, alpha, epsilon, sumsq, 1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "gsr_pgd_step_normed: launch failed: %s", hipGetErrorString(e));
@@ -1602,7 +1603,8 @@ int gsr_pgd_step(float* x, const float* grad, const float* x0, int64_t rows, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int dev = cur_dev();
   const size_t n = (size_t)rows * (size_t)cols;
-  const unsigned blocks = (unsigned)((rows + 63) / 64);
+  const int64_t rpw = pgd_rows_per_wave(cols);
+  const unsigned blocks = (unsigned)((rows + rpw - 1) / rpw);
   if (!l2) {
     hipLaunchKernelGGL((k_pgd_step<false>), dim3(blocks), dim3(64), 0, st, x, grad, x0, (size_t)rows, cols, alpha, epsilon,
                        (const double*)nullptr, 0);
@@ -1641,7 +1643,7 @@ int gsr_pgd_step_multi(int32_t n, float* const* x, const float* const* grad, con
     m.x[t] = x[t]; m.g[t] = grad[t]; m.x0[t] = x0[t];
     m.rows[t] = (unsigned long long)rows[t]; m.cols[t] = cols[t]; m.alpha[t] = alpha[t]; m.eps[t] = epsilon[t];
     m.first[t] = (unsigned)blocks;
-    blocks += (unsigned long long)((rows[t] + 63) / 64);
+    blocks += (unsigned long long)((rows[t] + pgd_rows_per_wave(cols[t]) - 1) / pgd_rows_per_wave(cols[t]));
     if (blocks > 0x7fffffffull) return set_err(GSR_ERR_INVALID, "gsr_pgd_step_multi: too many rows for one launch");
     if (l2 && rows[t] > 0) {
       if (sumsq && sumsq[t]) { m.partial[t] = sumsq[t]; m.nb[t] = 1; }

@@ -5,8 +5,8 @@
 //   L2:     x += -alpha * g / ||g||_2 (norm over the WHOLE tensor; no step if it is 0);
 //           d = x - x0, each ROW clipped to the eps ball: d *= eps / (||d_row|| + 1e-7) when ||d_row|| > eps
 //           (torch.renorm(p=2, dim=0, maxnorm=eps));  x = x0 + d                          (attack.py:53-119, 138-173)
-// Rows are whole Gaussians (cols = 3, 4, 1 or 45 floats).  A wave owns 64 consecutive rows = one contiguous span of
-// the three tensors: it is copied through LDS with coalesced 16-byte loads (cols is odd or small, so lane r walking row r
+// Rows are whole Gaussians (cols = 3, 4, 1 or 45 floats).  A wave owns 64 consecutive rows (32 of the wide ones) = one
+// contiguous span of the three tensors: it is copied through LDS with coalesced 16-byte loads (cols is odd or small, so lane r walking row r
 // is bank-conflict free for the 45-float rows) and written back the same way.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,6 +15,11 @@
 namespace gsr {
 
 constexpr int PGD_MAX_COLS = 48;
+// Rows per wave: 64 for narrow rows; 32 for rows wider than PGD_NARROW floats, so that a wave's deltas take 6 KB of LDS
+// instead of 12 and 16 waves fit a CU where 12 did (the kernel is bandwidth-bound: more waves = more loads in flight).
+constexpr int PGD_NARROW = 24;
+constexpr int PGD_LDS_FLOATS = 64 * PGD_NARROW > 32 * PGD_MAX_COLS ? 64 * PGD_NARROW : 32 * PGD_MAX_COLS;
+__host__ __device__ inline int pgd_rows_per_wave(int cols) { return cols > PGD_NARROW ? 32 : 64; }
 
 // per-block partial sums of squares (float per thread, double across the block: the order is fixed => reproducible).
 // 16-byte loads when the tensor starts on a 16-byte boundary (n / 4 float4 + a scalar tail), 4-byte loads otherwise.
@@ -38,21 +43,22 @@ __global__ void __launch_bounds__(256) k_pgd_sumsq(const float* __restrict__ g, 
 }
 
 // L2 == true: `partial[nb]` holds the block sums of squares of g.
-// A wave's 64 rows are one contiguous, 256-byte aligned span of 64 * cols floats: it is moved with 16-byte accesses
+// A wave's 64 (32) rows are one contiguous, 128-byte aligned span of 64 (32) * cols floats: it is moved with 16-byte accesses
 // (a full wave's span is a whole number of float4; the last, partial wave of a tensor falls back to 4-byte accesses).
 // (the body of both kernels below: `blk` = the wave's index among the tensor's groups of 64 rows)
 template <bool L2>
 __device__ __forceinline__ void pgd_step_wave(float* __restrict__ x, const float* __restrict__ g,
                                               const float* __restrict__ x0, size_t rows, int cols, float alpha,
                                               float eps, const double* __restrict__ partial, int nb, unsigned blk) {
-  __shared__ __attribute__((aligned(16))) float sd[64 * PGD_MAX_COLS];     // the wave's deltas x_new - x0
+  __shared__ __attribute__((aligned(16))) float sd[PGD_LDS_FLOATS];        // the wave's deltas x_new - x0
   __shared__ float sf[64];                    // per-row clip factors
   const int lane = threadIdx.x;
-  const size_t r0 = (size_t)blk * 64;
-  const int nr = (int)min((size_t)64, rows - r0);
+  const int rpw = pgd_rows_per_wave(cols);
+  const size_t r0 = (size_t)blk * (size_t)rpw;
+  const int nr = (int)min((size_t)rpw, rows - r0);
   const size_t base = r0 * (size_t)cols;
   const int n = nr * cols;
-  const bool vec = nr == 64 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x0)) & 15u) == 0u;
+  const bool vec = nr == rpw && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x0)) & 15u) == 0u;
   float scale = 0.f;                            // alpha / ||g||  (0 when the gradient is zero: no step)
   if (L2) {
     double t = 0.0;

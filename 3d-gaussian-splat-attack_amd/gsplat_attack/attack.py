@@ -68,8 +68,8 @@ def _step(model, originals, groups: Sequence[str], norm: str, alpha: float, epsi
     have = all(getattr(model, a).grad is not None for a in todo)
     if norm == "l2" and norms is not None and have and all(norms.sumsq_of(a) is not None for a in todo):
         # the raster backward left ||grad||^2 of every tensor on the device: one launch for all of them
-        if pgd.multi_step_([(getattr(model, a), getattr(model, a).grad, originals[a], norms.sumsq_of(a)) for a in todo],
-                           alpha, epsilon, True):
+        if MULTI_STEP and pgd.multi_step_([(getattr(model, a), getattr(model, a).grad, originals[a], norms.sumsq_of(a))
+                                           for a in todo], alpha, epsilon, True):
             return
         for a in todo:
             t = getattr(model, a)

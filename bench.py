@@ -94,6 +94,9 @@ def main():
                          "own buffer (gsr_backward_raw_batch_views); streams: one render() + backward per view dealt over "
                          "--streams HIP streams (rounds 2-5's headline, reported as `pipelined_streams` otherwise); auto: "
                          "batched-views when the configuration allows it")
+    ap.add_argument("--views-per-chain", type=int, default=0,
+                    help="headline regime: at most this many views per launch chain (default 8; the largest divisor of "
+                         "--steps up to it is used)")
     ap.add_argument("--headline-only", action="store_true",
                     help="profiling runs: only the headline regime (warm-up included) launches kernels, so that per-kernel "
                          "averages of a profiler describe one kind of launch")
@@ -212,7 +215,8 @@ def main():
     # groups and every launch of a kernel covers the same number of views.
     Bh = 0
     if world == 1 and args.headline != "streams" and not (args.classic or args.objects or args.color_only or args.cu_masks):
-        Bh = max([d for d in range(2, min(8, D.MAX_BATCH) + 1) if args.steps % d == 0], default=0)
+        cap = args.views_per_chain if args.views_per_chain else 8
+        Bh = max([d for d in range(2, min(cap, D.MAX_BATCH) + 1) if args.steps % d == 0], default=0)
     if args.headline == "batched-views" and Bh == 0:
         raise SystemExit("[bench] --headline batched-views needs N = 1, the fused path without object channels and a "
                          "--steps with a divisor in 2..8")

@@ -162,6 +162,17 @@ def test_all_stepped_tensors_in_one_launch_equal_the_per_tensor_steps(kind, rows
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), (kind, rows, i, (a - b).abs().max().item())
         assert a._version > vers[i]
+    # tensors of different lengths in one launch (the table of first workgroups per tensor)
+    cut = [rows, max(rows // 3, 1), rows, 1, max(rows - 5, 1), rows]
+    want2 = [x[:c].clone() for x, c in zip(xs, cut)]
+    for w, gr, x0, c in zip(want2, grads, x0s, cut):
+        (pgd.l2_step_ if l2 else pgd.linf_step_)(w, gr[:c].contiguous(), 0.5, 0.8, x0[:c].contiguous())
+    got2 = [x[:c].clone() for x, c in zip(xs, cut)]
+    assert pgd.multi_step_([(g_, gr[:c].contiguous(), x0[:c].contiguous(), None) for g_, gr, x0, c in zip(got2, grads, x0s, cut)],
+                           0.5, 0.8, l2)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got2, want2)):
+        assert torch.equal(a, b), (kind, rows, i, "ragged")
     # tensors the fused update does not take: nothing touched, the caller steps tensor by tensor
     keep = got[0].clone()
     assert not pgd.multi_step_([(got[0], grads[0], x0s[0], None), (got[1].double(), grads[1].double(), x0s[1].double(), None)],
