@@ -1247,8 +1247,11 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
   // is short whatever the tile count, so one wave per tile it is (S-hydrant-full, 2500 tiles: K7 0.169 -> 0.194 ms but
   // K8+K9 0.141 -> 0.084 ms, 2563 -> 2811 views/s); only without segments (object channels, GSR_FLAG_NO_SEGMENTS) an
   // image with fewer tiles than the chip has wave slots is split in two.  GSR_FLAG_BWD_SPLIT(n) overrides.
+  // (The rule looks at the tiles of ONE view, also for a batch: the split decides how many partial rows K9 adds up per
+  // pair -- the float32 association of the sums -- and a batch's per-view gradients are the single-view call's bit for bit.
+  // Found by tests/diag_fuzz_batch.py with GSR_FLAG_NO_SEGMENTS on batches of >= 4096 tiles of views with fewer.)
   const bool segs_on = c->bnd != nullptr && !obj;
-  const int bwd_npx = flag_bwd_npx(c->st.flags) ? flag_bwd_npx(c->st.flags) : ((c->ntiles < 4096 && !segs_on) ? 2 : 4);
+  const int bwd_npx = flag_bwd_npx(c->st.flags) ? flag_bwd_npx(c->st.flags) : ((c->tpv < 4096 && !segs_on) ? 2 : 4);
   const uint32_t nsub = (uint32_t)(PXL / bwd_npx);
   if (N > 0) {
     part_blk = pool_alloc(dev, sizeof(float4) * PART_F4 * (size_t)N * nsub, st);

@@ -7,7 +7,7 @@ that see nothing.  Checked, as tests/test_gpu_batch.py does on its fixed cases:
   * per-view gradients (GradBucketSet, gsr_backward_raw_batch_views) bit-equal to the single-view backward,
   * summed gradients (gsr_backward_raw_batch_into) against the double sum of the single-view gradients (test's yardstick).
 
-    python tests/diag_fuzz_batch.py first_seed last_seed
+    python tests/diag_fuzz_batch.py first_seed last_seed          (FUZZ_FLAGS=1: random extension flags per draw, see draw_flags)
 """
 import math
 import os
@@ -58,6 +58,24 @@ def draw(seed: int, dev):
     return model, cams, bgs, gcs, u(0.5, 1.6), f"P={P} {W}x{H} B={B} deg={model.active_sh_degree}"
 
 
+def draw_flags(seed: int) -> int:
+    """FUZZ_FLAGS=1: extension flags for the draw -- the same for the batch and for the single-view calls it is held to (which
+    must stay bit-equal under every combination): footprint cull off, segment records off, the forward's staging shared by
+    a tile's waves, no side stream for the colour kernel, forced forward / backward splits and tile maps."""
+    import diff_gaussian_rasterization as D
+    g = torch.Generator().manual_seed(seed + 77_777)
+    r = lambda n: int(torch.randint(0, n, (), generator=g))   # noqa: E731
+    f = 0
+    if r(3) == 0: f |= D.FLAG_NO_CULL
+    if r(3) == 0: f |= D.FLAG_NO_SEGMENTS
+    if r(4) == 0: f |= D.FLAG_FWD_SHARED
+    if r(3) == 0: f |= D.FLAG_NO_SIDE_STREAM
+    f |= D.flag_fwd_split((0, 0, 1, 2, 4)[r(5)])
+    f |= D.flag_bwd_split((0, 0, 2, 4)[r(4)])
+    if r(2) == 0: f |= D.flag_tile_map(r(4))
+    return f
+
+
 def per_view(model, cams, bgs, gcs, scale):
     import diff_gaussian_rasterization as D
     from gsplat_attack import renderer as R
@@ -92,9 +110,14 @@ def main():
     for seed in range(lo, hi):
         desc = "?"
         try:
+            import diff_gaussian_rasterization as D
             model, cams, bgs, gcs, scale, desc = draw(seed, dev)
-            seen += per_view(model, cams, bgs, gcs, scale)
-            TB._check_equal(model, cams, gcs, bg_list=bgs, scale=scale)
+            flags = draw_flags(seed) if os.environ.get("FUZZ_FLAGS") else 0
+            if flags:
+                desc += f" flags={flags:#x}"
+            with D.extra_flags(flags):
+                seen += per_view(model, cams, bgs, gcs, scale)
+                TB._check_equal(model, cams, gcs, bg_list=bgs, scale=scale)
             views += len(cams)
         except Exception as e:                               # noqa: BLE001
             bad.append(seed)

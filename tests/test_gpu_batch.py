@@ -340,3 +340,31 @@ def test_needles_seen_by_several_views_match_the_oracle_in_loop_and_batch(seed):
         assert ((gl - go).abs().max() / s_).item() <= 5e-5, (name, "loop")
         assert ((gb - go).abs().max() / s_).item() <= 5e-5, (name, "batch")
         assert ((gb - gl).abs().max() / s_).item() <= 5e-5, (name, "batch vs loop")
+
+
+def test_per_view_gradients_stay_bit_equal_without_segments_on_a_batch_of_many_tiles():
+    """Found by tests/diag_fuzz_batch.py with random extension flags (round 6): under GSR_FLAG_NO_SEGMENTS the backward
+    splits a tile over two waves when the image has fewer than 4096 tiles -- the rule looked at the batch's tiles (13 x 396
+    here), chose one wave per tile for the batch and two for the single view, and K9 summed a different number of partial
+    rows per pair: equal within float32 rounding, not bit for bit.  The rule looks at one view's tiles now."""
+    import diff_gaussian_rasterization as D
+    from gsplat_attack.scenes import make_scene
+    from gsplat_attack.renderer import PipelineParams, render, render_batch
+    dev = _dev()
+    P, W, H, B = 3000, 338, 274, 13
+    model, cams, _ = make_scene("nyc-1M", device=dev, P=P, width=W, height=H, n_views=B)
+    g = torch.Generator().manual_seed(13)
+    gcs = [torch.randn(3, H, W, generator=g).to(dev) for _ in cams]
+    bg = torch.tensor([0.3, 0.2, 0.1], device=dev)
+    for flags in (D.FLAG_NO_SEGMENTS, D.FLAG_NO_SEGMENTS | D.FLAG_FWD_SHARED | D.flag_tile_map(0), 0):
+        with D.extra_flags(flags):
+            bset = D.GradBucketSet(B, P, dev)
+            out = render_batch(cams, model, PipelineParams(skip_objects=True, grad_bucket=bset), bg)
+            out["render"].backward(torch.stack(gcs))
+            for v in (0, 7, 12):
+                one = D.GradBucket(P, dev)
+                o = render(cams[v], model, PipelineParams(skip_objects=True, grad_bucket=one), bg)
+                o["render"].backward(gcs[v])
+                torch.cuda.synchronize()
+                assert torch.equal(out["render"][v].detach(), o["render"].detach()), (flags, v)
+                assert torch.equal(bset.bucket(v).flat, one.flat), (flags, v)
