@@ -246,6 +246,14 @@ def main():
         gcb_rank = gc.unsqueeze(0).expand(B, 3, H, W).contiguous() if batch_views else None
         pipe_one = PipelineParams(skip_objects=not args.objects, grad_bucket=buckets[0])
 
+        def step_all():
+            # the identical projected L2 step on every rank (attack.py:53-173): all six tensors in one launch (gsr_pgd_step_multi,
+            # the norms summed in front), bit for bit the six per-tensor steps it falls back to
+            items = [(getattr(model, n_), getattr(model, n_).grad, originals[n_], None) for n_ in gdist.ATTACK_PARAMS]
+            if not gpgd.multi_step_(items, 0.5, 5.0, True):
+                for p_, g_, o_, _ in items:
+                    gpgd.l2_step_(p_, g_, 0.5, 5.0, o_)
+
         def pgd_step_batched():
             # the rank's B views through ONE launch chain (gsr_forward_raw_batch / gsr_backward_raw_batch_into): the bucket
             # receives the summed gradient of the B views, written once
@@ -269,9 +277,7 @@ def main():
                 e1.record()
                 ar_events.append((e0, e1))
                 tot.assign_to(model)
-                for n_ in gdist.ATTACK_PARAMS:
-                    p_ = getattr(model, n_)
-                    gpgd.l2_step_(p_, p_.grad, 0.5, 5.0, originals[n_])
+                step_all()
                 return
             for b_ in buckets:
                 b_.reset()
@@ -296,9 +302,7 @@ def main():
             e1.record()
             ar_events.append((e0, e1))
             tot.assign_to(model)
-            for n_ in gdist.ATTACK_PARAMS:                 # the identical projected step on every rank (attack.py:53-173)
-                p_ = getattr(model, n_)
-                gpgd.l2_step_(p_, p_.grad, 0.5, 5.0, originals[n_])
+            step_all()
 
         def run_steps(n, use_streams=True):                # noqa: F811 -- the N > 1 definition of a step
             for _ in range(n):
