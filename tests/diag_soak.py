@@ -28,3 +28,28 @@ for rep in range(4):
 assert D.pool_bytes() <= p0 * 1.3 + (64 << 20), (p0, D.pool_bytes())
 assert torch.cuda.memory_reserved() <= t0 * 1.3 + (256 << 20)
 print("flat: ok")
+
+# the same with batches of views of changing size through one launch chain (round 6): summed gradients and per-view buckets
+from gsplat_attack.renderer import render_batch
+P = int(model.get_xyz.shape[0])
+H, W = cams[0].image_height, cams[0].image_width
+bucket = D.GradBucket(P, dev)
+bset = D.GradBucketSet(8, P, dev)
+def run_batches(n):
+    for i in range(n):
+        B = (5, 8, 3, 1, 8)[i % 5]
+        group = [cams[(i + k) % 8] for k in range(B)]
+        tgt = bset if i % 2 else bucket
+        if tgt is bucket:
+            bucket.reset()
+        out = render_batch(group, model, PipelineParams(skip_objects=True, grad_bucket=tgt), bg)
+        out["render"].backward(gc.unsqueeze(0).expand(B, 3, H, W))
+    torch.cuda.synchronize()
+run_batches(10)
+p0, t0 = D.pool_bytes(), torch.cuda.memory_reserved()
+for rep in range(3):
+    t = time.perf_counter(); run_batches(200); dt = time.perf_counter() - t
+    print(f"batches round {rep}: {200 * 5.0 / dt:7.1f} views/s  pool {D.pool_bytes() / 2**20:8.1f} MiB  torch reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB", flush=True)
+assert D.pool_bytes() <= p0 * 1.3 + (64 << 20), (p0, D.pool_bytes())
+assert torch.cuda.memory_reserved() <= t0 * 1.3 + (256 << 20)
+print("batches flat: ok")
