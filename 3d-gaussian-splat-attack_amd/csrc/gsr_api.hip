@@ -807,7 +807,7 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     if (B > 1 && raw && batch_color_env != 0) {
       PreColorBatchArgs ca;
       ca.P = P; ca.B = B; ca.Ppad = Ppad; ca.deg = s->sh_degree; ca.vpack = c->vpack; ca.means = means3D; ca.sh = shs; ca.sh_dc = sh_dc;
-      ca.tcnt = tcnt; ca.G1 = G1; ca.G2 = G2; ca.D = c->D;
+      ca.tcnt = tcnt; ca.offg = nullptr; ca.G1 = G1; ca.G2 = G2; ca.D = c->D;
       hipLaunchKernelGGL(k_pre_color_batch, gridC, blkCol, 0, cs, ca);
     } else {
       for (int v = 0; v < B; ++v) {
@@ -1147,7 +1147,9 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
                      void* stream) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_rerender: null context");
   if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: out_color is null");
-  if (c->B > 1) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context is a batch of %d views (gsr_forward_raw_batch)", c->B);
+  // a batch context (gsr_forward_raw_batch): out_color [B,3,H,W], bg [B,3] or null; no object channels, one attribute segment
+  if (c->B > 1 && (out_objects || features_dc_b || features_rest_b))
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: a batch context (%d views) has no object channels and one attribute segment", c->B);
   if (c->P > 0 && (!c->lanegroup || !c->shs))
     return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context was not rendered from SH coefficients (raw parameters, "
                    "or shs with K = 16): there is no colour stage to run again");
@@ -1172,8 +1174,34 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
   if (features_dc) c->sh_dc = features_dc;
   if (features_rest_b) c->b.features_rest = features_rest_b;
   if (features_dc_b) c->b.features_dc = features_dc_b;
-  if (bg) c->st.bg = bg;
-  if (c->P > 0) {
+  if (bg && c->B > 1) {
+    for (int v = 0; v < c->B; ++v) c->views[v].bg = bg + 3 * (size_t)v;
+    c->st.bg = bg;
+  } else if (bg) {
+    c->st.bg = bg;
+  }
+  if (c->P > 0 && c->B > 1) {
+    // the batch's colour kernel over the Gaussians that emit pairs in ANY view (every SH row read once), the views' constants
+    // packed again first: the CONTENTS of a background tensor may have changed, and the compositors read it from there
+    StageTimer t(GSR_STAGE_PREPROCESS, st);
+    ViewPtrs vp{};
+    for (int v = 0; v < c->B; ++v) {
+      const GsrSettings& sv = c->views[v];
+      vp.vm[v] = sv.viewmatrix; vp.pm[v] = sv.projmatrix; vp.cam[v] = sv.campos; vp.bg[v] = sv.bg;
+      vp.tanfovx[v] = sv.tanfovx; vp.tanfovy[v] = sv.tanfovy;
+    }
+    hipLaunchKernelGGL(k_pack_views, dim3(c->B), dim3(64), 0, st, vp, c->B, c->vpack);
+    PreColorBatchArgs ca;
+    ca.P = c->P; ca.B = c->B; ca.Ppad = c->Ppad; ca.deg = c->st.sh_degree; ca.vpack = c->vpack; ca.means = c->means3D;
+    ca.sh = c->shs; ca.sh_dc = c->sh_dc; ca.tcnt = nullptr; ca.offg = c->offg; ca.G1 = c->G1; ca.G2 = c->G2;
+    const bool skip_D = (flags & GSR_RERENDER_COLOR_GRADS_ONLY) != 0u;
+    ca.D = skip_D ? nullptr : c->D;
+    c->D_stale = c->D != nullptr && skip_D;
+    const dim3 gridC((unsigned)((c->P + PREF_BLOCK - 1) / PREF_BLOCK)), blkC(PREF_BLOCK);
+    hipLaunchKernelGGL(k_pre_color_batch, gridC, blkC, 0, st, ca);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "rerender colours (batch): launch failed: %s", hipGetErrorString(e));
+  } else if (c->P > 0) {
     StageTimer t(GSR_STAGE_PREPROCESS, st);
     PreArgs pa{};
     pa.P = c->P; pa.va = view_args(c->st); pa.means = c->means3D; pa.sh = c->shs; pa.sh_dc = c->sh_dc;

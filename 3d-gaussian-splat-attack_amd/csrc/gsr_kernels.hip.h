@@ -1942,6 +1942,8 @@ struct PreColorBatchArgs {
   const float* sh;        // _features_rest [P,15,3]
   const float* sh_dc;     // _features_dc [P,1,3]
   const uint32_t* tcnt;   // [B * Ppad] tiles touched by (view, Gaussian)
+  const uint32_t* offg;   // tcnt == null (re-render of a kept batch context): (view, Gaussian) emits pairs iff
+                          // offg[i + 1] != offg[i], i = view * Ppad + g (the storage-order scan the context keeps)
   float4* G1;             // records of the virtual scene (G0 + 1, G0 + 2)
   float4* G2;
   float* D;               // [B * Ppad, 9] or null
@@ -1956,8 +1958,16 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color_batch(PreColorBatchArg
     const int g = chunk * PREF_BLOCK + wave * 64 + lane;
     uint32_t seen = 0;                                     // bit v: view v has pairs of this Gaussian
     if (g < a.P) {
+      if (a.tcnt != nullptr) {
 #pragma unroll 4
-      for (int v = 0; v < a.B; ++v) seen |= (a.tcnt[(size_t)v * (size_t)a.Ppad + g] != 0u ? 1u : 0u) << v;
+        for (int v = 0; v < a.B; ++v) seen |= (a.tcnt[(size_t)v * (size_t)a.Ppad + g] != 0u ? 1u : 0u) << v;
+      } else {
+#pragma unroll 4
+        for (int v = 0; v < a.B; ++v) {
+          const size_t i = (size_t)v * (size_t)a.Ppad + g;
+          seen |= (a.offg[i + 1] != a.offg[i] ? 1u : 0u) << v;
+        }
+      }
     }
     const bool ok = seen != 0u;
     const uint64_t live = __ballot(ok);

@@ -897,6 +897,18 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 MAX_BATCH = 16                # views per gsr_forward_raw_batch call (csrc/gsr_kernels.hip.h)
 
 
+class _BatchPack:
+    """What a kept BATCH context's cache entry holds on to: the views' settings packs (their device tensors are what the
+    context's pointers point into), the radii of the key's first render, and -- once a render came with other background
+    tensors than the forward's -- the [B,3] tensor of background values the context reads instead."""
+    __slots__ = ("packs", "radii", "bg_src", "bgt")
+
+    def __init__(self, packs, radii):
+        self.packs, self.radii = packs, radii
+        self.bg_src = tuple(pk.bg.data_ptr() for pk in packs)
+        self.bgt = None
+
+
 class _RasterizeGaussiansRawBatch(torch.autograd.Function):
     """B views of one set of RAW parameters through ONE launch chain (gsr_forward_raw_batch / gsr_backward_raw_batch_into):
     what the reference's batch loop does with B render() calls and one accumulated .grad (attack.py:476-494).
@@ -904,10 +916,11 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, settings_list, keep=True,
-                bucket=None, norms=None):
+                bucket=None, norms=None, cache_slot=None, color_only=False):
         lib = _load()
         ctx.bucket = bucket
         ctx.norms = norms
+        ctx.entry = None
         if not xyz.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device (got "
                                f"{xyz.device}); there is no CPU path")
@@ -932,13 +945,65 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
         radii = torch.empty(B, P, dtype=torch.int32, device=device)
         handle = ctypes.c_void_p(None)
         nren = ctypes.c_int64(0)
+        # a kept batch context (RenderCache): the key's geometry tensors and ALL its views' camera tensors unchanged since the
+        # key's last render -> the batch's colour kernel + one compositor launch over the kept lists (gsr_ctx_rerender)
+        entry, sig, refs = None, None, None
+        if cache_slot is not None and P > 0:
+            cache, key = cache_slot
+            geo = (xyz, opacity, scaling, rotation)
+            if all(a.data_ptr() == b.data_ptr() for a, b in zip(geo, (x, op, sc, ro))):
+                extra = [B]
+                for rs in settings_list[1:]:
+                    extra += [float(rs.tanfovx), float(rs.tanfovy)]
+                    for t in (rs.viewmatrix, rs.projmatrix, rs.campos):
+                        extra += [t.data_ptr(), t._version]
+                sig = _cache_sig(geo, settings_list[0], extra=extra)
+                refs = geo + tuple(t for rs in settings_list for t in (rs.viewmatrix, rs.projmatrix, rs.campos))
+                entry, may_store = cache._lookup(key, sig, refs)
+                if not may_store:
+                    sig = None                      # the key's context is waiting for a backward: plain forward, not stored
         with torch.cuda.device(device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            rc = lib.gsr_forward_raw_batch(carr, B, P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(op), _ptr(sc), _ptr(ro), _ptr(color),
-                                           _ptr(radii), ctypes.byref(handle) if keep else None, ctypes.byref(nren), stream)
+            if entry is not None:
+                _entry_enter(entry, device)
+                bp = entry.pack
+                radii = bp.radii.detach()              # geometry is unchanged: so are the radii of the key's first render
+                ptrs = tuple(pk.bg.data_ptr() for pk in packs)
+                bgt = None
+                if ptrs != bp.bg_src or bp.bgt is not None:
+                    # other background tensors than the context's forward saw: their values as one [B,3] tensor
+                    bgt = torch.stack([pk.bg[:3] for pk in packs]).contiguous()
+                    bp.bgt, bp.bg_src = bgt, ptrs       # (bp.packs stays: the context's camera pointers point into them)
+                rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(dc), _ptr(rest), None, None, _ptr(bgt), _ptr(color), None,
+                                          1 if color_only else 0, stream)
+                entry.gen += 1
+                nren.value = entry.nren
+                if rc == GSR_ERR_OVERFLOW:             # (see _RasterizeGaussiansRaw: the entry can never be re-rendered)
+                    cache.entries.pop(key, None)
+                    cache.dropped_overflow += 1
+                    entry = None
+            if entry is None:
+                want_ctx = keep or sig is not None
+                rc = lib.gsr_forward_raw_batch(carr, B, P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(op), _ptr(sc), _ptr(ro), _ptr(color),
+                                               _ptr(radii), ctypes.byref(handle) if want_ctx else None, ctypes.byref(nren), stream)
         if rc != 0:
             raise Exception(_err(lib)) if rc == 1 else (PairCapacityExceeded if rc == GSR_ERR_OVERFLOW else RuntimeError)(_err(lib))
-        ctx.holder = _CtxHolder(lib, handle) if (keep and handle.value) else None
+        if entry is not None:
+            ctx.holder = entry.holder
+        else:
+            ctx.holder = _CtxHolder(lib, handle) if handle.value else None
+            if sig is not None and ctx.holder is not None:
+                bp = _BatchPack(packs, radii)
+                entry = _CacheEntry(ctx.holder, sig, tuple(weakref.ref(t) for t in refs), bp, nren.value)
+                cache_slot[0]._store(cache_slot[1], entry)
+        if entry is not None:
+            _entry_leave(entry, device)
+            ctx.entry, ctx.entry_gen = entry, entry.gen
+            if keep:
+                ctx.token = _RenderToken()
+                entry.token = weakref.ref(ctx.token)
+        if not keep:
+            ctx.holder = None
         ctx.packs = packs
         ctx.pack = packs[0]
         ctx.B = B
@@ -960,9 +1025,15 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
             s = ctx.shapes
             dev0 = ctx.packs[0].device
             z = lambda i, shp: torch.zeros(shp, dtype=torch.float32, device=dev0) if (need[i] and shp is not None) else None
-            return (z(0, s[0]), z(1, s[1]), z(2, s[2]), z(3, s[3]), z(4, s[4]), z(5, s[5]), z(6, s[6]), None, None, None, None)
+            return (z(0, s[0]), z(1, s[1]), z(2, s[2]), z(3, s[3]), z(4, s[4]), z(5, s[5]), z(6, s[6]), None, None, None, None,
+                    None, None)
         lib = ctx.holder.lib
         device = x.device
+        if ctx.entry is not None:
+            if ctx.entry.gen != ctx.entry_gen:
+                raise RuntimeError("diff_gaussian_rasterization: this batch's kept context (RenderCache) was rendered again "
+                                   "before its backward ran; call backward() first, or render without the cache")
+            _entry_enter(ctx.entry, device)
         P, B = int(x.shape[0]), ctx.B
         H, W = ctx.pack.c.image_height, ctx.pack.c.image_width
         if grad_color is None:
@@ -1044,29 +1115,40 @@ class _RasterizeGaussiansRawBatch(torch.autograd.Function):
             for t in (d_x, d_dc, d_rest, d_op, d_sc, d_ro, d_m2):
                 if t is not None and bucket is None:
                     t.zero_()
+        if ctx.entry is not None:
+            _entry_leave(ctx.entry, device)
+            ctx.token.done = True
         s = ctx.shapes
         if bset is not None:
-            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None)
+            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None,
+                    None, None)
         if bucket is not None:
             bucket.fresh, bucket.used = False, True
-            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None)
+            return (None, None if d_m2 is None else d_m2.reshape(s[1]), None, None, None, None, None, None, None, None, None,
+                    None, None)
 
         def shaped(t, shape, wanted=True):
             return None if (t is None or not wanted) else t.reshape(shape)
         return (shaped(d_x, s[0]), shaped(d_m2, s[1]), shaped(d_dc, s[2], need[2]), shaped(d_rest, s[3], need[3]),
-                shaped(d_op, s[4]), shaped(d_sc, s[5]), shaped(d_ro, s[6]), None, None, None, None)
+                shaped(d_op, s[4]), shaped(d_sc, s[5]), shaped(d_ro, s[6]), None, None, None, None, None, None)
 
 
 def rasterize_gaussians_raw_batch(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, settings_list,
-                                  grad_bucket: Optional["GradBucket"] = None, grad_norms: Optional["GradNorms"] = None):
+                                  grad_bucket: Optional["GradBucket"] = None, grad_norms: Optional["GradNorms"] = None,
+                                  cache: Optional["RenderCache"] = None, cache_key=None):
     """(color[B,3,H,W], radii[B,P]) of B views (a list of GaussianRasterizationSettings that agree in image size, scale
     modifier and SH degree) of one set of RAW parameters, through one launch chain: every image and radius is bit for bit
     what rasterize_gaussians_raw gives for that view alone, and the backward leaves the SUM over the views of the
     attribute gradients, written once.  means2D: a [B,P,3] tensor whose .grad receives the per-view screen-space gradient
     (viewspace_points.grad of the reference, one slice per view), or None.  No object channels."""
     keep = _wants_backward(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation)
+    # `cache` (a RenderCache) + `cache_key` (one per tuple of cameras): a batch whose geometry inputs and cameras are unchanged
+    # since the key's last render re-uses that render's binning for all B views (gsr_ctx_rerender on the batch context)
+    slot = (cache, cache_key) if cache is not None else None
+    color_only = not (torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                       for t in (xyz, means2D, opacity, scaling, rotation)))
     return _RasterizeGaussiansRawBatch.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
-                                             list(settings_list), keep, grad_bucket, grad_norms)
+                                             list(settings_list), keep, grad_bucket, grad_norms, slot, color_only)
 
 
 def _wants_backward(*tensors) -> bool:

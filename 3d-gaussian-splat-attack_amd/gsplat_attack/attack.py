@@ -215,8 +215,8 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
                         at 1 M Gaussians) and later renders of it, the attack's and the success check's, run the colour
                         kernel and the compositor only.  Losses, flags and the saved model are bit for bit those of the
                         uncached loop (tests/test_gpu_rerender.py).
-      batched           (default on; device, fused path without object channels, a rank with two or more views, no kept
-                        binning) the rank's views go through ONE launch chain per iteration (render_batch ->
+      batched           (default on; device, fused path without object channels, a rank with two or more views) the rank's
+                        views go through ONE launch chain per iteration (render_batch ->
                         gsr_forward_raw_batch / gsr_backward_raw_batch_into): one scan, one depth sort, one emission, one tile
                         sort and one schedule for all of them, every SH row read once, and the 59 gradient floats per Gaussian
                         written once instead of read and rewritten per view.  Images bit for bit those of the per-view
@@ -255,10 +255,9 @@ def pgd_attack(model, cameras: Sequence, *, iters: int = 20, alpha: float = 0.5,
             and takes_fused_path(model, pipe)):
         from diff_gaussian_rasterization import RenderCache
         pipe.render_cache = RenderCache(max_entries=4 * max(len(mine), 1) + 8)      # pipe is this call's own copy here
-    # the rank's views through one launch chain (see `batched`); a colour-only attack with kept binning re-renders each camera
-    # from its kept context instead (two kernels per view), which a batch would redo
-    use_batch = bool(batched and dev.type == "cuda" and len(mine) >= 2 and getattr(pipe, "render_cache", None) is None
-                     and can_batch(mine, model, pipe))
+    # the rank's views through one launch chain (see `batched`)
+    # (a colour-only attack with kept binning keeps the BATCH's context: colour kernel + one compositor launch for all views)
+    use_batch = bool(batched and dev.type == "cuda" and len(mine) >= 2 and can_batch(mine, model, pipe))
     reduce_names = ("_features_dc", "_features_rest") if frozen else gdist.ATTACK_PARAMS
     running = {}                                           # accumulate_grads with world > 1: the running sums
     try:

@@ -222,7 +222,9 @@ def render_batch(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
     -> dict like render()'s with a leading view axis: render [B,3,H,W], viewspace_points [B,P,3] (a zero leaf whose .grad
     receives every view's screen-space gradient), radii [B,P], visibility_filter (lazy) [B,P]; render_object is a
     broadcast zero (no object channels: needs pipe.skip_objects).  Every image and radius is bit for bit render()'s for that
-    camera; the gradients are those of the B render() calls summed in view order."""
+    camera; the gradients are those of the B render() calls summed in view order.  With pipe.render_cache (a RenderCache)
+    the batch's context is kept under the tuple of cameras: a later batch of the same cameras whose geometry tensors are
+    unchanged (a colour attack) runs the batch's colour kernel and one compositor launch over the kept lists."""
     cams = list(cameras)
     if not can_batch(cams, pc, pipe):
         raise ValueError("render_batch needs the fused raw-parameter path without object channels (PipelineParams("
@@ -237,7 +239,9 @@ def render_batch(cameras, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0
         bucket = bucket()
     image, radii = rasterize_gaussians_raw_batch(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest, pc._opacity,
                                                  pc._scaling, pc._rotation, sts, grad_bucket=bucket,
-                                                 grad_norms=getattr(pipe, "grad_norms", None))
+                                                 grad_norms=getattr(pipe, "grad_norms", None),
+                                                 cache=getattr(pipe, "render_cache", None),
+                                                 cache_key=(getattr(pipe, "cache_tag", "view"), "batch") + tuple(id(c) for c in cams))
     objects = _zero_scalar(image.device).unsqueeze(0).expand(B, 16, image.shape[2], image.shape[3])
     return _result(image, screenspace_points, radii, objects)
 

@@ -223,7 +223,9 @@ int gsr_backward_raw_chunked(GsrCtx* ctx, const float* grad_color, const float* 
  * (accumulate == 0; Gaussians without pairs in any view: zeros) or added to what the buffers hold (accumulate != 0) -- bit
  * for bit what B calls of gsr_backward_raw_into in view order leave, the first with the caller's `accumulate` and the
  * others adding; dmeans2D [B,P,3] or NULL is per view (overwritten).  gsr_backward_raw / _into / _chunked accept a batch
- * context with these shapes too; gsr_ctx_rerender and gsr_ctx_request_sumsq do not. */
+ * context with these shapes too, and so do gsr_ctx_request_sumsq (the batch's one fused per-Gaussian launch leaves the sums
+ * of squares of the SUMMED gradient) and gsr_ctx_rerender (below: the batch's colour kernel + the compositor over the kept
+ * lists of all B views). */
 int gsr_forward_raw_batch(const GsrSettings* settings, int32_t B, int32_t P, const float* xyz, const float* features_dc,
                           const float* features_rest, const float* opacity_logit, const float* log_scaling,
                           const float* rotation_raw, float* out_color, int32_t* radii, GsrCtx** ctx_out,
@@ -289,6 +291,11 @@ int gsr_forward_raw2_keep(const GsrSettings* settings, int32_t Pa, const float* 
  *                  GSR_RERENDER_FIRST_SEGMENT_ONLY (two-segment contexts): the second segment's coefficients have not
  *                  changed since the context's last render (the frozen background of reference attack.py:513-530): the
  *                  colour kernel covers the first segment's Gaussians only; features_*_b must be NULL.
+ * A BATCH context (gsr_forward_raw_batch): out_color [B,3,H,W]; bg [B,3] (view v's background at bg + 3 v) or NULL = the
+ *                  views' previous background pointers, whose contents are read again; out_objects and features_*_b must
+ *                  be NULL.  One launch of the batch's colour kernel (every SH row read once for all views that see the
+ *                  Gaussian) and one compositor launch over the B views' kept lists: images and the gradients of a following
+ *                  gsr_backward_raw_batch_* are bit for bit those of a fresh gsr_forward_raw_batch with the same inputs.
  * The per-pixel state the backward reads (final T, last contributor, segment-boundary records) is overwritten: a
  * backward of the PREVIOUS render of this context must have been enqueued before, on the same stream or ordered
  * before it by the caller. */
