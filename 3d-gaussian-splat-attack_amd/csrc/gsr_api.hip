@@ -807,6 +807,8 @@ static int forward_impl(const GsrSettings* s, int32_t P, int32_t K, const float*
     if (B > 1 && raw && batch_color_env != 0) {
       PreColorBatchArgs ca;
       ca.P = P; ca.B = B; ca.Ppad = Ppad; ca.deg = s->sh_degree; ca.vpack = c->vpack; ca.means = means3D; ca.sh = shs; ca.sh_dc = sh_dc;
+      ca.Pa = segb ? P - segb->Pb : P; ca.means_b = segb ? segb->xyz : nullptr;
+      ca.sh_b = segb ? segb->features_rest : nullptr; ca.sh_dc_b = segb ? segb->features_dc : nullptr;
       ca.tcnt = tcnt; ca.offg = nullptr; ca.G1 = G1; ca.G2 = G2; ca.D = c->D;
       hipLaunchKernelGGL(k_pre_color_batch, gridC, blkCol, 0, cs, ca);
     } else {
@@ -1140,6 +1142,38 @@ int gsr_forward_raw_batch(const GsrSettings* s, int32_t B, int32_t P, const floa
                       nullptr, out_color, nullptr, radii, ctx_out, num_rendered, stream, true, nullptr, false, B);
 }
 
+// gsr_forward_raw_batch for TWO parameter sets as one scene per view (the success renders of a batch, reference
+// attack.py:513-530 inside the loop over the batch's cameras): forward only; a kept context is re-renderable, not differentiable.
+int gsr_forward_raw2_batch(const GsrSettings* s, int32_t B, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                           const float* features_rest_a, const float* opacity_logit_a, const float* log_scaling_a,
+                           const float* rotation_raw_a, int32_t Pb, const float* xyz_b, const float* features_dc_b,
+                           const float* features_rest_b, const float* opacity_logit_b, const float* log_scaling_b,
+                           const float* rotation_raw_b, float* out_color, int32_t* radii, GsrCtx** ctx_out,
+                           int64_t* num_rendered, void* stream) {
+  if (ctx_out) *ctx_out = nullptr;
+  if (Pa <= 0 || Pb <= 0 || (long long)Pa + Pb > 0x7FFFFFFFll)
+    return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: both segments must hold Gaussians (Pa=%d Pb=%d)", Pa, Pb);
+  if (!s || B < 1 || B > MAX_BATCH) return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: 1..%d views, got %d", MAX_BATCH, B);
+  if (!xyz_a || !features_dc_a || !features_rest_a || !opacity_logit_a || !log_scaling_a || !rotation_raw_a || !xyz_b ||
+      !features_dc_b || !features_rest_b || !opacity_logit_b || !log_scaling_b || !rotation_raw_b)
+    return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: null parameter tensor");
+  for (int v = 0; v < B; ++v) {
+    if (!s[v].bg || !s[v].viewmatrix || !s[v].projmatrix || !s[v].campos)
+      return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: view %d: settings tensors (bg, viewmatrix, projmatrix, campos) must be device pointers", v);
+    if (s[v].image_height != s[0].image_height || s[v].image_width != s[0].image_width || s[v].scale_modifier != s[0].scale_modifier ||
+        s[v].sh_degree != s[0].sh_degree || s[v].flags != s[0].flags)
+      return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: view %d differs from view 0 in image size, scale modifier, SH degree or "
+                     "flags (a batch shares them)", v);
+  }
+  if (s[0].flags & GSR_FLAG_NEEDLE_DOUBLE) return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: GSR_FLAG_NEEDLE_DOUBLE is a single-view flag");
+  if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_forward_raw2_batch: out_color is null");
+  SegB b;
+  b.Pb = Pb; b.xyz = xyz_b; b.features_dc = features_dc_b; b.features_rest = features_rest_b; b.objects_dc = nullptr;
+  b.opacity = opacity_logit_b; b.scaling = log_scaling_b; b.rotation = rotation_raw_b;
+  return forward_impl(s, Pa + Pb, 16, xyz_a, features_rest_a, features_dc_a, nullptr, nullptr, opacity_logit_a, log_scaling_a,
+                      rotation_raw_a, nullptr, out_color, nullptr, radii, ctx_out, num_rendered, stream, true, &b, true, B);
+}
+
 // Re-render of a kept context whose colour inputs (SH coefficients) may have changed and nothing else has: the colour
 // half of K1 over the Gaussians that emit pairs, then K6 over the kept lists.  include/gsraster.h has the contract.
 int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_rest, const float* features_dc_b,
@@ -1148,8 +1182,8 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
   if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_rerender: null context");
   if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: out_color is null");
   // a batch context (gsr_forward_raw_batch): out_color [B,3,H,W], bg [B,3] or null; no object channels, one attribute segment
-  if (c->B > 1 && (out_objects || features_dc_b || features_rest_b))
-    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: a batch context (%d views) has no object channels and one attribute segment", c->B);
+  if (c->B > 1 && out_objects)
+    return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: a batch context (%d views) has no object channels", c->B);
   if (c->P > 0 && (!c->lanegroup || !c->shs))
     return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: the context was not rendered from SH coefficients (raw parameters, "
                    "or shs with K = 16): there is no colour stage to run again");
@@ -1194,10 +1228,14 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
     PreColorBatchArgs ca;
     ca.P = c->P; ca.B = c->B; ca.Ppad = c->Ppad; ca.deg = c->st.sh_degree; ca.vpack = c->vpack; ca.means = c->means3D;
     ca.sh = c->shs; ca.sh_dc = c->sh_dc; ca.tcnt = nullptr; ca.offg = c->offg; ca.G1 = c->G1; ca.G2 = c->G2;
+    ca.Pa = c->has_b ? c->P - c->b.Pb : c->P; ca.means_b = c->has_b ? c->b.xyz : nullptr;
+    ca.sh_b = c->has_b ? c->b.features_rest : nullptr; ca.sh_dc_b = c->has_b ? c->b.features_dc : nullptr;
+    // two segments, the second one's coefficients untouched since the last render: its colour words are still right
+    if (c->has_b && (flags & GSR_RERENDER_FIRST_SEGMENT_ONLY)) ca.P = ca.Pa;
     const bool skip_D = (flags & GSR_RERENDER_COLOR_GRADS_ONLY) != 0u;
     ca.D = skip_D ? nullptr : c->D;
     c->D_stale = c->D != nullptr && skip_D;
-    const dim3 gridC((unsigned)((c->P + PREF_BLOCK - 1) / PREF_BLOCK)), blkC(PREF_BLOCK);
+    const dim3 gridC((unsigned)((ca.P + PREF_BLOCK - 1) / PREF_BLOCK)), blkC(PREF_BLOCK);
     hipLaunchKernelGGL(k_pre_color_batch, gridC, blkC, 0, st, ca);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(GSR_ERR_DEVICE, "rerender colours (batch): launch failed: %s", hipGetErrorString(e));

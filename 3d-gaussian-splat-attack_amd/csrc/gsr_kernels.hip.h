@@ -1941,6 +1941,10 @@ struct PreColorBatchArgs {
   const float* means;
   const float* sh;        // _features_rest [P,15,3]
   const float* sh_dc;     // _features_dc [P,1,3]
+  int Pa;                 // Gaussians g >= Pa live in the second attribute segment (gsr_forward_raw2_batch); == P: one segment
+  const float* means_b;
+  const float* sh_b;
+  const float* sh_dc_b;
   const uint32_t* tcnt;   // [B * Ppad] tiles touched by (view, Gaussian)
   const uint32_t* offg;   // tcnt == null (re-render of a kept batch context): (view, Gaussian) emits pairs iff
                           // offg[i + 1] != offg[i], i = view * Ppad + g (the storage-order scan the context keeps)
@@ -1976,7 +1980,10 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color_batch(PreColorBatchArg
     if (ok) {
       const int si = __popcll(live & ((1ull << lane) - 1ull));
       float* sl = ws + 4 * si;
-      sl[0] = a.means[3 * g]; sl[1] = a.means[3 * g + 1]; sl[2] = a.means[3 * g + 2]; sl[3] = __uint_as_float((uint32_t)g);
+      const bool second = g >= a.Pa;
+      const int gl = second ? g - a.Pa : g;
+      const float* means = second ? a.means_b : a.means;
+      sl[0] = means[3 * gl]; sl[1] = means[3 * gl + 1]; sl[2] = means[3 * gl + 2]; sl[3] = __uint_as_float((uint32_t)g);
       wm[si] = seen;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1990,7 +1997,8 @@ __global__ void __launch_bounds__(PREF_BLOCK) k_pre_color_batch(PreColorBatchArg
         const uint32_t gg = __float_as_uint(slv.w);
         const uint32_t mv = wm[si];
         float sv[12];
-        load_sh12<true>(a.sh, a.sh_dc, gg, q, sv);
+        if (gg >= (uint32_t)a.Pa) load_sh12<true>(a.sh_b, a.sh_dc_b, gg - (uint32_t)a.Pa, q, sv);
+        else load_sh12<true>(a.sh, a.sh_dc, gg, q, sv);
 #pragma unroll 1
         for (int v = 0; v < a.B; ++v) {
           if (!((mv >> v) & 1u)) continue;

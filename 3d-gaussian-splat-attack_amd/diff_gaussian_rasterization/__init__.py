@@ -137,6 +137,10 @@ def _load():
         lib.gsr_backward_raw_batch_into.argtypes = [vp] * 9 + [i32, vp]
         lib.gsr_backward_raw_batch_views.restype = ctypes.c_int
         lib.gsr_backward_raw_batch_views.argtypes = [vp] * 9 + [ctypes.c_int64, vp]
+    if hasattr(lib, "gsr_forward_raw2_batch"):
+        lib.gsr_forward_raw2_batch.restype = ctypes.c_int
+        lib.gsr_forward_raw2_batch.argtypes = ([ctypes.POINTER(_CSettings), i32, i32] + [vp] * 6 + [i32] + [vp] * 6
+                                               + [vp, vp, ctypes.POINTER(vp), i64p, vp])
     lib.gsr_ctx_rerender.restype = ctypes.c_int
     lib.gsr_ctx_rerender.argtypes = [vp] * 8 + [ctypes.c_uint32, vp]
     lib.gsr_ctx_free.restype = None
@@ -901,12 +905,13 @@ class _BatchPack:
     """What a kept BATCH context's cache entry holds on to: the views' settings packs (their device tensors are what the
     context's pointers point into), the radii of the key's first render, and -- once a render came with other background
     tensors than the forward's -- the [B,3] tensor of background values the context reads instead."""
-    __slots__ = ("packs", "radii", "bg_src", "bgt")
+    __slots__ = ("packs", "radii", "bg_src", "bgt", "b_sig", "last_inputs")
 
     def __init__(self, packs, radii):
         self.packs, self.radii = packs, radii
         self.bg_src = tuple(pk.bg.data_ptr() for pk in packs)
         self.bgt = None
+        self.b_sig = self.last_inputs = None      # (pair batches: the second model's coefficient versions, the inputs in flight)
 
 
 class _RasterizeGaussiansRawBatch(torch.autograd.Function):
@@ -1261,6 +1266,97 @@ def rasterize_gaussians_raw2(params_a, params_b, raster_settings, objects: bool 
     if rc != 0:
         raise (Exception if rc == 1 else PairCapacityExceeded if rc == GSR_ERR_OVERFLOW else RuntimeError)(_err(lib))
     return color, radii, objs
+
+
+@torch.no_grad()
+def rasterize_gaussians_raw2_batch(params_a, params_b, settings_list, cache: Optional["RenderCache"] = None, cache_key=None):
+    """rasterize_gaussians_raw2 for a BATCH of views through one launch chain (gsr_forward_raw2_batch): the success renders
+    of a batch of cameras (reference attack.py:513-530 renders the combined scene once per camera).  `params_*`: (xyz,
+    features_dc, features_rest, opacity, scaling, rotation), RAW tensors, both non-empty.  -> (color[B,3,H,W],
+    radii[B,Pa+Pb]); every image bit for bit rasterize_gaussians_raw2's for that view.  No object channels, not
+    differentiable.  With a cache the batch's context is kept: while both models' geometry and the cameras are unchanged a
+    render is the batch's colour kernel -- over the first model's Gaussians only while the second model's coefficient
+    tensors are untouched -- and one compositor launch."""
+    lib = _load()
+    xa = params_a[0]
+    if not xa.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization: tensors must live on a HIP device; there is no CPU path")
+    device = xa.device
+    B = len(settings_list)
+    if not 1 <= B <= MAX_BATCH:
+        raise ValueError(f"a batch holds 1..{MAX_BATCH} views, got {B}")
+    a = [_f32c(t.detach(), device) for t in params_a]
+    b = [_f32c(t.detach(), device) for t in params_b]
+    Pa, Pb = int(a[0].shape[0]), int(b[0].shape[0])
+    if Pa == 0 or Pb == 0:
+        raise ValueError("rasterize_gaussians_raw2_batch needs two non-empty models")
+    for P, (x, dc, rest, op, sc, ro) in ((Pa, a), (Pb, b)):
+        if tuple(dc.shape) != (P, 1, 3) or tuple(rest.shape) != (P, 15, 3):
+            raise ValueError("fused path needs _features_dc [P,1,3] and _features_rest [P,15,3] (SH degree 3 storage)")
+    H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+    packs = [_SettingsPack(rs, device) for rs in settings_list]
+    carr = (_CSettings * B)()
+    for v, pk in enumerate(packs):
+        carr[v] = pk.c
+    color = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
+    nren = ctypes.c_int64(0)
+    entry = sig = refs = None
+    if cache is not None:
+        geo = tuple(params_a[i] for i in (0, 3, 4, 5)) + tuple(params_b[i] for i in (0, 3, 4, 5))
+        used = (a[0], a[3], a[4], a[5], b[0], b[3], b[4], b[5])
+        if all(t.data_ptr() == u.data_ptr() for t, u in zip(geo, used)):
+            extra = ["pair-batch", B]
+            for rs in settings_list[1:]:
+                extra += [float(rs.tanfovx), float(rs.tanfovy)]
+                for t in (rs.viewmatrix, rs.projmatrix, rs.campos):
+                    extra += [t.data_ptr(), t._version]
+            sig = _cache_sig(geo, settings_list[0], extra=extra)
+            refs = geo + tuple(t for rs in settings_list for t in (rs.viewmatrix, rs.projmatrix, rs.campos))
+            entry, _ = cache._lookup(cache_key, sig, refs)       # forward-only contexts are never busy
+    b_dense = params_b[1].data_ptr() == b[1].data_ptr() and params_b[2].data_ptr() == b[2].data_ptr()
+    b_sig = tuple((t.data_ptr(), t._version) for t in (params_b[1], params_b[2])) if b_dense else None
+    with torch.cuda.device(device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        if entry is not None:
+            _entry_enter(entry, device)
+            bp = entry.pack
+            radii = bp.radii.detach()
+            ptrs = tuple(pk.bg.data_ptr() for pk in packs)
+            bgt = None
+            if ptrs != bp.bg_src or bp.bgt is not None:
+                bgt = torch.stack([pk.bg[:3] for pk in packs]).contiguous()
+                bp.bgt, bp.bg_src = bgt, ptrs
+            # the second model is the frozen background: while its coefficient tensors are those of the entry's last render,
+            # unmodified, the colour kernel covers the first model's Gaussians only
+            if b_sig is not None and bp.b_sig == b_sig:
+                rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(a[1]), _ptr(a[2]), None, None, _ptr(bgt), _ptr(color), None,
+                                          1 | 2, stream)
+            else:
+                rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(a[1]), _ptr(a[2]), _ptr(b[1]), _ptr(b[2]), _ptr(bgt),
+                                          _ptr(color), None, 1, stream)
+            bp.b_sig = b_sig
+            bp.last_inputs = (a, b, packs)             # read on the stream: referenced until the next render
+            entry.gen += 1
+            if rc == GSR_ERR_OVERFLOW:
+                cache.entries.pop(cache_key, None)
+                cache.dropped_overflow += 1
+                entry = None
+        if entry is None:
+            radii = torch.empty(B, Pa + Pb, dtype=torch.int32, device=device)
+            handle = ctypes.c_void_p(None)
+            rc = lib.gsr_forward_raw2_batch(carr, B, Pa, *[_ptr(t) for t in a], Pb, *[_ptr(t) for t in b], _ptr(color),
+                                            _ptr(radii), ctypes.byref(handle) if sig is not None else None, ctypes.byref(nren),
+                                            stream)
+            if rc == 0 and handle.value:
+                bp = _BatchPack(packs, radii)
+                bp.b_sig, bp.last_inputs = b_sig, (a, b, packs)
+                entry = _CacheEntry(_CtxHolder(lib, handle), sig, tuple(weakref.ref(t) for t in refs), bp, nren.value)
+                cache._store(cache_key, entry)
+        if entry is not None and rc == 0:
+            _entry_leave(entry, device)
+    if rc != 0:
+        raise (Exception if rc == 1 else PairCapacityExceeded if rc == GSR_ERR_OVERFLOW else RuntimeError)(_err(lib))
+    return color, radii
 
 
 def rasterize_gaussians(means3D, means2D, sh, sh_objs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

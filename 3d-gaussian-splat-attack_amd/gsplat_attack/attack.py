@@ -32,7 +32,8 @@ from torch import nn
 from . import dist as gdist
 from . import pgd
 from .streams import StreamRing
-from .renderer import PipelineParams, can_batch, render, render_batch, render_pair, takes_fused_path
+from .renderer import (PipelineParams, _has_raw_layout, can_batch, render, render_batch, render_pair, render_pair_batch,
+                       takes_fused_path)
 
 GROUPS = ("color", "position", "scaling", "rotation", "opacity")
 
@@ -605,13 +606,23 @@ def render_combined(attacked, background, cameras: Sequence, bg: torch.Tensor, p
     parameter sets go to the rasteriser side by side (render_pair -> gsr_forward_raw2): no deep copy of the model, no
     concatenation of its seven tensors per PGD iteration.  background None: the target alone."""
     pipe = pipe or PipelineParams(skip_objects=True)
+    cams = list(cameras)
+    # two or more cameras without object channels: ONE launch chain for all of them (render_batch / render_pair_batch), every
+    # image bit for bit the per-camera render's; `batched_checks=False` on the pipe keeps the per-camera loop (A/B, tests)
+    batch = (len(cams) >= 2 and bool(getattr(pipe, "batched_checks", True)) and attacked.get_xyz.is_cuda
+             and can_batch(cams, attacked, pipe))
     if background is None:
         if getattr(pipe, "render_cache", None) is not None:
             pipe = copy.copy(pipe)
             pipe.cache_tag = "check"      # its own kept contexts: the attack's forward of the same camera may run beside it
         with torch.no_grad():
-            return [render(cam, attacked, pipe, bg)["render"] for cam in cameras]
-    return [render_pair(cam, attacked, background, pipe, bg)["render"] for cam in cameras]
+            if batch:
+                return list(render_batch(cams, attacked, pipe, bg)["render"].unbind(0))
+            return [render(cam, attacked, pipe, bg)["render"] for cam in cams]
+    if (batch and _has_raw_layout(attacked) and _has_raw_layout(background) and attacked.get_xyz.shape[0] > 0
+            and background.get_xyz.shape[0] > 0):
+        return list(render_pair_batch(cams, attacked, background, pipe, bg)["render"].unbind(0))
+    return [render_pair(cam, attacked, background, pipe, bg)["render"] for cam in cams]
 
 
 def main():

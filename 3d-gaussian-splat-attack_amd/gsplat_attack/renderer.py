@@ -12,7 +12,8 @@ import math
 import torch
 
 from diff_gaussian_rasterization import (MAX_BATCH, GaussianRasterizationSettings, GaussianRasterizer, _zero_scalar,
-                                         rasterize_gaussians_raw, rasterize_gaussians_raw2, rasterize_gaussians_raw_batch)
+                                         rasterize_gaussians_raw, rasterize_gaussians_raw2, rasterize_gaussians_raw2_batch,
+                                         rasterize_gaussians_raw_batch)
 
 from .sh import eval_sh
 
@@ -50,6 +51,9 @@ class PipelineParams:
         # extension (default None): a diff_gaussian_rasterization.GradNorms -- the fused path's backward leaves the sums of
         # squares of the gradients it writes there, for the L2 step rules (no second pass over the gradient)
         self.grad_norms = grad_norms
+        # extension (default on; same bits either way): the success renders of two or more cameras (attack.render_combined)
+        # go through one launch chain (render_batch / render_pair_batch) instead of one forward per camera
+        self.batched_checks = True
 
 
 def _has_raw_layout(pc) -> bool:
@@ -262,4 +266,26 @@ def render_pair(viewpoint_camera, pc_a, pc_b, pipe, bg_color: torch.Tensor, scal
                                                      objects=not bool(getattr(pipe, "skip_objects", False)),
                                                      cache=getattr(pipe, "render_cache", None),
                                                      cache_key=("pair", id(viewpoint_camera)))
+    return _result(image, None, radii, objects)
+
+
+@torch.no_grad()
+def render_pair_batch(cameras, pc_a, pc_b, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
+    """render_pair() of a BATCH of cameras through one launch chain (gsr_forward_raw2_batch): the success renders of the
+    attack's batch (reference attack.py:513-530, once per camera of :476-485).  -> dict with a leading view axis like
+    render_batch()'s, `viewspace_points` None; every image bit for bit render_pair()'s for that camera.  Needs
+    pipe.skip_objects (no object channels in a batch), one image size, 1..MAX_BATCH cameras."""
+    cams = list(cameras)
+    if not (_has_raw_layout(pc_a) and _has_raw_layout(pc_b)):
+        raise ValueError("render_pair_batch needs two models in the reference's raw storage layout on a HIP device")
+    if not can_batch(cams, pc_a, pipe):
+        raise ValueError("render_pair_batch needs PipelineParams(skip_objects=True), one image size and "
+                         f"1..{MAX_BATCH} cameras")
+    sts = [_settings(cam, pc_a, pipe, bg_color, scaling_modifier) for cam in cams]
+
+    def raw(pc):
+        return (pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling, pc._rotation)
+    image, radii = rasterize_gaussians_raw2_batch(raw(pc_a), raw(pc_b), sts, cache=getattr(pipe, "render_cache", None),
+                                                  cache_key=("pair", "batch") + tuple(id(c) for c in cams))
+    objects = _zero_scalar(image.device).unsqueeze(0).expand(len(cams), 16, image.shape[2], image.shape[3])
     return _result(image, None, radii, objects)

@@ -186,7 +186,8 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
                # first render and re-used while the geometry tensors are untouched (gsr_ctx_rerender); same bits
                "binning_kept": bool(cache_binning and tuple(groups) == ("color",)),
                # all-attribute attacks on two or more views: the views of an iteration go through one launch chain
-               "views_batched": bool(batched and len(views) >= 2 and not (cache_binning and tuple(groups) == ("color",)))}
+               # (a colour attack's batch keeps ITS context: the batch's colour kernel + one compositor launch per render)
+               "views_batched": bool(batched and len(views) >= 2)}
         if n_streams == 1:
             # phase split on one stream: HIP events at the phase boundaries + the library's own stage events
             tm = PhaseTimer()
@@ -219,10 +220,15 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         "cfg3_rebinned_every_render": measure("config 3 with every render running the whole forward (cache_binning=False): "
                                               "what a rasteriser without kept contexts does", cams[:1], ("color",), 20, 1, True,
                                               cache_binning=False),
-        "cfg3_8views": measure("config 3's colour attack on a batch of 8 views over 4 streams, binning kept", cams[:8],
-                               ("color",), 6, max(args.streams, 1), True),
-        "cfg3_8views_rebinned_every_render": measure("the same, every render the whole forward", cams[:8], ("color",), 6,
-                                                     max(args.streams, 1), True, cache_binning=False),
+        "cfg3_8views": measure("config 3's colour attack on a batch of 8 views: the views as ONE batch whose binning is kept "
+                               "(gsr_ctx_rerender on the batch context: one colour kernel reading every SH row once + one "
+                               "compositor launch per render, one backward composite, the SH gradients written once)", cams[:8],
+                               ("color",), 6, 1, True),
+        "cfg3_8views_per_view_contexts": measure("the same with one kept context and one render() + backward per view, the "
+                                                 "views dealt over 4 streams (round 5's form)", cams[:8], ("color",), 6,
+                                                 max(args.streams, 1), True, batched=False),
+        "cfg3_8views_rebinned_every_render": measure("the batch with every render the whole forward", cams[:8], ("color",), 6,
+                                                     1, True, cache_binning=False),
         "cfg4_one_gpu": measure("BASELINE config 4 on one GPU: 8 views per iteration, L2 on {colour, position, scaling, "
                                 "rotation, opacity}, one stream, the 8 views as ONE batch (gsr_forward_raw_batch)", cams[:8],
                                 ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False),

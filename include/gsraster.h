@@ -266,6 +266,18 @@ int gsr_forward_raw2_keep(const GsrSettings* settings, int32_t Pa, const float* 
                           float* out_color, float* out_objects, int32_t* radii, GsrCtx** ctx_out, int64_t* num_rendered,
                           void* stream);
 
+/* gsr_forward_raw2_keep for a BATCH of views: the attacked target (a) followed by the frozen background (b) rendered from B
+ * cameras through one launch chain -- the success renders of a batch of views (reference attack.py:513-530 renders the
+ * combined scene once per camera of the batch, inside the loop of :476-485).  Forward only: settings [B], out_color
+ * [B,3,H,W], radii [B,Pa+Pb], no object channels; Pa, Pb > 0.  Every image and radius is bit for bit gsr_forward_raw2's
+ * for that view.  A kept context serves gsr_ctx_rerender ONLY (gsr_backward* return GSR_ERR_STATE). */
+int gsr_forward_raw2_batch(const GsrSettings* settings, int32_t B, int32_t Pa, const float* xyz_a, const float* features_dc_a,
+                           const float* features_rest_a, const float* opacity_logit_a, const float* log_scaling_a,
+                           const float* rotation_raw_a, int32_t Pb, const float* xyz_b, const float* features_dc_b,
+                           const float* features_rest_b, const float* opacity_logit_b, const float* log_scaling_b,
+                           const float* rotation_raw_b, float* out_color, int32_t* radii, GsrCtx** ctx_out,
+                           int64_t* num_rendered, void* stream);
+
 /* Re-render of a kept context after ONLY its colour inputs changed.  A colour attack (reference attack.py:25-49 steps
  * _features_dc / _features_rest and nothing else; configs/config.yaml attack groups = ["color"]; BASELINE configs 2, 3)
  * renders the same cameras iteration after iteration with the same means, scales, rotations and opacities: projection,
@@ -292,8 +304,8 @@ int gsr_forward_raw2_keep(const GsrSettings* settings, int32_t Pa, const float* 
  *                  changed since the context's last render (the frozen background of reference attack.py:513-530): the
  *                  colour kernel covers the first segment's Gaussians only; features_*_b must be NULL.
  * A BATCH context (gsr_forward_raw_batch): out_color [B,3,H,W]; bg [B,3] (view v's background at bg + 3 v) or NULL = the
- *                  views' previous background pointers, whose contents are read again; out_objects and features_*_b must
- *                  be NULL.  One launch of the batch's colour kernel (every SH row read once for all views that see the
+ *                  views' previous background pointers, whose contents are read again; out_objects must be NULL
+ *                  (features_*_b and GSR_RERENDER_FIRST_SEGMENT_ONLY as above for a gsr_forward_raw2_batch context).  One launch of the batch's colour kernel (every SH row read once for all views that see the
  *                  Gaussian) and one compositor launch over the B views' kept lists: images and the gradients of a following
  *                  gsr_backward_raw_batch_* are bit for bit those of a fresh gsr_forward_raw_batch with the same inputs.
  * The per-pixel state the backward reads (final T, last contributor, segment-boundary records) is overwritten: a

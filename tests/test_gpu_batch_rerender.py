@@ -253,3 +253,68 @@ def test_full_size_batch_rerender_on_the_benchmark_scene():
             model._features_dc.add_(0.1)
             model._features_rest.mul_(1.05)
     assert cached.render_cache.hits == 1
+
+
+@pytest.mark.parametrize("Pa,Pb,W,H,B", [(20000, 30000, 320, 240, 3), (300, 70000, 400, 300, 5), (50000, 100, 256, 256, 2)])
+def test_pair_batch_equals_the_per_camera_pair_renders(Pa, Pb, W, H, B):
+    """render_pair_batch (gsr_forward_raw2_batch): target + background from B cameras through one launch chain -- images and
+    radii bit for bit render_pair's; through a cache, over colour steps of the target and then of the background too."""
+    from diff_gaussian_rasterization import RenderCache
+    from gsplat_attack.renderer import PipelineParams, render_pair, render_pair_batch
+    dev, model, cams, bg = _scene(Pa + Pb, W, H, B)
+    from gsplat_attack.gaussian_model import GaussianModel
+
+    def part(sl):
+        return GaussianModel.from_tensors(model._xyz[sl].detach().clone(), model._features_dc[sl].detach().clone(),
+                                          model._features_rest[sl].detach().clone(), model._scaling[sl].detach().clone(),
+                                          model._rotation[sl].detach().clone(), model._opacity[sl].detach().clone(),
+                                          model._objects_dc[sl].detach().clone(), sh_degree=model.max_sh_degree,
+                                          device=dev, requires_grad=False)
+    a, b = part(slice(0, Pa)), part(slice(Pa, Pa + Pb))
+    plain = PipelineParams(skip_objects=True)
+    cache = RenderCache()
+    cached = PipelineParams(skip_objects=True, render_cache=cache)
+    gen = torch.Generator().manual_seed(11)
+    for it in range(5):
+        want = [render_pair(c, a, b, plain, bg) for c in cams]
+        got = render_pair_batch(cams, a, b, plain, bg)
+        got_c = render_pair_batch(cams, a, b, cached, bg)
+        for v in range(B):
+            assert torch.equal(got["render"][v], want[v]["render"]), ("image", it, v)
+            assert torch.equal(got["radii"][v], want[v]["radii"]), ("radii", it, v)
+            assert torch.equal(got_c["render"][v], want[v]["render"]), ("cached image", it, v)
+            assert torch.equal(got_c["radii"][v], want[v]["radii"]), ("cached radii", it, v)
+        _step_colours(a, gen, dev)
+        if it >= 2:
+            _step_colours(b, gen, dev)                # the frozen background is not frozen any more: its colours are redone
+    assert cache.misses == 1 and cache.hits == 4
+
+
+@pytest.mark.parametrize("groups", [("color",), ("color", "position", "opacity")])
+def test_attack_with_batched_success_renders_equals_the_per_camera_checks(groups, tmp_path):
+    """pgd_attack with a background model: the success renders of the rank's views through render_pair_batch against one
+    render_pair per camera (PipelineParams.batched_checks): bit-equal history, flags, what the success function saw."""
+    from gsplat_attack.attack import pgd_attack
+    from gsplat_attack.renderer import PipelineParams
+    dev, model, cams, bg = _scene(8000, 160, 128, 3)
+    base, back = model.clone(), model.clone()
+    with torch.no_grad():
+        back._xyz.add_(torch.tensor([0.05, -0.02, 0.1], device=dev))
+    runs = []
+    for batched_checks in (False, True):
+        m = base.clone()
+        calls = []
+
+        def success(im, i, calls=calls):
+            calls.append(float(im.double().sum()))
+            return len(calls) > 3 * len(cams)
+        recs = []
+        pipe = PipelineParams(skip_objects=True)
+        pipe.batched_checks = batched_checks
+        hist = pgd_attack(m, cams, iters=6, groups=groups, success_fn=success, background=back, log=recs.append, pipe=pipe)
+        torch.cuda.synchronize()
+        runs.append((hist, [r.get("successes") for r in recs], calls, {n: getattr(m, n).detach().clone() for n in ALL}))
+    (h0, f0, c0, p0), (h1, f1, c1, p1) = runs
+    assert len(h0) == 4 and h0 == h1 and f0 == f1 and c0 == c1
+    for n in ALL:
+        assert torch.equal(p0[n], p1[n]), n
