@@ -167,10 +167,14 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
     det = SurrogateDetector().to(dev)
     never = lambda im, i: False                            # noqa: E731 -- the success check runs, the loop never stops on it
 
-    def measure(name, views, groups, iters, n_streams, rerender, cache_binning=True, batched=True):
+    def measure(name, views, groups, iters, n_streams, rerender, cache_binning=True, batched=True, checks_batched=True):
         m = model.clone()
         kw = dict(groups=groups, loss_fn=det, streams=n_streams, alpha=0.5, epsilon=5.0, cache_binning=cache_binning,
                   batched=batched)
+        if not checks_batched:
+            from gsplat_attack.renderer import PipelineParams
+            kw["pipe"] = PipelineParams(skip_objects=True)
+            kw["pipe"].batched_checks = False
         if rerender:
             kw.update(success_fn=never, background=None)
         pgd_attack(m, views, iters=3, **kw)                # warm-up
@@ -187,7 +191,8 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
                "binning_kept": bool(cache_binning and tuple(groups) == ("color",)),
                # all-attribute attacks on two or more views: the views of an iteration go through one launch chain
                # (a colour attack's batch keeps ITS context: the batch's colour kernel + one compositor launch per render)
-               "views_batched": bool(batched and len(views) >= 2)}
+               "views_batched": bool(batched and len(views) >= 2),
+               "success_renders_batched": bool(rerender and checks_batched and len(views) >= 2)}
         if n_streams == 1:
             # phase split on one stream: HIP events at the phase boundaries + the library's own stage events
             tm = PhaseTimer()
@@ -232,6 +237,13 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         "cfg4_one_gpu": measure("BASELINE config 4 on one GPU: 8 views per iteration, L2 on {colour, position, scaling, "
                                 "rotation, opacity}, one stream, the 8 views as ONE batch (gsr_forward_raw_batch)", cams[:8],
                                 ("color", "position", "scaling", "rotation", "opacity"), 6, 1, False),
+        "cfg4_one_gpu_with_success_renders": measure("config 4 on one GPU with the forward-only success render of every view "
+                                                     "after the step (reference attack.py:522-530; SURVEY 8d: B x (fwd + bwd) + B x "
+                                                     "fwd): the 8 success renders as ONE forward-only batch", cams[:8],
+                                                     ("color", "position", "scaling", "rotation", "opacity"), 6, 1, True),
+        "cfg4_one_gpu_with_success_renders_per_view": measure("the same with one forward per success render", cams[:8],
+                                                              ("color", "position", "scaling", "rotation", "opacity"), 6, 1,
+                                                              True, checks_batched=False),
         "cfg4_one_gpu_pipelined": measure("the same with the 8 views dealt over 4 streams, one render() per view", cams[:8],
                                           ("color", "position", "scaling", "rotation", "opacity"), 6, max(args.streams, 1), False,
                                           batched=False),
