@@ -53,3 +53,33 @@ for rep in range(3):
 assert D.pool_bytes() <= p0 * 1.3 + (64 << 20), (p0, D.pool_bytes())
 assert torch.cuda.memory_reserved() <= t0 * 1.3 + (256 << 20)
 print("batches flat: ok")
+
+# a colour attack on a batch with kept contexts (round 6, second session): the batch's re-render + colour-only backward and the
+# forward-only pair batch of the success renders, the colours stepped in place between iterations
+from gsplat_attack.renderer import render_pair_batch
+cache = D.RenderCache()
+cpipe = PipelineParams(skip_objects=True, viewspace_grad=False, render_cache=cache)
+for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+    getattr(model, n).requires_grad_(False)
+back = model.clone()
+gcb = gc.unsqueeze(0).expand(8, 3, H, W).contiguous()
+def run_colour(n):
+    for i in range(n):
+        model.zero_grad()
+        out = render_batch(cams, model, cpipe, bg)
+        out["render"].backward(gcb)
+        with torch.no_grad():
+            model._features_dc.add_(1e-3)
+            if i % 4 == 0:
+                render_pair_batch(cams, model, back, cpipe, bg)
+    torch.cuda.synchronize()
+run_colour(5)
+p0, t0 = D.pool_bytes(), torch.cuda.memory_reserved()
+for rep in range(3):
+    t = time.perf_counter(); run_colour(100); dt = time.perf_counter() - t
+    print(f"kept batch round {rep}: {100 * 8.0 / dt:7.1f} views/s (re-render + SH backward)  pool {D.pool_bytes() / 2**20:8.1f} MiB  "
+          f"torch reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB  cache hits {cache.hits} misses {cache.misses}", flush=True)
+assert D.pool_bytes() <= p0 * 1.3 + (64 << 20), (p0, D.pool_bytes())
+assert torch.cuda.memory_reserved() <= t0 * 1.3 + (256 << 20)
+assert cache.misses == 2
+print("kept batch flat: ok")
