@@ -1396,6 +1396,7 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
     pa.dscales = c->cov3d ? nullptr : dscales; pa.drots = c->cov3d ? nullptr : drotations;
     pa.dcov3d = c->cov3d ? dcov3D : nullptr;
     pa.accumulate = accumulate ? 1 : 0;
+    pa.vpack = nullptr; pa.Ppad = 0; pa.Pscene = P; pa.vstride = 0;
     if (c->raw && ((pa.dsh == nullptr) != (pa.dsh_dc == nullptr)))
       return done(set_err(GSR_ERR_INVALID, "gsr_backward_raw: dfeatures_dc and dfeatures_rest must both be given"));
     if (c->lanegroup && c->shs && geom && !c->D)
@@ -1446,7 +1447,20 @@ static int backward_impl(GsrCtx* c, const float* grad_color, const float* grad_o
           else hipLaunchKernelGGL((k_pre_bwd_batch<false, false>), gridB, blkB, lds, st, ba);
         }
       }
-      for (int v = 0; !batch_fused && ge > gb && v < c->B; ++v) {
+      // per-view gradients of a batch (gsr_backward_raw_batch_views): ONE launch whose grid.y is the view -- the B per-view
+      // launches' ramp-ups and tails happen once (GSR_BATCH_K9_VIEWS=0: one launch per view, the A/B form; same bits)
+      static const int views_one_launch = [] { const char* e = getenv("GSR_BATCH_K9_VIEWS"); return e ? atoi(e) : 1; }();
+      const bool views_fused = !batch_fused && view_stride != 0 && c->B > 1 && c->raw && c->lanegroup && views_one_launch != 0;
+      if (views_fused && ge > gb) {
+        pa.vpack = c->vpack; pa.Ppad = c->Ppad; pa.Pscene = P; pa.vstride = (long long)view_stride;
+        pa.accumulate = 0; pa.abc = nullptr;
+        pa.g0 = gb; pa.P = ge;
+        const dim3 gridV((unsigned)((ge - gb + PRE_BLOCK - 1) / PRE_BLOCK), (unsigned)c->B);
+        if (geom) hipLaunchKernelGGL((k_pre_bwd<true, true>), gridV, dim3(PRE_BLOCK), 0, st, pa);
+        else hipLaunchKernelGGL((k_pre_bwd<true, false>), gridV, dim3(PRE_BLOCK), 0, st, pa);
+        pa.vpack = nullptr;
+      }
+      for (int v = 0; !batch_fused && !views_fused && ge > gb && v < c->B; ++v) {
         const size_t o = (size_t)v * (size_t)c->Ppad;
         const bool acc_v = view_stride == 0 && (accumulate || v > 0);
         if (c->B > 1) {

@@ -1504,6 +1504,12 @@ struct PreBwdArgs {
   int needle_double;      // GSR_FLAG_NEEDLE_DOUBLE was set in the forward (generic k_preprocess_bwd recomputes the double chain)
   float* sumsq;           // k_pre_bwd<RAW = true, ., ACC = false> only, or null: [workgroups][SUMSQ_W] per-workgroup sums of
                           // squares of the gradients this launch writes, per attribute tensor (SUMSQ_* below)
+  // k_pre_bwd over ALL views of a batch context in one launch (per-view gradients, gsr_backward_raw_batch_views): grid.y =
+  // view; the per-view arrays of the virtual scene (offg, records, D) lie view * Ppad further, dmeans2D view * Pscene * 3,
+  // the attribute gradients view * vstride floats; the view's camera comes from vpack[view].  vpack == null: one view, `va`.
+  const ViewDev* vpack;
+  int Ppad, Pscene;
+  long long vstride;
 };
 // Slots of PreBwdArgs::sumsq / gsr_ctx_request_sumsq: the six tensors the reference's L2 steps normalise over (attack.py:
 // 53-119, 138-173: a global norm per tensor, _features_dc and _features_rest separately).
@@ -2076,6 +2082,21 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
   float* hand = &shand[wave * 64 * HAND_W];
   const int nw = min(64, a.P - gw0);                     // Gaussians this wave owns (may be <= 0)
   if (nw <= 0) return;
+  const int vw = a.vpack != nullptr ? (int)blockIdx.y : 0;
+  if (a.vpack != nullptr) {
+    // this workgroup's view of a batch: its slice of the virtual scene's arrays, its own output buffers (uniform offsets)
+    const size_t o = (size_t)vw * (size_t)a.Ppad;
+    const size_t vs = (size_t)vw * (size_t)a.vstride;
+    a.offg += o; a.G0 += REC * o; a.G1 += REC * o; a.G2 += REC * o;
+    if (a.D) a.D += 9 * o;
+    if (a.dmeans2D) a.dmeans2D += 3 * (size_t)vw * (size_t)a.Pscene;
+    if (a.dmeans3D) a.dmeans3D += vs;
+    if (a.dsh) a.dsh += vs;
+    if (a.dsh_dc) a.dsh_dc += vs;
+    if (a.dopac) a.dopac += vs;
+    if (a.dscales) a.dscales += vs;
+    if (a.drots) a.drots += vs;
+  }
   uint32_t o0 = 0, o1 = 0;
   if (g < a.P) { o0 = a.offg[g] * a.nsub; o1 = a.offg[g + 1] * a.nsub; }
   constexpr bool acc = ACC;
@@ -2196,7 +2217,12 @@ __global__ void __launch_bounds__(PRE_BLOCK) k_pre_bwd(PreBwdArgs a) {
         for (int c = 0; c < NUM_OBJ; ++c) a.dsh_objs[(size_t)g * NUM_OBJ + c] = acc_o[c];      // per view: never added to
       }
       View v;
-      load_view(v, a.va);
+      if (a.vpack != nullptr) {
+        const ViewDev& vd = a.vpack[vw];
+        make_view(v, vd.vm, vd.pm, vd.cam, a.va.H, a.va.W, vd.tanfovx, vd.tanfovy, a.va.mod, a.va.deg);
+      } else {
+        load_view(v, a.va);
+      }
       const float A = e0.z, B = e0.w, C = e1.x;
       // dL/d(pixel centre) = -(A mx + B my, B mx + C my); screen-space means are reported in NDC units
       const float dndcx = (float)(-((double)A * mx + (double)B * my) * (0.5 * (double)v.W));
