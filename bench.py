@@ -566,6 +566,13 @@ def main():
                     valu = {"bound": "fp32 VALU issue", "wave_instr_per_launch": round(n_valu),
                             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
                             "frac": round(ach / peak, 4), "launch_ms": round(per[dom]["avg_ms"] * vpl, 4)}
+                    if dom == "render_bwd":
+                        # what a kernel made of NOTHING but K7's strip-body instruction mix sustains on this chip at six
+                        # waves per SIMD (tests/ubench/valu_rate.hip `kmix`: 2 transcendentals, 1 min, 4 compares, 2 selects,
+                        # 23 mul / add / fma per strip evaluation; profiles/r06_valu_rate.txt)
+                        valu["mix_ceiling"] = 765.9
+                        valu["frac_of_mix_ceiling"] = round(ach / 765.9, 4)
+                        valu["mix_source"] = "profiles/r06_valu_rate.txt (K7 strip-body mix, 6 waves/SIMD)"
         except Exception as e:                             # noqa: BLE001
             traffic = None
             valu = None
