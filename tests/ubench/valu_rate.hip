@@ -32,6 +32,14 @@ __global__ void __launch_bounds__(64) k(float* out, int iters, float s) {
         if (MODE == 12) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
         if (MODE == 13) asm volatile("v_cmp_le_u32 s[20:21], %0, %1\n\ts_and_b64 s[22:23], s[20:21], vcc" : : "v"(a[i]), "v"(s) : "s20", "s21", "s22", "s23", "scc");
         if (MODE == 14) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[(i + 1) & 7]));
+        if (MODE == 15) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 16) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(s));
+        if (MODE == 17) asm volatile("v_cmp_le_i32 s[20:21], %0, %1" : : "v"(a[i]), "v"(s) : "s20", "s21");
+        if (MODE == 18) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 19) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 20) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 21) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        if (MODE == 22) { if (i & 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i])); else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(s)); }
       }
     }
   }
@@ -137,6 +145,14 @@ int main() {
     run<12>("v_sub_u32", wps);
     run<13>("v_cmp->sgpr + s_and", wps);
     run<14>("v_permlane32_swap", wps);
+    run<15>("v_min_u32", wps);
+    run<16>("v_cndmask_b32 (sgpr mask)", wps);
+    run<17>("v_cmp_le_i32 -> sgpr", wps);
+    run<18>("v_max_f32", wps);
+    run<19>("v_med3_f32", wps);
+    run<20>("v_sub_f32", wps);
+    run<21>("v_and_b32", wps);
+    run<22>("1 v_exp : 1 v_fma", wps);
     run_mix(wps);
   }
   return 0;
