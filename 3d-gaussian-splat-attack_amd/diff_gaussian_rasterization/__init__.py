@@ -720,7 +720,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         pack = _SettingsPack(raster_settings, device)
         color = torch.empty(3, H, W, dtype=torch.float32, device=device)
-        objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if obj is not None
+        # all-zero object features (the attack's combined scenes, reference scene/gaussian_model.py:528) composite to exactly
+        # zero: as on the classic surface, the forward then runs without the 16 object channels and hands back a broadcast
+        # zero; the context keeps the features for a backward that is given dL/dobjects
+        obj_zero = obj is not None and _objects_all_zero(obj, objects_dc)
+        with_obj = obj is not None and not obj_zero
+        if obj_zero:
+            pack.c.flags |= FLAG_OBJECTS_FOR_BACKWARD_ONLY
+        objects = (torch.empty(NUM_OBJECTS, H, W, dtype=torch.float32, device=device) if with_obj
                    else _zero_scalar(device).expand(NUM_OBJECTS, H, W))
         radii = None
         handle = ctypes.c_void_p(None)
@@ -730,7 +737,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             cache, key = cache_slot
             geo = (xyz, opacity, scaling, rotation, objects_dc if obj is not None else None)
             dense = all(a is None or a.data_ptr() == b.data_ptr() for a, b in zip(geo, (x, op, sc, ro, obj)))
-            sig = _cache_sig(geo, raster_settings) if dense else None
+            sig = _cache_sig(geo, raster_settings, extra=(obj_zero,)) if dense else None
             # identity (weak references) of the geometry AND the camera tensors: a new camera object that happens to get
             # the id, the addresses and the versions of a dead one is never mistaken for it
             geo = geo + (raster_settings.viewmatrix, raster_settings.projmatrix, raster_settings.campos)
@@ -745,7 +752,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 _entry_enter(entry, device)
                 radii = entry.pack.radii.detach()      # geometry is unchanged: so are the radii of the key's first render
                 rc = lib.gsr_ctx_rerender(entry.holder.handle, _ptr(dc), _ptr(rest), None, None, _ptr(pack.bg), _ptr(color),
-                                          _ptr(objects) if obj is not None else None, 1 if color_only else 0, stream)
+                                          _ptr(objects) if with_obj else None, 1 if color_only else 0, stream)
                 entry.gen += 1
                 nren.value = entry.nren
                 if rc == GSR_ERR_OVERFLOW:
@@ -759,7 +766,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 want_ctx = keep or (cache_slot is not None and P > 0 and sig is not None)
                 radii = torch.empty(P, dtype=torch.int32, device=device)
                 rc = lib.gsr_forward_raw(ctypes.byref(pack.c), P, _ptr(x), _ptr(dc), _ptr(rest), _ptr(obj), _ptr(op), _ptr(sc),
-                                         _ptr(ro), _ptr(color), _ptr(objects) if obj is not None else None, _ptr(radii),
+                                         _ptr(ro), _ptr(color), _ptr(objects) if with_obj else None, _ptr(radii),
                                          ctypes.byref(handle) if want_ctx else None,
                                          ctypes.byref(nren), stream)
         if rc != 0:
@@ -1476,3 +1483,75 @@ __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gau
            "rasterize_gaussians_raw2", "rasterize_gaussians_raw_batch", "MAX_BATCH", "GradBucketSet", "PairCapacityExceeded", "GradBucket", "GradNorms",
            "NUM_OBJECTS",
            "library_path", "profile", "profile_read", "pool_bytes", "trim_pool", "last_num_rendered", "export_state"]
+
+
+def _auto_patch_reference():
+    """GSR_PATCH_REFERENCE=1 in the environment: the reference's ``gaussian_renderer.render`` becomes this package's fused
+    ``gsplat_attack.renderer.render`` WITHOUT a line of the reference being edited and without a call to
+    ``gsplat_attack.patch_reference()``.  The module object of ``gaussian_renderer`` is given a subclass of
+    ``types.ModuleType`` whose attribute lookup answers ``render`` with the fused function once the reference has defined
+    its own -- so ``from gaussian_renderer import render`` (reference attack.py:20) and ``gaussian_renderer.render`` both
+    bind the fused one.  Two ways in, whichever comes first: the reference imports this package from INSIDE
+    ``gaussian_renderer/__init__.py`` (line 14), while that module is still being executed -- it is then in sys.modules
+    already and is re-classed on the spot; or this package was imported earlier (``scene/gaussian_model.py:17`` imports
+    ``simple_knn._C``, which loads the same library) -- then a meta-path finder re-classes ``gaussian_renderer`` right after
+    its own import has run.  Same signature, same returned dict (tests/test_golden_glue.py pins the fused function against
+    the EXECUTED reference one); the raw parameters go straight into the kernels: no activated copies, no 192 MB ``cat`` per
+    view, no PyTorch backward of the getters.  GSR_PATCH_MODULE names another module than ``gaussian_renderer``.  Off by
+    default: an installed package does not rebind a caller's functions unasked."""
+    if os.environ.get("GSR_PATCH_REFERENCE", "0") in ("", "0"):
+        return None
+    import importlib.abc
+    import importlib.util
+    import sys
+    import types
+    want = os.environ.get("GSR_PATCH_MODULE", "gaussian_renderer")
+
+    class _FusedRenderModule(types.ModuleType):
+        def __getattribute__(self, name):
+            if name == "render" and "render" in types.ModuleType.__getattribute__(self, "__dict__"):
+                from gsplat_attack.renderer import render as fused
+                return fused
+            return types.ModuleType.__getattribute__(self, name)
+
+    def reclass(module):
+        try:
+            if isinstance(module, types.ModuleType) and type(module) is not _FusedRenderModule:
+                module.__class__ = _FusedRenderModule
+        except TypeError:
+            pass
+
+    if want in sys.modules:                    # being imported right now (or imported already): re-class it on the spot
+        reclass(sys.modules[want])
+        return "reclassed"
+
+    class _Finder(importlib.abc.MetaPathFinder):
+        busy = False
+
+        def find_spec(self, fullname, path, target=None):
+            if fullname != want or _Finder.busy:
+                return None
+            _Finder.busy = True
+            try:
+                spec = importlib.util.find_spec(fullname)
+            finally:
+                _Finder.busy = False
+            if spec is None or spec.loader is None:
+                return None
+            inner = spec.loader
+
+            class _Loader(importlib.abc.Loader):
+                def create_module(self, spec_):
+                    return inner.create_module(spec_)
+
+                def exec_module(self, module):
+                    inner.exec_module(module)
+                    reclass(module)
+            spec.loader = _Loader()
+            return spec
+
+    sys.meta_path.insert(0, _Finder())
+    return "finder"
+
+
+_auto_patch_reference()

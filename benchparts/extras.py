@@ -110,8 +110,11 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
 
         dmodel = [model]
 
+        pipe_cur = [pipe_d]
+
         def dropin_steps(n, sts):
             m_ = dmodel[0]
+            pipe_d = pipe_cur[0]
             for s_ in (sts or []):
                 s_.wait_stream(torch.cuda.current_stream(dev))
             for i in range(n):
@@ -147,7 +150,13 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
         with torch.no_grad():
             dmodel[0]._objects_dc.zero_()
         rates_z, st_z = dropin_rates()
+        # GSR_PATCH_REFERENCE=1 (or gsplat_attack.patch_reference()): the reference's render() rebound to the fused one -- the raw
+        # parameters straight into the kernels, the reference's own pipe (objects on); same two models
+        pipe_cur[0] = PipelineParams(skip_objects=False)
+        rates_pz, st_pz = dropin_rates()
         dmodel[0] = model
+        rates_p, st_p = dropin_rates()
+        pipe_cur[0] = pipe_d
         extras["dropin"] = {"value": round(rates[0], 1), "sequential_views_per_s": round(rates[1], 1), "unit": "views/s",
                             "steps": n_d, "streams": len(streams) if streams else 1, "stages_ms": st_d,
                             "what": "render() on the classic surface with object channels on (--classic --objects): the "
@@ -158,7 +167,16 @@ def extras_and_pgd(args, D, dev, model, cams, pipe, bg, gc, streams):
                                 "what": "the same with every object feature zero, as in the attack's combined scenes "
                                         "(reference scene/gaussian_model.py:528): the binding finds that out once per tensor "
                                         "version and composites without the 16 object channels; image, object map (zeros) "
-                                        "and gradients equal the object variant's (tests/test_gpu_zero_objects.py)"}}
+                                        "and gradients equal the object variant's (tests/test_gpu_zero_objects.py)"},
+                            "env_patched": {
+                                "value": round(rates_p[0], 1), "sequential_views_per_s": round(rates_p[1], 1), "stages_ms": st_p,
+                                "zero_object_features": {"value": round(rates_pz[0], 1),
+                                                         "sequential_views_per_s": round(rates_pz[1], 1), "stages_ms": st_pz},
+                                "what": "the reference UNCHANGED but started with GSR_PATCH_REFERENCE=1 in the environment "
+                                        "(diff_gaussian_rasterization._auto_patch_reference rebinds gaussian_renderer.render "
+                                        "to the fused render(): raw parameters into the kernels, no activated copies, no "
+                                        "PyTorch backward of the getters; tests/test_auto_patch.py); object channels on as "
+                                        "the reference's render() asks, and the same with all-zero object features"}}
     if col_rate is not None:
         extras["sh_grads_only_ring_views_per_s"] = round(ring_rates[0], 1)
         extras["sh_grads_only_ring_binning_kept_views_per_s"] = round(ring_rates[1], 1)
