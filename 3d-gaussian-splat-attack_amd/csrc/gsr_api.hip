@@ -1181,7 +1181,7 @@ int gsr_ctx_rerender(GsrCtx* c, const float* features_dc, const float* features_
                      void* stream) {
   if (!c) return set_err(GSR_ERR_STATE, "gsr_ctx_rerender: null context");
   if (!out_color) return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: out_color is null");
-  // a batch context (gsr_forward_raw_batch): out_color [B,3,H,W], bg [B,3] or null; no object channels, one attribute segment
+  // a batch context (gsr_forward_raw_batch / gsr_forward_raw2_batch): out_color [B,3,H,W], bg [B,3] or null; no object channels
   if (c->B > 1 && out_objects)
     return set_err(GSR_ERR_INVALID, "gsr_ctx_rerender: a batch context (%d views) has no object channels", c->B);
   if (c->P > 0 && (!c->lanegroup || !c->shs))

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 600 /* 0.6.0: the batch entry points, gsr_pgd_step_multi */
+#define GSR_VERSION 601 /* 0.6.1: the batch entry points, gsr_pgd_step_multi; + gsr_forward_raw2_batch, gsr_ctx_rerender on batch contexts */
 #define GSR_NUM_OBJECTS 16 /* object-feature channels, reference scene/gaussian_model.py:52 */
 
 enum {
