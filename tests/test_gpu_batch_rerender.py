@@ -318,3 +318,18 @@ def test_attack_with_batched_success_renders_equals_the_per_camera_checks(groups
     assert len(h0) == 4 and h0 == h1 and f0 == f1 and c0 == c1
     for n in ALL:
         assert torch.equal(p0[n], p1[n]), n
+
+
+def test_full_size_pair_batch_on_the_benchmark_scene():
+    """S-nyc-1M plus a shifted copy of itself as the background (2 M Gaussians per view), four ring cameras at 1080p: the pair
+    batch's images and radii are bit for bit the four render_pair calls'."""
+    from gsplat_attack.renderer import PipelineParams, render_pair, render_pair_batch
+    dev, model, cams, bg = _scene(None, None, None, 4, key="nyc-1M")
+    back = model.clone()
+    with torch.no_grad():
+        back._xyz.add_(torch.tensor([0.3, 0.1, -0.2], device=dev))
+        pipe = PipelineParams(skip_objects=True)
+        got = render_pair_batch(cams, model, back, pipe, bg)
+        for v, c in enumerate(cams):
+            want = render_pair(c, model, back, pipe, bg)
+            assert torch.equal(got["render"][v], want["render"]) and torch.equal(got["radii"][v], want["radii"]), v
